@@ -1,0 +1,129 @@
+/*
+ * ttscale.h -- C ABI of libttscale.so: yuv420p 8-bit scale / crop / pad on MI355X.
+ *
+ * The reference has no FFI for this path: its boundary is the argv of an external
+ * `ffmpeg` process.  Each entry point below therefore replaces one
+ * piece of that process boundary and cites the reference line that drives it.
+ * Plain pointers and sizes only; no torch / C++ types cross this header.
+ * All functions return 0 on success or a negative tts_status; nothing throws.
+ */
+#ifndef TTSCALE_H
+#define TTSCALE_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef enum tts_status {
+    TTS_OK = 0,
+    TTS_ERR_INVALID_INPUT = -1,         /* web spec string INVALID_INPUT  (compression.test.js:62-90) */
+    TTS_ERR_INVALID_FORMAT = -2,        /* INVALID_FORMAT: filter string not understood */
+    TTS_ERR_INITIALIZATION_FAILED = -3, /* INITIALIZATION_FAILED: no HIP device / allocation failed */
+    TTS_ERR_PROCESSING_FAILED = -4,     /* PROCESSING_FAILED: launch or copy failed */
+    TTS_ERR_UNSUPPORTED = -5            /* geometry outside what the kernels cover */
+} tts_status;
+
+enum { TTS_ALG_BICUBIC = 0, TTS_ALG_AREA = 1, TTS_ALG_BILINEAR = 2 };
+enum { TTS_MEM_DEVICE = 0, TTS_MEM_HOST = 1 };
+
+/*
+ * Resolved geometry of one filter chain, in luma pixels of a yuv420p frame:
+ *   [crop] -> [scale] -> [crop] -> [pad]   (every stage optional)
+ * Produced by tts_parse_vf() or filled in by hand.
+ */
+typedef struct tts_geom {
+    int32_t in_w, in_h;                       /* source frame */
+    int32_t pre_x, pre_y, pre_w, pre_h;       /* crop applied before scale (whole frame if none) */
+    int32_t do_scale, alg;                    /* scale stage present; TTS_ALG_* */
+    int32_t sc_w, sc_h;                       /* (virtual) scaled size */
+    int32_t crop_x, crop_y, crop_w, crop_h;   /* crop applied after scale (whole scaled frame if none) */
+    int32_t do_pad, pad_x, pad_y;             /* pad stage present; where the picture sits */
+    int32_t out_w, out_h;                     /* final frame size */
+    int32_t fill_y, fill_u, fill_v;           /* pad colour */
+} tts_geom;
+
+/* One yuv420p frame: Y, U, V plane pointers and byte strides. */
+typedef struct tts_frame {
+    void   *plane[3];
+    int32_t stride[3];
+    int32_t width, height;
+    int32_t mem;                               /* TTS_MEM_DEVICE or TTS_MEM_HOST */
+} tts_frame;
+
+typedef struct tts_plan tts_plan;
+
+/*
+ * Parse a `-vf` chain exactly as the reference writes them and resolve it for an
+ * iw x ih input.  Replaces libavfilter's option parsing for:
+ *   scripts/processVideos.js:94-97   `.size('720x1280')` -> "scale=w=720:h=1280"
+ *   src/services/video.js:329-332    "scale=320x180:force_original_aspect_ratio=decrease,
+ *                                     pad=320x180:-1:-1:color=black,format=yuv420p"
+ *   web/src/tests/video/portrait.test.js:78,95-96,146  "scale=W:H", "min(720,...", decrease
+ * Accepted filters: scale, crop, pad, format=yuv420p.
+ */
+int tts_parse_vf(const char *vf, int iw, int ih, tts_geom *out);
+
+/*
+ * Build the per-geometry state on the current HIP device (coefficient tables in HBM).
+ * Replaces sws_getContext()/sws_init_context() inside the ffmpeg child that
+ * scripts/processVideos.js:108 (`.save()`) and src/services/video.js:334 spawn.
+ * The plan is immutable afterwards and may be shared between host threads.
+ */
+int tts_plan_create(const tts_geom *g, tts_plan **out);
+void tts_plan_destroy(tts_plan *p);
+int tts_plan_geom(const tts_plan *p, tts_geom *out);
+
+/*
+ * Run n_frames frames through the plan, asynchronously on hip_stream (a hipStream_t,
+ * NULL = default stream).  Replaces the per-frame scale/crop/pad loop of the ffmpeg
+ * child (scripts/processVideos.js:71-108).  Frames must be TTS_MEM_DEVICE; the caller
+ * owns every buffer and nothing is allocated here.
+ */
+int tts_run(const tts_plan *p, const tts_frame *src, const tts_frame *dst, int n_frames, void *hip_stream);
+
+/*
+ * Same, for a batch laid out as consecutive packed I420 frames (Y, U, V back to back,
+ * strides == widths) at a fixed byte pitch between frames -- what a raw-video demuxer
+ * (`-f rawvideo -pix_fmt yuv420p`) hands over.  Device pointers.
+ */
+int tts_run_batch(const tts_plan *p, const void *src, size_t src_frame_pitch,
+                  void *dst, size_t dst_frame_pitch, int n_frames, void *hip_stream);
+
+/*
+ * Convenience for callers that hold host memory (the CLI, the Node addon): allocates
+ * staging buffers, copies in, runs, copies out, synchronises.  Packed I420 as above.
+ */
+int tts_run_host(const tts_plan *p, const void *src, void *dst, int n_frames);
+
+/*
+ * Read back the integer filter tables of one plane class (0 = luma, 1 = chroma) and
+ * axis (0 = horizontal, 1 = vertical) so tests can compare them with the oracle.
+ * coef/pos may be NULL to query sizes.  Replaces nothing in the reference: swscale
+ * keeps these private.
+ */
+int tts_plan_filter(const tts_plan *p, int plane_class, int axis,
+                    int *taps, int *n_out, int16_t *coef, int32_t *pos);
+
+/*
+ * Host-only: the integer table that resamples `src` samples to `dst` samples
+ * (one = 1<<14 horizontal, 1<<12 vertical; alg = TTS_ALG_*).  No device is touched.
+ * Call with coef == NULL to learn *taps, then with coef[dst * *taps], pos[dst].
+ * Replaces nothing in the reference (libswscale's initFilter is private).
+ */
+int tts_build_filter(int src, int dst, int one, int alg, int *taps, int16_t *coef, int32_t *pos);
+
+/* Which kernel family the plan dispatches to for a plane class: 0 = generic, 1 = strip. */
+int tts_plan_kernel_kind(const tts_plan *p, int plane_class);
+
+size_t tts_frame_bytes(int w, int h);          /* packed I420 size of a w x h frame */
+const char *tts_strerror(int status);
+const char *tts_last_error(void);          /* detail of the calling thread's last tts_parse_vf failure */
+const char *tts_version(void);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* TTSCALE_H */

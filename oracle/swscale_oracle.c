@@ -1,0 +1,351 @@
+/*
+ * oracle/swscale_oracle.c -- TEST INFRASTRUCTURE, NOT PRODUCT CODE.
+ *
+ * Plain-C restatement of the pixel arithmetic the reference hands to an
+ * external `ffmpeg` through filter strings:
+ *   scripts/processVideos.js:94-97      .size('720x1280')  -> scale=w=720:h=1280
+ *   src/services/video.js:22,329-332    scale=320x180:force_original_aspect_ratio=decrease,
+ *                                       pad=320x180:-1:-1:color=black,format=yuv420p
+ *   web/src/tests/video/portrait.test.js:78,95-96  scale=W:H / min(720 / decrease
+ *
+ * The arithmetic itself lives in a third-party dependency that is absent from
+ * /root/reference and from the container: FFmpeg (system binary, unpinned;
+ * @ffmpeg/core ^0.11.0 wraps FFmpeg 4.3).  What follows restates, from the
+ * published algorithm as recalled, libswscale's 8-bit planar C path:
+ *   libswscale/utils.c   initFilter(), sws_init_context()   (SURVEY.md S1-S3,S6)
+ *   libswscale/swscale.c hScale8To15_c()                    
+ *   libswscale/output.c  yuv2planeX_8_c(), yuv2plane1_8_c()
+ * and libavfilter's vf_scale / vf_crop / vf_pad geometry.
+ *
+ * PARITY UNPINNED: no golden vector, known-answer test or runnable FFmpeg
+ * exists to pin this file against.  tests/golden/ holds vectors
+ * produced BY this oracle plus hand-derivable anchors (taps sum to `one`,
+ * constant planes stay constant, identity geometry reproduces the input).
+ *
+ * Only tests/, __graft_entry__.smoke() and bench.py's cpu_baseline leg may use
+ * this file.  It is deliberately scalar and unoptimised.
+ */
+#include "swscale_oracle.h"
+#include <stdlib.h>
+#include <string.h>
+#include <math.h>
+
+#define TTO_MAX_REDUCE_CUTOFF 0.002   /* SWS_MAX_REDUCE_CUTOFF */
+
+static int tto_log2(unsigned v) { int n = 0; while (v >>= 1) n++; return n; }   /* av_log2, av_log2(0)=0 */
+static int64_t tto_abs64(int64_t a) { return a < 0 ? -a : a; }
+static int64_t tto_rounded_div(int64_t a, int64_t b)                           /* ROUNDED_DIV */
+{
+    return (a >= 0 ? a + (b >> 1) : a - (b >> 1)) / b;
+}
+
+/* libswscale/utils.c initFilter(), srcFilter/dstFilter NULL, filterAlign 1 (C path),
+ * srcPos == dstPos == 128 (get_local_pos(): luma, and centre-sited 4:2:0 chroma). */
+int tto_filter_init(tto_filter *f, int srcW, int dstW, int one, int alg)
+{
+    const int xInc = (int)((((int64_t)srcW << 16) + (dstW >> 1)) / dstW);      /* sws_init_context */
+    const int srcPos = 128, dstPos = 128;
+    const int64_t fone = 1LL << (54 - (tto_log2((unsigned)(srcW / dstW)) < 8 ? tto_log2((unsigned)(srcW / dstW)) : 8));
+    int filterSize, minFilterSize, i, j;
+    int64_t *filter = NULL, *filter2 = NULL;
+    int32_t *pos;
+
+    memset(f, 0, sizeof(*f));
+    if (srcW < 1 || dstW < 1) return -1;
+    pos = (int32_t *)calloc((size_t)dstW, sizeof(*pos));
+    if (!pos) return -1;
+
+    if (llabs((long long)xInc - 0x10000) < 10) {                 /* unscaled */
+        filterSize = 1;
+        filter = (int64_t *)calloc((size_t)dstW, sizeof(*filter));
+        for (i = 0; i < dstW; i++) { filter[i] = fone; pos[i] = i; }
+    } else if (xInc <= (1 << 16) && alg == TTO_ALG_AREA) {       /* "bilinear upscale" branch */
+        int64_t xDstInSrc;
+        filterSize = 2;
+        filter = (int64_t *)calloc((size_t)dstW * filterSize, sizeof(*filter));
+        xDstInSrc = ((dstPos * (int64_t)xInc) >> 8) - ((srcPos * 0x8000LL) >> 7);
+        for (i = 0; i < dstW; i++) {
+            int xx = (int)((xDstInSrc - ((int64_t)(filterSize - 1) << 15) + (1 << 15)) >> 16);
+            pos[i] = xx;
+            for (j = 0; j < filterSize; j++) {
+                int64_t coeff = fone - tto_abs64((int64_t)xx * (1 << 16) - xDstInSrc) * (fone >> 16);
+                if (coeff < 0) coeff = 0;
+                filter[i * filterSize + j] = coeff;
+                xx++;
+            }
+            xDstInSrc += xInc;
+        }
+    } else {
+        int64_t xDstInSrc;
+        int sizeFactor = alg == TTO_ALG_BICUBIC ? 4 : alg == TTO_ALG_AREA ? 1 : 2;
+        if (xInc <= 1 << 16) filterSize = 1 + sizeFactor;                       /* upscale */
+        else                 filterSize = 1 + (sizeFactor * srcW + dstW - 1) / dstW;
+        if (filterSize > srcW - 2) filterSize = srcW - 2;
+        if (filterSize < 1) filterSize = 1;
+        filter = (int64_t *)calloc((size_t)dstW * filterSize, sizeof(*filter));
+
+        xDstInSrc = ((dstPos * (int64_t)xInc) >> 7) - ((srcPos * 0x10000LL) >> 7);
+        for (i = 0; i < dstW; i++) {
+            int xx = (int)((xDstInSrc - (filterSize - 2) * (1LL << 16)) / (1 << 17)); /* C division */
+            pos[i] = xx;
+            for (j = 0; j < filterSize; j++) {
+                int64_t d = tto_abs64(((int64_t)xx * (1 << 17)) - xDstInSrc) << 13;
+                int64_t coeff;
+                if (xInc > 1 << 16) d = d * dstW / srcW;
+                if (alg == TTO_ALG_BICUBIC) {
+                    const int64_t B = 0;                                        /* SWS_PARAM_DEFAULT */
+                    const int64_t C = (int64_t)(0.6 * (1 << 24));
+                    if (d >= 1LL << 31) {
+                        coeff = 0;
+                    } else {
+                        int64_t dd  = (d * d) >> 30;
+                        int64_t ddd = (dd * d) >> 30;
+                        if (d < 1LL << 30)
+                            coeff = (12 * (1 << 24) - 9 * B - 6 * C) * ddd +
+                                    (-18 * (1 << 24) + 12 * B + 6 * C) * dd +
+                                    (6 * (1 << 24) - 2 * B) * (1LL << 30);
+                        else
+                            coeff = (-B - 6 * C) * ddd + (6 * B + 30 * C) * dd +
+                                    (-12 * B - 48 * C) * d + (8 * B + 24 * C) * (1LL << 30);
+                    }
+                    coeff /= (1LL << 54) / fone;
+                } else if (alg == TTO_ALG_AREA) {
+                    int64_t d2 = d - (1 << 29);
+                    if (d2 * xInc < -(1LL << (29 + 16)))     coeff = 1LL << (30 + 16);
+                    else if (d2 * xInc < (1LL << (29 + 16))) coeff = -d2 * xInc + (1LL << (29 + 16));
+                    else                                     coeff = 0;
+                    coeff *= fone >> (30 + 16);
+                } else {                                                         /* bilinear */
+                    coeff = (1LL << 30) - d;
+                    if (coeff < 0) coeff = 0;
+                    coeff *= fone >> 30;
+                }
+                filter[i * filterSize + j] = coeff;
+                xx++;
+            }
+            xDstInSrc += 2 * xInc;
+        }
+    }
+
+    /* no src/dst filter: filter2 = filter, filter2Size = filterSize */
+    filter2 = filter; filter = NULL;
+    {
+        const int filter2Size = filterSize;
+        /* step 1: shift near-zero leading taps out, count near-zero trailing taps */
+        minFilterSize = 0;
+        for (i = dstW - 1; i >= 0; i--) {
+            int min = filter2Size;
+            int64_t cutOff = 0;
+            for (j = 0; j < filter2Size; j++) {
+                int k;
+                cutOff += tto_abs64(filter2[i * filter2Size]);
+                if ((double)cutOff > TTO_MAX_REDUCE_CUTOFF * (double)fone) break;
+                /* preserve monotonicity */
+                if (i < dstW - 1 && pos[i] >= pos[i + 1]) break;
+                for (k = 1; k < filter2Size; k++)
+                    filter2[i * filter2Size + k - 1] = filter2[i * filter2Size + k];
+                filter2[i * filter2Size + k - 1] = 0;
+                pos[i]++;
+            }
+            cutOff = 0;
+            for (j = filter2Size - 1; j > 0; j--) {
+                cutOff += tto_abs64(filter2[i * filter2Size + j]);
+                if ((double)cutOff > TTO_MAX_REDUCE_CUTOFF * (double)fone) break;
+                min--;
+            }
+            if (min > minFilterSize) minFilterSize = min;
+        }
+        /* step 2: reduce (filterAlign == 1 on the C path) */
+        filterSize = minFilterSize;
+        filter = (int64_t *)calloc((size_t)dstW * filterSize, sizeof(*filter));
+        for (i = 0; i < dstW; i++)
+            for (j = 0; j < filterSize; j++)
+                filter[i * filterSize + j] = j >= filter2Size ? 0 : filter2[i * filter2Size + j];
+        free(filter2);
+    }
+
+    /* fix borders: out-of-range taps are folded into the edge tap */
+    for (i = 0; i < dstW; i++) {
+        if (pos[i] < 0) {
+            for (j = 1; j < filterSize; j++) {
+                int left = j + pos[i] > 0 ? j + pos[i] : 0;
+                filter[i * filterSize + left] += filter[i * filterSize + j];
+                filter[i * filterSize + j] = 0;
+            }
+            pos[i] = 0;
+        }
+        if (pos[i] + filterSize > srcW) {
+            int shift = pos[i] + (filterSize - srcW < 0 ? filterSize - srcW : 0);
+            int64_t acc = 0;
+            for (j = filterSize - 1; j >= 0; j--) {
+                if (pos[i] + j >= srcW) {
+                    acc += filter[i * filterSize + j];
+                    filter[i * filterSize + j] = 0;
+                }
+            }
+            for (j = filterSize - 1; j >= 0; j--) {
+                if (j < shift) filter[i * filterSize + j] = 0;
+                else           filter[i * filterSize + j] = filter[i * filterSize + j - shift];
+            }
+            pos[i] -= shift;
+            filter[i * filterSize + srcW - 1 - pos[i]] += acc;
+        }
+    }
+
+    /* normalise to `one` with error diffusion */
+    f->coef = (int16_t *)calloc((size_t)dstW * filterSize, sizeof(int16_t));
+    for (i = 0; i < dstW; i++) {
+        int64_t error = 0, sum = 0;
+        for (j = 0; j < filterSize; j++) sum += filter[i * filterSize + j];
+        sum = (sum + one / 2) / one;
+        if (!sum) sum = 1;
+        for (j = 0; j < filterSize; j++) {
+            int64_t v = filter[i * filterSize + j] + error;
+            int intV  = (int)tto_rounded_div(v, sum);
+            f->coef[i * filterSize + j] = (int16_t)intV;
+            error = v - intV * sum;
+        }
+    }
+    free(filter);
+    f->pos = pos; f->size = filterSize; f->dst = dstW; f->src = srcW;
+    return 0;
+}
+
+void tto_filter_free(tto_filter *f)
+{
+    free(f->coef); free(f->pos); memset(f, 0, sizeof(*f));
+}
+
+static uint8_t tto_clip_u8(int v) { return v < 0 ? 0 : v > 255 ? 255 : (uint8_t)v; }
+
+/* hScale8To15_c then yuv2planeX_8_c / yuv2plane1_8_c (dither = ff_sws_pb_64 for 8-bit sources) */
+int tto_scale_plane(const uint8_t *src, int sstride, int sw, int sh,
+                    uint8_t *dst, int dstride, int dw, int dh, int alg)
+{
+    tto_filter hf, vf;
+    int16_t *tmp;
+    int x, y, j;
+    if (tto_filter_init(&hf, sw, dw, 1 << 14, alg)) return -1;
+    if (tto_filter_init(&vf, sh, dh, 1 << 12, alg)) { tto_filter_free(&hf); return -1; }
+    tmp = (int16_t *)malloc((size_t)dw * sh * sizeof(int16_t));
+    for (y = 0; y < sh; y++) {
+        const uint8_t *s = src + (size_t)y * sstride;
+        int16_t *t = tmp + (size_t)y * dw;
+        for (x = 0; x < dw; x++) {
+            int val = 0, p = hf.pos[x];
+            for (j = 0; j < hf.size; j++) val += (int)s[p + j] * hf.coef[hf.size * x + j];
+            val >>= 7;
+            t[x] = (int16_t)(val < (1 << 15) - 1 ? val : (1 << 15) - 1);
+        }
+    }
+    for (y = 0; y < dh; y++) {
+        uint8_t *d = dst + (size_t)y * dstride;
+        int p = vf.pos[y];
+        const int16_t *c = vf.coef + (size_t)vf.size * y;
+        if (vf.size == 1) {
+            const int16_t *t = tmp + (size_t)p * dw;
+            for (x = 0; x < dw; x++) d[x] = tto_clip_u8((t[x] + 64) >> 7);
+        } else {
+            for (x = 0; x < dw; x++) {
+                int val = 64 << 12;
+                for (j = 0; j < vf.size; j++) val += tmp[(size_t)(p + j) * dw + x] * c[j];
+                d[x] = tto_clip_u8(val >> 19);
+            }
+        }
+    }
+    free(tmp); tto_filter_free(&hf); tto_filter_free(&vf);
+    return 0;
+}
+
+/* av_rescale(a,b,c) with AV_ROUND_NEAR_INF, positive operands */
+static int64_t tto_rescale(int64_t a, int64_t b, int64_t c) { return (a * b + c / 2) / c; }
+
+/* libavfilter scale_eval.c ff_scale_adjust_dimensions(), SAR 1:1 */
+int tto_scale_dims(int iw, int ih, int w, int h, int foar, int fdb, int *ow, int *oh)
+{
+    int factor_w = 1, factor_h = 1;
+    if (w == 0) w = iw;
+    if (h == 0) h = ih;
+    if (w < -1) factor_w = -w;
+    if (h < -1) factor_h = -h;
+    if (w < 0 && h < 0) { w = iw; h = ih; }
+    if (w < 0) w = (int)(tto_rescale(h, iw, (int64_t)ih * factor_w) * factor_w);
+    if (h < 0) h = (int)(tto_rescale(w, ih, (int64_t)iw * factor_h) * factor_h);
+    if (foar) {
+        int tmp_w = (int)tto_rescale(h, iw, ih);
+        int tmp_h = (int)tto_rescale(w, ih, iw);
+        if (fdb < 1) fdb = 1;
+        if (foar == 1) {
+            w = tmp_w < w ? tmp_w : w;
+            h = tmp_h < h ? tmp_h : h;
+            if (fdb > 1) { w = w / fdb * fdb; h = h / fdb * fdb; }
+        } else {
+            w = tmp_w > w ? tmp_w : w;
+            h = tmp_h > h ? tmp_h : h;
+            if (fdb > 1) { w = (w + fdb - 1) / fdb * fdb; h = (h + fdb - 1) / fdb * fdb; }
+        }
+    }
+    if (w <= 0 || h <= 0) return -1;
+    *ow = w; *oh = h;
+    return 0;
+}
+
+/* libavfilter vf_crop.c: x = lrint(expr), clamp into frame, then mask to the 4:2:0 chroma grid */
+int tto_crop_offset(int in, int out, double expr_value, int use_expr)
+{
+    double v = use_expr ? expr_value : (in - out) / 2.0;
+    int x = (int)lrint(v);
+    if (x < 0) x = 0;
+    if (x + out > in) x = in - out;
+    return x & ~1;
+}
+
+static void tto_copy_rect(const uint8_t *s, int ss, uint8_t *d, int ds, int w, int h)
+{
+    for (int y = 0; y < h; y++) memcpy(d + (size_t)y * ds, s + (size_t)y * ss, (size_t)w);
+}
+
+int tto_run_chain(const tto_chain *c,
+                  const uint8_t *sy, const uint8_t *su, const uint8_t *sv,
+                  int sys, int sus, int svs,
+                  uint8_t *dy, uint8_t *du, uint8_t *dv,
+                  int dys, int dus, int dvs)
+{
+    const uint8_t *sp[3] = { sy, su, sv };
+    const int sst[3] = { sys, sus, svs };
+    uint8_t *dp[3] = { dy, du, dv };
+    const int dst_[3] = { dys, dus, dvs };
+    const int fill[3] = { c->fill_y, c->fill_u, c->fill_v };
+
+    for (int p = 0; p < 3; p++) {
+        const int sub = p ? 1 : 0;
+        /* vf_crop (before scale): pointer offset; sizes are even so >>1 is exact */
+        const uint8_t *s = sp[p] + (size_t)(c->pre_y >> sub) * sst[p] + (c->pre_x >> sub);
+        const int pw = (c->pre_w + sub) >> sub, ph = (c->pre_h + sub) >> sub;        /* AV_CEIL_RSHIFT */
+        const int vw = (c->sc_w + sub) >> sub,  vh = (c->sc_h + sub) >> sub;
+        uint8_t *scaled = NULL;
+        const uint8_t *q; int qs;
+        if (c->do_scale) {
+            scaled = (uint8_t *)malloc((size_t)vw * vh);
+            if (tto_scale_plane(s, sst[p], pw, ph, scaled, vw, vw, vh, c->alg)) { free(scaled); return -1; }
+            q = scaled; qs = vw;
+        } else { q = s; qs = sst[p]; }
+        /* vf_crop (after scale) */
+        q += (size_t)(c->crop_y >> sub) * qs + (c->crop_x >> sub);
+        const int cw = (c->crop_w + sub) >> sub, ch = (c->crop_h + sub) >> sub;
+        if (!c->do_pad) {
+            tto_copy_rect(q, qs, dp[p], dst_[p], cw, ch);
+        } else {
+            /* vf_pad.c filter_frame(): bars filled, frame copied, then the right border is drawn
+             * from x + (in_w rounded DOWN to the chroma grid): an odd input width loses its
+             * last column to the fill colour. */
+            const int ow = (c->out_w + sub) >> sub, oh = (c->out_h + sub) >> sub;
+            const int px = c->pad_x >> sub, py = c->pad_y >> sub;
+            const int in_w_r = (c->crop_w & ~1) >> sub;
+            for (int y = 0; y < oh; y++) memset(dp[p] + (size_t)y * dst_[p], fill[p], (size_t)ow);
+            tto_copy_rect(q, qs, dp[p] + (size_t)py * dst_[p] + px, dst_[p], in_w_r < cw ? in_w_r : cw, ch);
+        }
+        free(scaled);
+    }
+    return 0;
+}

@@ -1,0 +1,64 @@
+/*
+ * oracle/swscale_oracle.h -- TEST INFRASTRUCTURE, NOT PRODUCT CODE.
+ *
+ * CPU restatement of the third-party pixel engine behind the reference's
+ * filter strings (libswscale 8-bit planar C path + libavfilter scale/crop/pad
+ * geometry).  Only tests/, __graft_entry__.smoke() and bench.py's cpu_baseline
+ * leg may load this.  The shipped library (libttscale.so) never links it.
+ *
+ * PARITY UNPINNED: FFmpeg is not in /root/reference nor in the container and
+ * the reference's own tests hold no pixel vectors, so this
+ * restatement is anchored only on the published algorithm as recalled.
+ */
+#ifndef TTO_SWSCALE_ORACLE_H
+#define TTO_SWSCALE_ORACLE_H
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+enum { TTO_ALG_BICUBIC = 0, TTO_ALG_AREA = 1, TTO_ALG_BILINEAR = 2 };
+
+/* one axis of one plane: int16 taps, first-tap positions, taps per sample */
+typedef struct tto_filter {
+    int16_t *coef;   /* dst * size */
+    int32_t *pos;    /* dst */
+    int size;
+    int dst;
+    int src;
+} tto_filter;
+
+int  tto_filter_init(tto_filter *f, int src, int dst, int one, int alg);
+void tto_filter_free(tto_filter *f);
+
+/* scale one 8-bit plane (hScale8To15 then yuv2planeX_8 / yuv2plane1_8) */
+int tto_scale_plane(const uint8_t *src, int sstride, int sw, int sh,
+                    uint8_t *dst, int dstride, int dw, int dh, int alg);
+
+/* geometry of a whole chain, all in luma pixels */
+typedef struct tto_chain {
+    int in_w, in_h;
+    int pre_x, pre_y, pre_w, pre_h;   /* crop before scale (pre_w = in_w if none) */
+    int do_scale, alg, sc_w, sc_h;    /* virtual scaled size */
+    int crop_x, crop_y, crop_w, crop_h; /* crop after scale */
+    int do_pad, pad_x, pad_y, out_w, out_h; /* pad canvas */
+    int fill_y, fill_u, fill_v;
+} tto_chain;
+
+/* vf_scale output-size rule; foar: 0 disable, 1 decrease, 2 increase */
+int tto_scale_dims(int iw, int ih, int w, int h, int foar, int fdb, int *ow, int *oh);
+/* vf_crop default/explicit offset -> chroma-aligned int; pass x<0 for centred */
+int tto_crop_offset(int in, int out, double expr_value, int use_expr);
+
+/* run a yuv420p frame through the chain, unfused (scale whole, crop, pad) */
+int tto_run_chain(const tto_chain *c,
+                  const uint8_t *sy, const uint8_t *su, const uint8_t *sv,
+                  int sys, int sus, int svs,
+                  uint8_t *dy, uint8_t *du, uint8_t *dv,
+                  int dys, int dus, int dvs);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

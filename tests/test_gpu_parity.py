@@ -1,0 +1,180 @@
+"""GPU parity: libttscale (through the C ABI) vs the CPU oracle, bit-exact (0 LSB).
+
+The oracle itself is PARITY UNPINNED against real FFmpeg (oracle/swscale_oracle.c header):
+these tests prove HIP == oracle, not oracle == swscale."""
+import numpy as np
+import pytest
+
+import synth
+
+pytestmark = pytest.mark.gpu
+
+PORTRAIT = "scale=1080:1920:force_original_aspect_ratio=increase,crop=1080:1920"
+THUMB_REF = "scale=320x180:force_original_aspect_ratio=decrease,pad=320x180:-1:-1:color=black,format=yuv420p"
+
+# (vf, iw, ih): the reference's own chains first, BASELINE.json's shapes, then edge geometries
+CASES = [
+    ("scale=w=720:h=1280", 480, 854),                 # scripts/processVideos.js:96 on a sub-720p clip
+    ("scale=w=720:h=1280", 360, 640),
+    (THUMB_REF, 720, 1280),                            # src/services/video.js:329-332, portrait source
+    (THUMB_REF, 1280, 720),                            # landscape source (test/helpers/video.js)
+    (THUMB_REF, 1080, 1080),                           # square (portrait.test.js:86)
+    ("scale='min(720,iw)':'min(1280,ih)':force_original_aspect_ratio=decrease", 720, 2560),  # portrait.test.js:136-138
+    (PORTRAIT, 1920, 1080),                            # BASELINE configs[1]
+    (PORTRAIT, 1280, 720),
+    (PORTRAIT, 3840, 2160),
+    ("scale=320:568:flags=area", 1080, 1920),          # BASELINE configs[2]
+    ("scale=160:284:flags=area", 1080, 1920),
+    ("scale=640:360:flags=bilinear", 1280, 720),
+    ("scale=1281:721", 1280, 720),                     # barely scaled, odd output
+    ("scale=101:57", 64, 36),                          # odd everything, tiny
+    ("scale=64:36", 101, 57),
+    ("scale=8:8", 6, 6),
+    ("scale=2:2", 64, 64),                             # huge shrink: many taps -> generic kernel
+    ("scale=500:2", 16, 300),
+    ("crop=64:32:10:6,scale=128:96", 100, 60),         # crop before scale
+    ("crop=320:180", 640, 360),                        # crop only
+    ("pad=640:480:-1:-1:color=white", 320, 240),      # pad only
+    ("scale=iw/2:-2,pad=iw+20:ih+10:10:4:color=red", 200, 150),
+    ("format=yuv420p", 64, 48),                        # identity
+]
+
+
+def run_case(tts, oracle, vf, iw, ih, patterns, n=2):
+    import torch
+    plan = tts.Plan.from_vf(vf, iw, ih)
+    for pat in patterns:
+        src = synth.frames(pat, iw, ih, n)
+        want = oracle.run_chain(plan.geom, src)
+        got = plan.run_batch(torch.from_numpy(src).cuda())
+        torch.cuda.synchronize()
+        got = got.cpu().numpy()
+        bad = np.flatnonzero(got != want)
+        assert bad.size == 0, "%s %dx%d %s: %d bytes differ, first at %d (got %d want %d)" % (
+            vf, iw, ih, pat, bad.size, bad[0] if bad.size else -1,
+            got.ravel()[bad[0]] if bad.size else 0, want.ravel()[bad[0]] if bad.size else 0)
+    plan.close()
+
+
+@pytest.mark.parametrize("vf,iw,ih", CASES)
+def test_chain_matches_oracle(tts, oracle, vf, iw, ih):
+    big = iw * ih > 1000 * 1000
+    pats = ("random", "impulse") if big else synth.PATTERNS
+    run_case(tts, oracle, vf, iw, ih, pats, n=1 if big else 3)
+
+
+def test_batch_of_frames_ragged_tail(tts, oracle):
+    # 37 frames: the last workgroup of every launch is partly idle
+    run_case(tts, oracle, "scale=96:54", 64, 36, ("random",), n=37)
+
+
+def test_empty_batch(tts):
+    import torch
+    plan = tts.Plan.from_vf("scale=96:54", 64, 36)
+    out = plan.run_batch(torch.empty((0, plan.in_bytes), dtype=torch.uint8, device="cuda"))
+    assert out.shape == (0, plan.out_bytes)
+
+
+def test_generic_and_strip_kernels_agree(tts, oracle, monkeypatch):
+    import torch
+    src = synth.frames("random", 320, 180, 2)
+    plan = tts.Plan.from_vf("scale=568:320", 320, 180)
+    assert plan.kernel_kind(0) == 1 and plan.kernel_kind(1) == 1
+    a = plan.run_batch(torch.from_numpy(src).cuda()).cpu().numpy()
+    monkeypatch.setenv("TTS_FORCE_GENERIC", "1")
+    plan2 = tts.Plan.from_vf("scale=568:320", 320, 180)
+    assert plan2.kernel_kind(0) == 0
+    b = plan2.run_batch(torch.from_numpy(src).cuda()).cpu().numpy()
+    assert np.array_equal(a, b)
+    assert np.array_equal(a, oracle.run_chain(plan.geom, src))
+
+
+@pytest.mark.parametrize("seg", [16, 33, 64, 4096])
+def test_row_segmentation_is_invisible(tts, oracle, monkeypatch, seg):
+    import torch
+    monkeypatch.setenv("TTS_SEG_ROWS", str(seg))
+    src = synth.frames("random", 200, 150, 2)
+    for vf in ("scale=355:267", "scale=120:90:flags=area"):
+        plan = tts.Plan.from_vf(vf, 200, 150)
+        got = plan.run_batch(torch.from_numpy(src).cuda()).cpu().numpy()
+        assert np.array_equal(got, oracle.run_chain(plan.geom, src))
+
+
+def test_frame_pointer_api_matches_batch_api(tts, oracle):
+    """tts_run with per-frame plane pointers and padded strides == tts_run_batch."""
+    import torch
+    iw, ih, n = 160, 90, 5
+    plan = tts.Plan.from_vf("scale=284:160", iw, ih)
+    ow, oh = plan.out_size
+    src = synth.frames("random", iw, ih, n)
+    want = oracle.run_chain(plan.geom, src)
+    sp, dp, ss, ds, keep = [], [], [], [], []
+    for i in range(n):
+        y, u, v = synth.split(src[i], iw, ih)
+        planes, strides = [], []
+        for k, pl in enumerate((y, u, v)):
+            stride = pl.shape[1] + (24 if k == 0 else 8)
+            t = torch.zeros((pl.shape[0], stride), dtype=torch.uint8, device="cuda")
+            t[:, : pl.shape[1]] = torch.from_numpy(np.ascontiguousarray(pl)).cuda()
+            keep.append(t); planes.append(t.data_ptr()); strides.append(stride)
+        sp.append(planes); ss.append(strides)
+        outs, ostr = [], []
+        for k in range(3):
+            w_, h_ = (ow, oh) if k == 0 else ((ow + 1) // 2, (oh + 1) // 2)
+            stride = w_ + 16
+            t = torch.full((h_, stride), 7, dtype=torch.uint8, device="cuda")
+            keep.append(t); outs.append(t); ostr.append(stride)
+        dp.append(outs); ds.append(ostr)
+    plan.run_frames(sp, [[t.data_ptr() for t in o] for o in dp], ss, ds)
+    torch.cuda.synchronize()
+    for i in range(n):
+        wy, wu, wv = synth.split(want[i], ow, oh)
+        for k, wpl in enumerate((wy, wu, wv)):
+            got = dp[i][k].cpu().numpy()
+            assert np.array_equal(got[:, : wpl.shape[1]], wpl)
+            assert (got[:, wpl.shape[1]:] == 7).all(), "wrote into the stride padding"
+
+
+# ---- BASELINE.json full sizes: size-independent properties ---------------------------------
+
+def test_full_size_constant_planes_stay_constant(tts):
+    import torch
+    plan = tts.Plan.from_vf(PORTRAIT, 1920, 1080)
+    for val in (0, 16, 128, 235, 255):
+        src = torch.full((4, plan.in_bytes), val, dtype=torch.uint8, device="cuda")
+        out = plan.run_batch(src)
+        assert int(out.min()) == val and int(out.max()) == val
+
+
+def test_full_size_crop_equals_uncropped_then_sliced(tts):
+    """scale+crop must equal the crop of the full virtual scale (fusing the crop is invisible)."""
+    import torch
+    src = torch.from_numpy(synth.frames("random", 1920, 1080, 2)).cuda()
+    fused = tts.Plan.from_vf(PORTRAIT, 1920, 1080).run_batch(src).cpu().numpy()
+    full = tts.Plan.from_vf("scale=3413:1920", 1920, 1080).run_batch(src).cpu().numpy()
+    for i in range(2):
+        fy, fu, fv = synth.split(full[i], 3413, 1920)
+        cy, cu, cv = synth.split(fused[i], 1080, 1920)
+        assert np.array_equal(cy, fy[:, 1166:1166 + 1080])
+        assert np.array_equal(cu, fu[:, 583:583 + 540])
+        assert np.array_equal(cv, fv[:, 583:583 + 540])
+
+
+def test_full_size_frames_are_independent(tts):
+    """Every frame of a 300-frame batch equals the same frame run alone (checksum of checksums)."""
+    import torch
+    plan = tts.Plan.from_vf(PORTRAIT, 1920, 1080)
+    base = torch.from_numpy(synth.frames("random", 1920, 1080, 3)).cuda()
+    single = plan.run_batch(base)
+    batch = base.repeat(100, 1)
+    out = plan.run_batch(batch)
+    torch.cuda.synchronize()
+    assert torch.equal(out.view(100, 3, -1), single.unsqueeze(0).expand(100, -1, -1))
+
+
+def test_full_size_thumbnails_match_oracle_sample(tts, oracle):
+    import torch
+    plan = tts.Plan.from_vf("scale=320:568:flags=area", 1080, 1920)
+    src = synth.frames("random", 1080, 1920, 2)
+    got = plan.run_batch(torch.from_numpy(src).cuda()).cpu().numpy()
+    assert np.array_equal(got, oracle.run_chain(plan.geom, src))

@@ -1,0 +1,32 @@
+// Host-side planning for libttscale: integer filter tables and chain geometry.
+// Product code (never includes or links anything under oracle/).
+#pragma once
+#include <cstdint>
+#include <string>
+#include <vector>
+#include "../../include/ttscale.h"
+
+namespace tts {
+
+// One axis of one plane: taps[i*size + j] weighs source sample pos[i] + j.
+struct AxisFilter {
+    int src = 0, dst = 0, size = 0;
+    std::vector<int16_t> taps;
+    std::vector<int32_t> pos;
+};
+
+// swscale-compatible table for resampling `src` samples to `dst` samples
+// (SURVEY.md S1-S3, S6).  one = 1<<14 horizontally, 1<<12 vertically.
+bool build_axis_filter(int src, int dst, int one, int alg, AxisFilter &out);
+
+// Geometry helpers.
+bool scale_output_size(int iw, int ih, int w, int h, int foar, int fdb, int &ow, int &oh);
+int  crop_origin(int in, int out, double value, bool has_value);
+
+// Validate a resolved geometry; returns TTS_OK or an error.
+int  check_geom(const tts_geom &g);
+
+// "-vf" chain parser; err receives a one-line reason on failure.
+int  parse_vf(const char *vf, int iw, int ih, tts_geom &g, std::string &err);
+
+}  // namespace tts

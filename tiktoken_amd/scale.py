@@ -1,0 +1,135 @@
+"""Host-side handle on a libttscale plan: the Python mirror of "give ffmpeg a -vf string".
+
+The reference drives this path through filter strings only
+(scripts/processVideos.js:94-97, src/services/video.js:329-332); `Plan.from_vf` takes the
+same strings.  Frames are packed I420 (`-f rawvideo -pix_fmt yuv420p`) uint8 tensors that
+already live in HBM; torch is used for device memory and streams, nothing else."""
+import ctypes
+
+import numpy as np
+
+from . import _lib
+from ._lib import Geom, Frame, TtsError, check
+
+ALG = {"bicubic": 0, "area": 1, "bilinear": 2}
+
+
+def frame_bytes(w, h):
+    return int(_lib.lib().tts_frame_bytes(w, h))
+
+
+def parse_vf(vf, iw, ih):
+    """Resolve a filter chain for an iw x ih input -> Geom (raises TtsError)."""
+    g = Geom()
+    rc = _lib.lib().tts_parse_vf(vf.encode(), iw, ih, ctypes.byref(g))
+    check(rc, _lib.lib().tts_last_error().decode() if rc else "")
+    return g
+
+
+def build_filter(src, dst, one, alg):
+    """Host-only integer resampling table: (taps[dst, size] int16, pos[dst] int32)."""
+    taps = ctypes.c_int()
+    check(_lib.lib().tts_build_filter(src, dst, one, alg, ctypes.byref(taps), None, None))
+    coef = np.zeros((dst, taps.value), np.int16)
+    pos = np.zeros(dst, np.int32)
+    check(_lib.lib().tts_build_filter(src, dst, one, alg, ctypes.byref(taps),
+                                      coef.ctypes.data_as(ctypes.c_void_p), pos.ctypes.data_as(ctypes.c_void_p)))
+    return coef, pos
+
+
+class Plan:
+    """Immutable per-geometry state (coefficient tables in HBM on the current device)."""
+
+    def __init__(self, geom):
+        self._h = ctypes.c_void_p()
+        self.geom = geom
+        check(_lib.lib().tts_plan_create(ctypes.byref(geom), ctypes.byref(self._h)))
+
+    @classmethod
+    def from_vf(cls, vf, iw, ih):
+        return cls(parse_vf(vf, iw, ih))
+
+    def close(self):
+        if self._h:
+            _lib.lib().tts_plan_destroy(self._h)
+            self._h = ctypes.c_void_p()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    @property
+    def in_size(self):
+        return self.geom.in_w, self.geom.in_h
+
+    @property
+    def out_size(self):
+        return self.geom.out_w, self.geom.out_h
+
+    @property
+    def in_bytes(self):
+        return frame_bytes(*self.in_size)
+
+    @property
+    def out_bytes(self):
+        return frame_bytes(*self.out_size)
+
+    def kernel_kind(self, plane_class):
+        return _lib.lib().tts_plan_kernel_kind(self._h, plane_class)
+
+    def filter(self, plane_class, axis):
+        """(taps[n_out, size] int16, pos[n_out] int32) of one plane class / axis."""
+        taps, n = ctypes.c_int(), ctypes.c_int()
+        check(_lib.lib().tts_plan_filter(self._h, plane_class, axis, ctypes.byref(taps), ctypes.byref(n), None, None))
+        coef = np.zeros((n.value, taps.value), np.int16)
+        pos = np.zeros(n.value, np.int32)
+        check(_lib.lib().tts_plan_filter(self._h, plane_class, axis, None, None,
+                                         coef.ctypes.data_as(ctypes.c_void_p), pos.ctypes.data_as(ctypes.c_void_p)))
+        return coef, pos
+
+    def run_batch(self, src, dst=None, stream=None):
+        """src: uint8 cuda tensor [n, in_bytes] (or flat); returns dst [n, out_bytes].
+        Asynchronous on `stream` (default: torch's current stream)."""
+        import torch
+        if not (src.is_cuda and src.dtype == torch.uint8 and src.is_contiguous()):
+            raise TtsError(-1, "src must be a contiguous uint8 CUDA tensor")
+        if src.numel() % self.in_bytes:
+            raise TtsError(-1, "src size is not a multiple of the packed frame size")
+        n = src.numel() // self.in_bytes
+        if dst is None:
+            dst = torch.empty((n, self.out_bytes), dtype=torch.uint8, device=src.device)
+        if not (dst.is_cuda and dst.dtype == torch.uint8 and dst.is_contiguous() and dst.numel() == n * self.out_bytes):
+            raise TtsError(-1, "dst must be a contiguous uint8 CUDA tensor of n*out_bytes")
+        if stream is None:
+            stream = torch.cuda.current_stream(src.device).cuda_stream
+        check(_lib.lib().tts_run_batch(self._h, src.data_ptr(), self.in_bytes, dst.data_ptr(), self.out_bytes, n,
+                                       ctypes.c_void_p(stream)))
+        return dst
+
+    def run_frames(self, src_planes, dst_planes, src_strides, dst_strides, stream=None):
+        """Arbitrary plane pointers: lists (one entry per frame) of 3 device pointers / 3 strides."""
+        n = len(src_planes)
+        S, D = (Frame * n)(), (Frame * n)()
+        for i in range(n):
+            for k in range(3):
+                S[i].plane[k] = src_planes[i][k]
+                D[i].plane[k] = dst_planes[i][k]
+                S[i].stride[k] = src_strides[i][k]
+                D[i].stride[k] = dst_strides[i][k]
+            S[i].width, S[i].height = self.in_size
+            D[i].width, D[i].height = self.out_size
+        if stream is None:
+            import torch
+            stream = torch.cuda.current_stream().cuda_stream
+        check(_lib.lib().tts_run(self._h, S, D, n, ctypes.c_void_p(stream)))
+
+    def run_host(self, src):
+        """numpy uint8 [n, in_bytes] on the host -> numpy [n, out_bytes]; stages through HBM."""
+        src = np.ascontiguousarray(src, dtype=np.uint8)
+        n = src.size // self.in_bytes
+        dst = np.empty((n, self.out_bytes), np.uint8)
+        check(_lib.lib().tts_run_host(self._h, src.ctypes.data_as(ctypes.c_void_p),
+                                      dst.ctypes.data_as(ctypes.c_void_p), n))
+        return dst
