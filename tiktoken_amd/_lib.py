@@ -55,6 +55,13 @@ def lib():
             raise RuntimeError(
                 "tiktoken_amd: %s is missing. Build it with `python -m tiktoken_amd.build` "
                 "(hipcc, gfx950). There is no CPU fallback." % LIB_PATH)
+        # One HIP runtime per process: torch bundles its own libamdhip64 (same soname as the
+        # system one libttscale links).  Load torch's first so device pointers, streams and
+        # the current device are shared between torch and the library.
+        try:
+            import torch  # noqa: F401
+        except ImportError:
+            pass
         handle = ctypes.CDLL(LIB_PATH)
         for name, (res, args) in SYMBOLS.items():
             fn = getattr(handle, name)

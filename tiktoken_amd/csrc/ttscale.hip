@@ -513,12 +513,17 @@ int tts_plan_create(const tts_geom *g, tts_plan **out)
     int rc = tts::check_geom(*g);
     if (rc) return rc;
     int dev = 0;
-    if (hipGetDevice(&dev) != hipSuccess) return TTS_ERR_INITIALIZATION_FAILED;
+    const hipError_t he = hipGetDevice(&dev);
+    if (he != hipSuccess) { g_last_error = std::string("hipGetDevice: ") + hipGetErrorString(he); return TTS_ERR_INITIALIZATION_FAILED; }
     tts_plan *p = new (std::nothrow) tts_plan();
     if (!p) return TTS_ERR_INITIALIZATION_FAILED;
     p->g = *g; p->device = dev;
     for (int ci = 0; ci < 2 && rc == TTS_OK; ++ci) rc = build_class(*g, ci, p->cls[ci]);
-    if (rc) { tts_plan_destroy(p); return rc; }
+    if (rc) {
+        if (rc == TTS_ERR_INITIALIZATION_FAILED) g_last_error = std::string("table upload: ") + hipGetErrorString(hipGetLastError());
+        tts_plan_destroy(p);
+        return rc;
+    }
     *out = p;
     return TTS_OK;
 }
@@ -574,7 +579,9 @@ size_t tts_frame_bytes(int w, int h)
 int tts_run_batch(const tts_plan *p, const void *src, size_t src_pitch, void *dst, size_t dst_pitch,
                   int n_frames, void *hip_stream)
 {
-    if (!p || !src || !dst || n_frames < 0) return TTS_ERR_INVALID_INPUT;
+    if (!p || n_frames < 0) return TTS_ERR_INVALID_INPUT;
+    if (n_frames == 0) return TTS_OK;
+    if (!src || !dst) return TTS_ERR_INVALID_INPUT;
     const tts_geom &g = p->g;
     if (src_pitch < tts_frame_bytes(g.in_w, g.in_h) || dst_pitch < tts_frame_bytes(g.out_w, g.out_h)) return TTS_ERR_INVALID_INPUT;
     if (src_pitch >= (size_t(1) << 31) || dst_pitch >= (size_t(1) << 31)) return TTS_ERR_UNSUPPORTED;
@@ -611,7 +618,9 @@ int tts_run_batch(const tts_plan *p, const void *src, size_t src_pitch, void *ds
 
 int tts_run(const tts_plan *p, const tts_frame *src, const tts_frame *dst, int n_frames, void *hip_stream)
 {
-    if (!p || !src || !dst || n_frames < 0) return TTS_ERR_INVALID_INPUT;
+    if (!p || n_frames < 0) return TTS_ERR_INVALID_INPUT;
+    if (n_frames == 0) return TTS_OK;
+    if (!src || !dst) return TTS_ERR_INVALID_INPUT;
     const tts_geom &g = p->g;
     for (int i = 0; i < n_frames; ++i) {
         if (src[i].mem != TTS_MEM_DEVICE || dst[i].mem != TTS_MEM_DEVICE) return TTS_ERR_INVALID_INPUT;

@@ -43,7 +43,8 @@ class Plan:
     def __init__(self, geom):
         self._h = ctypes.c_void_p()
         self.geom = geom
-        check(_lib.lib().tts_plan_create(ctypes.byref(geom), ctypes.byref(self._h)))
+        rc = _lib.lib().tts_plan_create(ctypes.byref(geom), ctypes.byref(self._h))
+        check(rc, _lib.lib().tts_last_error().decode() if rc else "")
 
     @classmethod
     def from_vf(cls, vf, iw, ih):
