@@ -10,13 +10,15 @@
 //   strip_kernel<LW,R,N>  the hot path.  One lane owns N adjacent output columns of one
 //       plane of one frame and walks down a segment of output rows.  Per source row it
 //       gathers one LW-byte window per column straight through the vector L1 (the
-//       windows of a wave are a contiguous run of the row), runs the horizontal taps
-//       with v_dot2 on the window, and drops the 15-bit result into a register ring of
-//       R source rows kept as packed row pairs.  Every output row whose last source
-//       row has arrived is produced from the ring with v_dot2 against wave-uniform
-//       vertical taps (scalar loads) and stored as N contiguous bytes.  The
-//       intermediate never leaves registers: HBM sees the source window once and the
-//       output once.  No LDS, no barriers, no inter-workgroup traffic.
+//       windows of a wave are a contiguous run of the row; the next row's windows are
+//       already in flight while this row is computed), runs the horizontal taps with
+//       v_dot2 on the window, and drops the 15-bit result into a register ring of R
+//       source rows kept as packed row pairs.  Every output row whose last source row
+//       has arrived is produced from the ring with v_dot2 against wave-uniform vertical
+//       taps (scalar loads) and stored as N contiguous bytes.  The intermediate never
+//       leaves registers: HBM sees the source window once and the output once.  No LDS,
+//       no barriers, no inter-workgroup traffic.  Luma and chroma planes of a batch go
+//       out in ONE launch (block ranges), so the chroma blocks fill the luma tail.
 //   generic_kernel        any tap counts (e.g. the 29-tap 720->101 thumbnail), one
 //       lane per output sample; correctness path for shapes the strip kernel does not
 //       cover.
@@ -27,7 +29,6 @@
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
-#include <mutex>
 #include <new>
 #include <string>
 #include <vector>
@@ -47,28 +48,39 @@ typedef short short2_t __attribute__((ext_vector_type(2)));
 typedef uint32_t u32x2_t __attribute__((ext_vector_type(2)));
 typedef uint32_t u32x4_t __attribute__((ext_vector_type(4)));
 
-struct PlaneAddr {
-    // item -> byte offset of its plane origin, relative to the base pointer of the launch
+// Where the planes of frame f live, relative to the base pointers of the launch.
+struct FrameAddr {
     uint32_t src_pitch, dst_pitch;            // packed mode: bytes between frames
-    uint32_t src_plane[2], dst_plane[2];      // packed mode: plane origin inside a frame
+    uint32_t src_plane[3], dst_plane[3];      // packed mode: plane origin inside a frame
     int32_t  use_table;                        // table mode: explicit per-frame offsets
-    uint32_t src_tab[2][kMaxTableFrames];
-    uint32_t dst_tab[2][kMaxTableFrames];
+    uint32_t src_tab[3][kMaxTableFrames];
+    uint32_t dst_tab[3][kMaxTableFrames];
+};
+
+// One plane class (0 = luma, 1 = both chroma planes) of a strip launch.
+struct StripClass {
+    uint32_t hoff, hsel, hcoef;    // dword offsets into the table buffer
+    uint32_t seginfo, emit, vcoef;
+    int32_t  maxrows, nseg, seg_rows;
+    int32_t  strips, planes, plane0, n_items;
+    int32_t  ow, oh, src_stride, dst_stride;
+    uint32_t nblocks;              // workgroups of this class in the launch
 };
 
 struct StripArgs {
-    uint32_t src_span, dst_span;      // bytes reachable from the base pointers (buffer range check)
-    int32_t src_stride, dst_stride;
-    int32_t ow, oh;
-    int32_t strips, planes, n_items;
-    int32_t seg_rows, nseg;
-    PlaneAddr addr;
+    StripClass c[2];
+    uint32_t src_span, dst_span;   // bytes reachable from the base pointers (buffer range check)
+    FrameAddr addr;
 };
 
+// clamp = true selects the VOP3P form (v_dot2_i32_i16 d, a, b, c) whose accumulator input is a
+// free operand; the sums here never reach the int32 range, so the clamp never acts.
 __device__ __forceinline__ int dot2(uint32_t a, uint32_t b, int c)
 {
-    return __builtin_amdgcn_sdot2(__builtin_bit_cast(short2_t, a), __builtin_bit_cast(short2_t, b), c, false);
+    return __builtin_amdgcn_sdot2(__builtin_bit_cast(short2_t, a), __builtin_bit_cast(short2_t, b), c, true);
 }
+
+__device__ __forceinline__ uint32_t uni(uint32_t v) { return uint32_t(__builtin_amdgcn_readfirstlane(int(v))); }
 
 // Blocks are dealt round-robin over the 8 XCDs; give each XCD a contiguous run of
 // logical blocks so neighbouring strips and row segments share one L2.
@@ -78,17 +90,11 @@ __device__ __forceinline__ uint32_t xcd_remap(uint32_t b, uint32_t n)
     return (x < r ? x * (q + 1) : r * (q + 1) + (x - r) * q) + k;
 }
 
-template <int LW>
-__device__ __forceinline__ int hpass(const uint32_t (&w)[LW / 4], const uint32_t (&c)[LW / 2])
+// 15-bit intermediate of swscale's horizontal pass: truncating >>7, clip to 32767
+__device__ __forceinline__ uint32_t hfinish(int acc)
 {
-    int acc = 0;
-#pragma unroll
-    for (int k = 0; k < LW / 4; ++k) {
-        acc = dot2(__builtin_amdgcn_perm(0, w[k], 0x0c010c00), c[2 * k], acc);
-        acc = dot2(__builtin_amdgcn_perm(0, w[k], 0x0c030c02), c[2 * k + 1], acc);
-    }
-    acc >>= 7;                         // truncating, keeps the sign
-    return acc < 32767 ? acc : 32767;
+    acc >>= 7;
+    return uint32_t(acc < 32767 ? acc : 32767);
 }
 
 // four vertical sums -> four clipped bytes (val >> 19, clip to 0..255)
@@ -105,31 +111,65 @@ __device__ __forceinline__ uint32_t pack4(int v0, int v1, int v2, int v3)
     return b01 | (b23 << 16);
 }
 
-// hoff  [strips*N]        first byte of each column's window
-// hcoef [strips*N][LW/2]  window taps as int16 pairs
-// vtab  [oh][2+R/2]       first row, last row, taps by ring slot as int16 pairs
-// The tables are __restrict__ kernel arguments so the wave-uniform reads become scalar loads.
-template <int LW, int R, int N>
+// How a lane fetches the source bytes of its N columns from one source row:
+//   kGroup4 (taps <= 4, 4 columns span <= 8 bytes): one 8-byte window per 4 columns; each column
+//           picks its taps out of the window with a per-lane byte selector (v_perm).
+//   else    one LW-byte window per column (LW = 4 or 8), taps at fixed byte positions.
+// The texture addresser handles a gather at 4 lanes per clock whatever its width, so fewer,
+// wider loads are what keeps it off the critical path.
+template <int LW, int N, bool kGroup4> struct RowWin {
+    static constexpr int NL = kGroup4 ? N / 4 : N;        // loads per row per lane
+    static constexpr int WD = kGroup4 ? 2 : LW / 4;       // dwords per load
+};
+
+template <int NL, int WD>
+__device__ __forceinline__ void load_row(uint32_t (&w)[NL][WD], __amdgpu_buffer_rsrc_t srs,
+                                         const uint32_t (&off)[NL], int rowoff)
+{
+#pragma unroll
+    for (int i = 0; i < NL; ++i) {
+        if constexpr (WD == 1) {
+            w[i][0] = __builtin_amdgcn_raw_buffer_load_b32(srs, off[i], rowoff, 0);
+        } else {
+            const u32x2_t t = __builtin_amdgcn_raw_buffer_load_b64(srs, off[i], rowoff, 0);
+            w[i][0] = t.x; w[i][1] = t.y;
+        }
+    }
+}
+
+// tab layout per class (dword offsets in StripClass):
+//   hoff   [cols/4] or [cols]   first byte of each window
+//   hsel   [cols][2]            (kGroup4 only) v_perm selectors: taps 0,1 and taps 2,3 as 16-bit lanes
+//   hcoef  [cols][LW/2]         horizontal taps as int16 pairs
+//   seginfo[nseg][2]            first source row, number of source rows of a row segment
+//   emit   [nseg][maxrows]      output rows completed by the k-th source row of the segment
+//   vcoef  [oh][R/2]            vertical taps by ring slot ((row - first row of segment) % R), int16 pairs
+// `tab` is a __restrict__ kernel argument so the wave-uniform reads become scalar loads.
+template <int LW, int R, int N, int D, bool G4>
 __global__ __launch_bounds__(kBlock) void strip_kernel(const uint8_t *__restrict__ src, uint8_t *__restrict__ dst,
-                                                       const uint32_t *__restrict__ hoff,
-                                                       const uint32_t *__restrict__ hcoef,
-                                                       const uint32_t *__restrict__ vtab, const StripArgs a)
+                                                       const uint32_t *__restrict__ tab, const StripArgs a)
 {
     static_assert(LW == 4 || LW == 8, "window is one or two dwords");
     static_assert(R % 2 == 0 && N % 4 == 0, "ring holds row pairs; stores are dwords");
-    constexpr int VS = 2 + R / 2;
+    static_assert(R % D == 0, "in-flight rows rotate with the ring");
+    static_assert(!G4 || LW == 4, "grouped windows carry at most 4 taps");
+    using RW = RowWin<LW, N, G4>;
 
-    const uint32_t lb  = xcd_remap(blockIdx.x, gridDim.x);
-    const int      seg = int(lb % uint32_t(a.nseg));
-    const int      sb  = int(lb / uint32_t(a.nseg));
-    int            g   = sb * kBlock + int(threadIdx.x);
-    const bool     live = g < a.n_items;
-    if (!live) g = a.n_items - 1;
+    uint32_t lb = xcd_remap(blockIdx.x, gridDim.x);
+    const int ci = lb >= a.c[0].nblocks ? 1 : 0;
+    if (ci) lb -= a.c[0].nblocks;
+    const StripClass &c = a.c[ci];
 
-    const int strip = g % a.strips;
-    const int fp    = g / a.strips;
-    const int plane = fp % a.planes;
-    const int frame = fp / a.planes;
+    const int seg = int(lb % uint32_t(c.nseg));
+    const int sb  = int(lb / uint32_t(c.nseg));
+    int       g   = sb * kBlock + int(threadIdx.x);
+    const bool live = g < c.n_items;
+    if (!live) g = c.n_items - 1;
+
+    const int strip = g % c.strips;
+    const int fp    = g / c.strips;
+    const int plane = c.plane0 + fp % c.planes;
+    const int frame = fp / c.planes;
     uint32_t soff, doff;
     if (a.addr.use_table) {
         soff = a.addr.src_tab[plane][frame];
@@ -141,13 +181,23 @@ __global__ __launch_bounds__(kBlock) void strip_kernel(const uint8_t *__restrict
     doff += uint32_t(strip) * N;
 
     // per-lane horizontal tables stay in registers for the whole walk
-    uint32_t off[N];
+    uint32_t off[RW::NL];
     uint32_t hc[N][LW / 2];
+    uint32_t sel[G4 ? N : 1][2];
+    {
+        const uint32_t *ho = tab + c.hoff + strip * RW::NL;
+        const uint32_t *hk = tab + c.hcoef + strip * N * (LW / 2);
 #pragma unroll
-    for (int i = 0; i < N; ++i) {
-        off[i] = hoff[strip * N + i] + soff;
+        for (int i = 0; i < RW::NL; ++i) off[i] = ho[i] + soff;
 #pragma unroll
-        for (int k = 0; k < LW / 2; ++k) hc[i][k] = hcoef[(strip * N + i) * (LW / 2) + k];
+        for (int i = 0; i < N; ++i)
+#pragma unroll
+            for (int k = 0; k < LW / 2; ++k) hc[i][k] = hk[i * (LW / 2) + k];
+        if constexpr (G4) {
+            const uint32_t *hs = tab + c.hsel + strip * N * 2;
+#pragma unroll
+            for (int i = 0; i < N; ++i) { sel[i][0] = hs[2 * i]; sel[i][1] = hs[2 * i + 1]; }
+        }
     }
 
     uint32_t ring[N][R / 2];
@@ -156,61 +206,71 @@ __global__ __launch_bounds__(kBlock) void strip_kernel(const uint8_t *__restrict
 #pragma unroll
         for (int k = 0; k < R / 2; ++k) ring[i][k] = 0;
 
-    const int y0 = seg * a.seg_rows;
-    const int y1 = min(a.oh, y0 + a.seg_rows);
-    int y = y0;
-    const int rstart = __builtin_amdgcn_readfirstlane(int(vtab[y0 * VS]));
-    const int rend   = __builtin_amdgcn_readfirstlane(int(vtab[(y1 - 1) * VS + 1]));
-    int ylast = __builtin_amdgcn_readfirstlane(int(vtab[y * VS + 1]));
-    const int cols = live ? min(N, a.ow - strip * N) : 0;     // valid columns of this strip
+    const int rstart = int(uni(tab[c.seginfo + 2 * seg]));
+    const int nrows  = int(uni(tab[c.seginfo + 2 * seg + 1]));
+    const uint32_t *emit = tab + c.emit + seg * c.maxrows;
+    const uint32_t *vco  = tab + c.vcoef;
+    int y = seg * c.seg_rows;
+    const int cols = live ? min(N, c.ow - strip * N) : 0;      // valid columns of this strip
+    const bool all_full = __builtin_amdgcn_ballot_w64(cols != N) == 0;   // wave-uniform
 
     // Buffer addressing: wave-uniform descriptor + per-lane 32-bit byte offset + scalar row
     // offset, so a row step costs no vector instructions; reads past the span return 0.
     const __amdgpu_buffer_rsrc_t srs = __builtin_amdgcn_make_buffer_rsrc(const_cast<uint8_t *>(src), 0, a.src_span, 0x00020000);
     const __amdgpu_buffer_rsrc_t drs = __builtin_amdgcn_make_buffer_rsrc(dst, 0, a.dst_span, 0x00020000);
 
-    for (int r0 = rstart - rstart % R; r0 <= rend; r0 += R) {
+    // D source rows are kept in flight so a row's bytes are requested D iterations before use.
+    uint32_t w[D][RW::NL][RW::WD];
+#pragma unroll
+    for (int d = 0; d < D; ++d) load_row<RW::NL, RW::WD>(w[d], srs, off, (rstart + min(d, nrows - 1)) * c.src_stride);
+    int cnt_next = int(uni(emit[0]));
+
+    for (int k0 = 0; k0 < nrows; k0 += R) {
 #pragma unroll
         for (int s = 0; s < R; ++s) {
-            const int r = r0 + s;
-            if (r < rstart || r > rend) continue;             // wave-uniform
-            const int rowoff = r * a.src_stride;
-            uint32_t w[N][LW / 4];
+            const int k = k0 + s;
+            if (k >= nrows) break;                              // wave-uniform
+            const int cnt = cnt_next;
+            cnt_next = int(uni(emit[min(k + 1, nrows - 1)]));
+            uint32_t (&wk)[RW::NL][RW::WD] = w[s % D];
 #pragma unroll
             for (int i = 0; i < N; ++i) {
-                if constexpr (LW == 4) {
-                    w[i][0] = __builtin_amdgcn_raw_buffer_load_b32(srs, off[i], rowoff, 0);
+                int acc = 0;
+                if constexpr (G4) {
+                    acc = dot2(__builtin_amdgcn_perm(wk[i / 4][1], wk[i / 4][0], sel[i][0]), hc[i][0], acc);
+                    acc = dot2(__builtin_amdgcn_perm(wk[i / 4][1], wk[i / 4][0], sel[i][1]), hc[i][1], acc);
                 } else {
-                    const u32x2_t t = __builtin_amdgcn_raw_buffer_load_b64(srs, off[i], rowoff, 0);
-                    w[i][0] = t.x; w[i][1] = t.y;
-                }
-            }
 #pragma unroll
-            for (int i = 0; i < N; ++i) {
-                const uint32_t t = uint32_t(hpass<LW>(w[i], hc[i]));
+                    for (int q = 0; q < LW / 4; ++q) {
+                        acc = dot2(__builtin_amdgcn_perm(0, wk[i][q], 0x0c010c00), hc[i][2 * q], acc);
+                        acc = dot2(__builtin_amdgcn_perm(0, wk[i][q], 0x0c030c02), hc[i][2 * q + 1], acc);
+                    }
+                }
+                const uint32_t t = hfinish(acc);
                 ring[i][s / 2] = (s & 1) ? __builtin_amdgcn_perm(t, ring[i][s / 2], 0x05040100)
                                          : __builtin_amdgcn_perm(ring[i][s / 2], t, 0x07060100);
             }
-            while (y < y1 && ylast == r) {                     // wave-uniform
-                const uint32_t *vt = vtab + y * VS + 2;
+            // refill the slot just consumed with row k + D (rows past the segment re-read its last row)
+            load_row<RW::NL, RW::WD>(wk, srs, off, (rstart + min(k + D, nrows - 1)) * c.src_stride);
+            for (int e = 0; e < cnt; ++e) {                     // wave-uniform
                 uint32_t vk[R / 2];
 #pragma unroll
-                for (int k = 0; k < R / 2; ++k) vk[k] = uint32_t(__builtin_amdgcn_readfirstlane(int(vt[k])));
+                for (int q = 0; q < R / 2; ++q) vk[q] = uni(vco[y * (R / 2) + q]);
                 uint32_t o[N / 4];
 #pragma unroll
                 for (int q = 0; q < N / 4; ++q) {
                     int v[4];
 #pragma unroll
-                    for (int e = 0; e < 4; ++e) {
+                    for (int j = 0; j < 4; ++j) {
                         int acc = 64 << 12;
 #pragma unroll
-                        for (int k = 0; k < R / 2; ++k) acc = dot2(ring[4 * q + e][k], vk[k], acc);
-                        v[e] = acc;
+                        for (int p = 0; p < R / 2; ++p) acc = dot2(ring[4 * q + j][p], vk[p], acc);
+                        v[j] = acc;
                     }
                     o[q] = pack4(v[0], v[1], v[2], v[3]);
                 }
-                const int outoff = y * a.dst_stride;
-                if (cols == N) {
+                const int outoff = y * c.dst_stride;
+                if (all_full || cols == N) {
                     if constexpr (N == 16) {
                         __builtin_amdgcn_raw_buffer_store_b128(u32x4_t{o[0], o[1], o[2], o[3]}, drs, doff, outoff, 0);
                     } else {
@@ -222,7 +282,6 @@ __global__ __launch_bounds__(kBlock) void strip_kernel(const uint8_t *__restrict
                         if (i < cols) __builtin_amdgcn_raw_buffer_store_b8(uint8_t(o[i / 4] >> (8 * (i % 4))), drs, doff + i, outoff, 0);
                 }
                 ++y;
-                ylast = __builtin_amdgcn_readfirstlane(int(vtab[min(y, a.oh - 1) * VS + 1]));
             }
         }
     }
@@ -236,8 +295,8 @@ struct GenericArgs {
     int32_t ht, vt;
     int32_t x0, y0, ow, oh;
     int32_t src_stride, dst_stride;
-    int32_t planes, n_fp;                          // frames*planes
-    PlaneAddr addr;
+    int32_t planes, plane0;
+    FrameAddr addr;
 };
 
 __global__ __launch_bounds__(kBlock) void generic_kernel(const GenericArgs a)
@@ -246,7 +305,7 @@ __global__ __launch_bounds__(kBlock) void generic_kernel(const GenericArgs a)
     const int y  = int(blockIdx.y) * 4 + int(threadIdx.x >> 6);
     const int fp = int(blockIdx.z);
     if (x >= a.ow || y >= a.oh) return;
-    const int plane = fp % a.planes, frame = fp / a.planes;
+    const int plane = a.plane0 + fp % a.planes, frame = fp / a.planes;
     uint32_t soff, doff;
     if (a.addr.use_table) {
         soff = a.addr.src_tab[plane][frame];
@@ -275,11 +334,12 @@ __global__ __launch_bounds__(kBlock) void generic_kernel(const GenericArgs a)
 
 struct FillArgs {
     uint8_t *dst;
-    int32_t w, h, stride;              // canvas of this plane
+    int32_t w, h, stride;              // canvas of this plane class
     int32_t px, py, pw, ph;            // picture rectangle that is left alone
-    int32_t planes, n_fp;
-    int32_t fill[2];
-    PlaneAddr addr;                    // dst side only
+    int32_t planes, plane0;
+    int32_t fill[3];
+    uint32_t origin;                   // bytes from the canvas origin to the picture origin
+    FrameAddr addr;                    // dst side only (plane origins point at the picture)
 };
 
 __global__ __launch_bounds__(kBlock) void fill_kernel(const FillArgs a)
@@ -288,9 +348,9 @@ __global__ __launch_bounds__(kBlock) void fill_kernel(const FillArgs a)
     const int y  = int(blockIdx.y) * 4 + int(threadIdx.x >> 6);
     const int fp = int(blockIdx.z);
     if (x >= a.w || y >= a.h) return;
-    const int plane = fp % a.planes, frame = fp / a.planes;
-    const uint32_t doff = a.addr.use_table ? a.addr.dst_tab[plane][frame]
-                                           : uint32_t(frame) * a.addr.dst_pitch + a.addr.dst_plane[plane];
+    const int plane = a.plane0 + fp % a.planes, frame = fp / a.planes;
+    const uint32_t doff = (a.addr.use_table ? a.addr.dst_tab[plane][frame]
+                                            : uint32_t(frame) * a.addr.dst_pitch + a.addr.dst_plane[plane]) - a.origin;
     uint8_t *row = a.dst + doff + size_t(y) * size_t(a.stride);
     const uint8_t f = uint8_t(a.fill[plane]);
     const bool in_rows = y >= a.py && y < a.py + a.ph;
@@ -306,6 +366,15 @@ __global__ __launch_bounds__(kBlock) void fill_kernel(const FillArgs a)
 
 namespace {
 
+constexpr int kSegOptions[] = {16, 24, 32, 48, 64, 96, 128, 256};
+constexpr int kNumSegOptions = int(sizeof(kSegOptions) / sizeof(kSegOptions[0]));
+
+struct SegTables {
+    int seg_rows = 0, nseg = 0, maxrows = 0;
+    uint32_t seginfo = 0, emit = 0, vcoef = 0;     // dword offsets into the plan's table buffer
+    int total_src_rows = 0;                        // sum over segments (halo cost model)
+};
+
 struct ClassPlan {
     tts::AxisFilter h, v;
     int sub = 0;
@@ -314,9 +383,12 @@ struct ClassPlan {
     int canvas_w = 0, canvas_h = 0;    // output plane
     int pad_x = 0, pad_y = 0;
     int kind = 0;                      // 0 generic, 1 strip
-    int LW = 0, R = 0, N = 0, strips = 0;
-    // device tables
-    uint32_t *d_hoff = nullptr, *d_hcoef = nullptr, *d_vtab = nullptr;
+    int LW = 0, R = 0;
+    uint32_t hoff = 0, hcoef = 0;      // dword offsets into the table buffer (columns padded to 16)
+    bool g4 = false;                   // grouped 8-byte windows usable (taps <= 4, every 4 columns span <= 8 bytes)
+    uint32_t hoff4 = 0, hsel4 = 0, hcoef4 = 0;
+    std::vector<SegTables> segs;
+    // generic tables
     int32_t *d_hpos = nullptr, *d_vpos = nullptr;
     int16_t *d_htaps = nullptr, *d_vtaps = nullptr;
 };
@@ -343,7 +415,9 @@ int env_int(const char *name, int dflt)
 struct tts_plan {
     tts_geom g;
     ClassPlan cls[2];
+    uint32_t *d_tab = nullptr;        // strip tables of both classes
     int device = 0;
+    int n_cus = 256;
 };
 
 namespace {
@@ -354,7 +428,39 @@ bool monotone(const std::vector<int32_t> &p)
     return true;
 }
 
-int build_class(const tts_geom &g, int sub, ClassPlan &c)
+inline uint32_t pack16(int16_t lo, int16_t hi) { return uint32_t(uint16_t(lo)) | (uint32_t(uint16_t(hi)) << 16); }
+
+void build_seg_tables(const ClassPlan &c, int seg_rows, std::vector<uint32_t> &tab, SegTables &st)
+{
+    const int VT = c.v.size, R = c.R;
+    st.seg_rows = seg_rows;
+    st.nseg = (c.oh + seg_rows - 1) / seg_rows;
+    st.maxrows = 0; st.total_src_rows = 0;
+    std::vector<int> first(st.nseg), rows(st.nseg);
+    for (int s = 0; s < st.nseg; ++s) {
+        const int y0 = s * seg_rows, y1 = std::min(c.oh, y0 + seg_rows);
+        first[s] = c.v.pos[c.y0 + y0];
+        rows[s] = c.v.pos[c.y0 + y1 - 1] + VT - first[s];
+        st.maxrows = std::max(st.maxrows, rows[s]);
+        st.total_src_rows += rows[s];
+    }
+    st.seginfo = uint32_t(tab.size());
+    for (int s = 0; s < st.nseg; ++s) { tab.push_back(uint32_t(first[s])); tab.push_back(uint32_t(rows[s])); }
+    st.emit = uint32_t(tab.size());
+    tab.resize(tab.size() + size_t(st.nseg) * st.maxrows, 0);
+    st.vcoef = uint32_t(tab.size());
+    tab.resize(tab.size() + size_t(c.oh) * (R / 2), 0);
+    for (int y = 0; y < c.oh; ++y) {
+        const int s = y / seg_rows, vy = c.y0 + y;
+        const int p = c.v.pos[vy];
+        tab[st.emit + size_t(s) * st.maxrows + (p + VT - 1 - first[s])] += 1;
+        int16_t slot[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+        for (int j = 0; j < VT; ++j) slot[(p + j - first[s]) % R] = c.v.taps[size_t(vy) * VT + j];
+        for (int k = 0; k < R / 2; ++k) tab[st.vcoef + size_t(y) * (R / 2) + k] = pack16(slot[2 * k], slot[2 * k + 1]);
+    }
+}
+
+int build_class(const tts_geom &g, int sub, ClassPlan &c, std::vector<uint32_t> &tab)
 {
     c.sub = sub;
     c.src_w = ceil_shift(g.pre_w, sub); c.src_h = ceil_shift(g.pre_h, sub);
@@ -379,109 +485,190 @@ int build_class(const tts_geom &g, int sub, ClassPlan &c)
                           !env_int("TTS_FORCE_GENERIC", 0);
     if (!strip_ok) { c.kind = 0; return TTS_OK; }
     c.kind = 1; c.LW = LW; c.R = R;
-    c.N = (LW == 4 && R == 4) ? 16 : 8;
-    c.strips = (c.ow + c.N - 1) / c.N;
 
-    std::vector<uint32_t> hoff(size_t(c.strips) * c.N), hcoef(size_t(c.strips) * c.N * (LW / 2), 0);
-    for (int i = 0; i < c.strips * c.N; ++i) {
+    // horizontal tables, columns padded to a multiple of 16 so N = 8 and N = 16 share them
+    const int ncols = (c.ow + 15) / 16 * 16;
+    c.hoff = uint32_t(tab.size());
+    tab.resize(tab.size() + ncols);
+    c.hcoef = uint32_t(tab.size());
+    tab.resize(tab.size() + size_t(ncols) * (LW / 2), 0);
+    for (int i = 0; i < ncols; ++i) {
         const int vx = c.x0 + std::min(i, c.ow - 1);
         const int pos = c.h.pos[vx];
-        const int lo = std::min(pos, c.src_w - LW);
+        const int lo = std::min(pos, c.src_w - LW);           // keep the window inside the row
         int16_t slot[8] = {0, 0, 0, 0, 0, 0, 0, 0};
         for (int j = 0; j < HT; ++j) slot[pos - lo + j] = c.h.taps[size_t(vx) * HT + j];
-        hoff[i] = uint32_t(lo);
-        for (int k = 0; k < LW / 2; ++k)
-            hcoef[size_t(i) * (LW / 2) + k] = uint32_t(uint16_t(slot[2 * k])) | (uint32_t(uint16_t(slot[2 * k + 1])) << 16);
+        tab[c.hoff + i] = uint32_t(lo);
+        for (int k = 0; k < LW / 2; ++k) tab[c.hcoef + size_t(i) * (LW / 2) + k] = pack16(slot[2 * k], slot[2 * k + 1]);
     }
-    const int VS = 2 + R / 2;
-    std::vector<uint32_t> vtab(size_t(c.oh) * VS, 0);
-    for (int y = 0; y < c.oh; ++y) {
-        const int vy = c.y0 + y;
-        const int first = c.v.pos[vy];
-        int16_t slot[8] = {0, 0, 0, 0, 0, 0, 0, 0};
-        for (int j = 0; j < VT; ++j) slot[(first + j) % R] = c.v.taps[size_t(vy) * VT + j];
-        vtab[size_t(y) * VS + 0] = uint32_t(first);
-        vtab[size_t(y) * VS + 1] = uint32_t(first + VT - 1);
-        for (int k = 0; k < R / 2; ++k)
-            vtab[size_t(y) * VS + 2 + k] = uint32_t(uint16_t(slot[2 * k])) | (uint32_t(uint16_t(slot[2 * k + 1])) << 16);
+    // grouped windows: one 8-byte window per 4 columns, taps picked by per-lane byte selectors
+    c.g4 = LW == 4 && c.src_w >= 8 && !env_int("TTS_NO_G4", 0);
+    std::vector<int> glo(ncols / 4);
+    for (int q = 0; q < ncols / 4 && c.g4; ++q) {
+        const int vx0 = c.x0 + std::min(4 * q, c.ow - 1), vx3 = c.x0 + std::min(4 * q + 3, c.ow - 1);
+        glo[q] = std::min(c.h.pos[vx0], c.src_w - 8);
+        if (c.h.pos[vx3] + HT - glo[q] > 8 || c.h.pos[vx0] < glo[q]) c.g4 = false;
     }
-    if (!upload(c.d_hoff, hoff) || !upload(c.d_hcoef, hcoef) || !upload(c.d_vtab, vtab)) return TTS_ERR_INITIALIZATION_FAILED;
+    if (c.g4) {
+        c.hoff4 = uint32_t(tab.size());
+        tab.resize(tab.size() + ncols / 4);
+        c.hsel4 = uint32_t(tab.size());
+        tab.resize(tab.size() + size_t(ncols) * 2);
+        c.hcoef4 = uint32_t(tab.size());
+        tab.resize(tab.size() + size_t(ncols) * 2, 0);
+        for (int i = 0; i < ncols; ++i) {
+            const int vx = c.x0 + std::min(i, c.ow - 1);
+            const uint32_t d = uint32_t(c.h.pos[vx] - glo[i / 4]);          // 0..4: first tap's byte in the window
+            int16_t t4[4] = {0, 0, 0, 0};
+            for (int j = 0; j < HT; ++j) t4[j] = c.h.taps[size_t(vx) * HT + j];
+            if (i % 4 == 0) tab[c.hoff4 + i / 4] = uint32_t(glo[i / 4]);
+            tab[c.hsel4 + 2 * size_t(i)]     = 0x0c000c00u | d | ((d + 1) << 16);
+            tab[c.hsel4 + 2 * size_t(i) + 1] = 0x0c000c00u | (d + 2) | ((d + 3) << 16);
+            tab[c.hcoef4 + 2 * size_t(i)]     = pack16(t4[0], t4[1]);
+            tab[c.hcoef4 + 2 * size_t(i) + 1] = pack16(t4[2], t4[3]);
+        }
+    }
+    std::vector<int> opts(kSegOptions, kSegOptions + kNumSegOptions);
+    const int forced = env_int("TTS_SEG_ROWS", 0);
+    if (forced > 0) opts.assign(1, forced);
+    for (int sr : opts) {
+        SegTables st;
+        build_seg_tables(c, sr, tab, st);
+        c.segs.push_back(st);
+    }
     return TTS_OK;
 }
 
 void free_class(ClassPlan &c)
 {
-    (void)hipFree(c.d_hoff); (void)hipFree(c.d_hcoef); (void)hipFree(c.d_vtab);
     (void)hipFree(c.d_hpos); (void)hipFree(c.d_vpos); (void)hipFree(c.d_htaps); (void)hipFree(c.d_vtaps);
 }
 
-typedef void (*strip_fn)(const uint8_t *, uint8_t *, const uint32_t *, const uint32_t *, const uint32_t *, const StripArgs);
+typedef void (*strip_fn)(const uint8_t *, uint8_t *, const uint32_t *, const StripArgs);
 
-strip_fn pick_strip(int LW, int R, int N)
+struct StripChoice { int LW, R, N; bool g4; };
+
+StripChoice strip_choice(const ClassPlan &c)
 {
-    if (LW == 4 && R == 4 && N == 16) return strip_kernel<4, 4, 16>;
-    if (LW == 4 && R == 6) return strip_kernel<4, 6, 8>;
-    if (LW == 4 && R == 8) return strip_kernel<4, 8, 8>;
-    if (LW == 8 && R == 4) return strip_kernel<8, 4, 8>;
-    if (LW == 8 && R == 6) return strip_kernel<8, 6, 8>;
-    if (LW == 8 && R == 8) return strip_kernel<8, 8, 8>;
+    StripChoice ch{c.LW, c.R, 8, c.g4};
+    if (c.LW == 4 && c.R == 4) ch.N = env_int("TTS_STRIP_N", 8) == 16 ? 16 : 8;
+    return ch;
+}
+
+strip_fn pick_strip(const StripChoice &ch)
+{
+    const int D = env_int("TTS_STRIP_D", 0);
+    if (ch.LW == 4 && ch.R == 4 && ch.g4) {
+        if (ch.N == 16) return D == 1 ? strip_kernel<4, 4, 16, 1, true> : strip_kernel<4, 4, 16, 2, true>;
+        return D == 1 ? strip_kernel<4, 4, 8, 1, true> : D == 4 ? strip_kernel<4, 4, 8, 4, true> : strip_kernel<4, 4, 8, 2, true>;
+    }
+    if (ch.LW == 4 && ch.R == 4) return ch.N == 16 ? strip_kernel<4, 4, 16, 1, false> : strip_kernel<4, 4, 8, 2, false>;
+    if (ch.LW == 4 && ch.R == 6) return ch.g4 ? strip_kernel<4, 6, 8, 2, true> : strip_kernel<4, 6, 8, 2, false>;
+    if (ch.LW == 4 && ch.R == 8) return ch.g4 ? strip_kernel<4, 8, 8, 2, true> : strip_kernel<4, 8, 8, 2, false>;
+    if (ch.LW == 8 && ch.R == 4) return strip_kernel<8, 4, 8, 2, false>;
+    if (ch.LW == 8 && ch.R == 6) return strip_kernel<8, 6, 8, 2, false>;
+    if (ch.LW == 8 && ch.R == 8) return strip_kernel<8, 8, 8, 2, false>;
     return nullptr;
 }
 
-// One launch set: frames [0, n) addressed by `addr` relative to (src, dst).
-int launch_class(const tts_plan *p, int ci, const uint8_t *src, uint8_t *dst, int n,
-                 int src_stride, int dst_stride, uint32_t src_span, uint32_t dst_span,
-                 const PlaneAddr &addr, hipStream_t st)
+void fill_strip_class(const tts_plan *p, int ci, int n, int N, bool g4, int src_stride, int dst_stride,
+                      const SegTables &st, StripClass &sc)
 {
     const ClassPlan &c = p->cls[ci];
-    const int planes = ci == 0 ? 1 : 2;
+    sc.hoff = g4 ? c.hoff4 : c.hoff; sc.hcoef = g4 ? c.hcoef4 : c.hcoef; sc.hsel = c.hsel4;
+    sc.seginfo = st.seginfo; sc.emit = st.emit; sc.vcoef = st.vcoef;
+    sc.maxrows = st.maxrows; sc.nseg = st.nseg; sc.seg_rows = st.seg_rows;
+    sc.strips = (c.ow + N - 1) / N;
+    sc.planes = ci ? 2 : 1; sc.plane0 = ci ? 1 : 0;
+    sc.n_items = n * sc.planes * sc.strips;
+    sc.ow = c.ow; sc.oh = c.oh; sc.src_stride = src_stride; sc.dst_stride = dst_stride;
+    sc.nblocks = uint32_t((sc.n_items + kBlock - 1) / kBlock) * uint32_t(st.nseg);
+}
 
-    if (p->g.do_pad) {
-        FillArgs f{};
-        f.dst = dst; f.w = c.canvas_w; f.h = c.canvas_h; f.stride = dst_stride;
-        f.px = c.pad_x; f.py = c.pad_y; f.pw = c.ow; f.ph = c.oh;
-        f.planes = planes; f.n_fp = n * planes;
-        f.fill[0] = ci == 0 ? p->g.fill_y : p->g.fill_u;
-        f.fill[1] = p->g.fill_v;
-        f.addr = addr;
-        // the picture origin is folded into dst_plane/dst_tab for the scaler; undo it for the canvas
-        const uint32_t shift = uint32_t(c.pad_y) * uint32_t(dst_stride) + uint32_t(c.pad_x);
-        for (int k = 0; k < 2; ++k) {
-            f.addr.dst_plane[k] -= shift;
-            for (int i = 0; i < kMaxTableFrames; ++i) f.addr.dst_tab[k][i] -= shift;
+// Pick the row-segment length: enough workgroups to keep every CU busy with little tail, but
+// segments long enough that the (taps-1)-row halo at each segment start stays cheap.
+const SegTables &pick_seg(const tts_plan *p, const int *cis, int ncls, int n, int N, int idx_of_class_to_return)
+{
+    const ClassPlan &ret = p->cls[cis[idx_of_class_to_return]];
+    if (ret.segs.size() == 1) return ret.segs[0];
+    double best = 1e300; size_t best_i = 0;
+    const double slots = double(p->n_cus) * 4.0;               // resident workgroups (4 per CU at <=128 VGPRs)
+    for (size_t i = 0; i < ret.segs.size(); ++i) {
+        double blocks = 0, work = 0;
+        for (int k = 0; k < ncls; ++k) {
+            const ClassPlan &c = p->cls[cis[k]];
+            const SegTables &st = c.segs[i];
+            const double sb = double((int64_t(n) * (cis[k] ? 2 : 1) * ((c.ow + N - 1) / N) + kBlock - 1) / kBlock);
+            blocks += sb * st.nseg;
+            work += sb * (st.total_src_rows + 1.5 * c.oh);      // row cost units: H pass ~1, V pass ~1.5 per out row... relative
         }
-        dim3 grid((c.canvas_w + 255) / 256, (c.canvas_h + 3) / 4, n * planes);
-        hipLaunchKernelGGL(fill_kernel, grid, dim3(kBlock), 0, st, f);
+        const double rounds = blocks / slots;
+        const double eff = rounds / std::max(1.0, std::ceil(rounds - 0.15));
+        const double cost = work / std::min(1.0, eff);
+        if (cost < best) { best = cost; best_i = i; }
+    }
+    return ret.segs[best_i];
+}
+
+// One launch set: frames [0, n) addressed by `addr` relative to (src, dst).
+int launch_all(const tts_plan *p, const uint8_t *src, uint8_t *dst, int n, const int src_stride[2],
+               const int dst_stride[2], uint32_t src_span, uint32_t dst_span, const FrameAddr &addr, hipStream_t st)
+{
+    if (p->g.do_pad) {
+        for (int ci = 0; ci < 2; ++ci) {
+            const ClassPlan &c = p->cls[ci];
+            FillArgs f{};
+            f.dst = dst; f.w = c.canvas_w; f.h = c.canvas_h; f.stride = dst_stride[ci];
+            f.px = c.pad_x; f.py = c.pad_y; f.pw = c.ow; f.ph = c.oh;
+            f.planes = ci ? 2 : 1; f.plane0 = ci ? 1 : 0;
+            f.fill[0] = p->g.fill_y; f.fill[1] = p->g.fill_u; f.fill[2] = p->g.fill_v;
+            f.origin = uint32_t(c.pad_y) * uint32_t(dst_stride[ci]) + uint32_t(c.pad_x);
+            f.addr = addr;
+            dim3 grid((c.canvas_w + 255) / 256, (c.canvas_h + 3) / 4, n * f.planes);
+            hipLaunchKernelGGL(fill_kernel, grid, dim3(kBlock), 0, st, f);
+        }
     }
 
-    if (c.kind == 1) {
+    // strip classes: one launch when both classes run the same instantiation, else one each
+    int strip_cls[2], ns = 0;
+    for (int ci = 0; ci < 2; ++ci) if (p->cls[ci].kind == 1) strip_cls[ns++] = ci;
+    bool merged = false;
+    if (ns == 2 && !env_int("TTS_NO_MERGE", 0)) {
+        const StripChoice a0 = strip_choice(p->cls[0]), a1 = strip_choice(p->cls[1]);
+        merged = a0.LW == a1.LW && a0.R == a1.R && a0.N == a1.N && a0.g4 == a1.g4;
+    }
+    for (int k = 0; k < ns; ++k) {
         StripArgs a{};
-        a.src_span = src_span; a.dst_span = dst_span;
-        a.src_stride = src_stride; a.dst_stride = dst_stride;
-        a.ow = c.ow; a.oh = c.oh;
-        a.strips = c.strips; a.planes = planes; a.n_items = n * planes * c.strips;
-        const int nsb = (a.n_items + kBlock - 1) / kBlock;
-        int seg_rows = env_int("TTS_SEG_ROWS", 0);
-        if (seg_rows <= 0) {
-            // enough row segments to put >= ~8 waves on every SIMD, but not shorter than 16 rows
-            seg_rows = 64;
-            while (seg_rows > 16 && int64_t(nsb) * ((c.oh + seg_rows - 1) / seg_rows) < 256 * 8) seg_rows >>= 1;
-        }
-        a.seg_rows = seg_rows; a.nseg = (c.oh + seg_rows - 1) / seg_rows;
-        a.addr = addr;
-        strip_fn fn = pick_strip(c.LW, c.R, c.N);
+        a.src_span = src_span; a.dst_span = dst_span; a.addr = addr;
+        const int ci = strip_cls[k];
+        const StripChoice ch = strip_choice(p->cls[ci]);
+        strip_fn fn = pick_strip(ch);
         if (!fn) return TTS_ERR_UNSUPPORTED;
-        hipLaunchKernelGGL(fn, dim3(uint32_t(nsb) * uint32_t(a.nseg)), dim3(kBlock), 0, st, src, dst, c.d_hoff, c.d_hcoef, c.d_vtab, a);
-    } else {
+        if (merged) {
+            for (int j = 0; j < 2; ++j)
+                fill_strip_class(p, j, n, ch.N, ch.g4, src_stride[j], dst_stride[j], pick_seg(p, strip_cls, 2, n, ch.N, j), a.c[j]);
+        } else {
+            // a single class rides in slot 0; slot 1 is empty
+            fill_strip_class(p, ci, n, ch.N, ch.g4, src_stride[ci], dst_stride[ci], pick_seg(p, &ci, 1, n, ch.N, 0), a.c[0]);
+            a.c[1] = a.c[0]; a.c[1].nblocks = 0;
+        }
+        const uint32_t blocks = a.c[0].nblocks + (merged ? a.c[1].nblocks : 0);
+        hipLaunchKernelGGL(fn, dim3(blocks), dim3(kBlock), 0, st, src, dst, p->d_tab, a);
+        if (merged) break;
+    }
+
+    for (int ci = 0; ci < 2; ++ci) {
+        const ClassPlan &c = p->cls[ci];
+        if (c.kind != 0) continue;
         GenericArgs a{};
         a.src = src; a.dst = dst;
         a.hpos = c.d_hpos; a.htaps = c.d_htaps; a.vpos = c.d_vpos; a.vtaps = c.d_vtaps;
         a.ht = c.h.size; a.vt = c.v.size;
         a.x0 = c.x0; a.y0 = c.y0; a.ow = c.ow; a.oh = c.oh;
-        a.src_stride = src_stride; a.dst_stride = dst_stride;
-        a.planes = planes; a.n_fp = n * planes;
+        a.src_stride = src_stride[ci]; a.dst_stride = dst_stride[ci];
+        a.planes = ci ? 2 : 1; a.plane0 = ci ? 1 : 0;
         a.addr = addr;
-        dim3 grid((c.ow + 63) / 64, (c.oh + 3) / 4, n * planes);
+        dim3 grid((c.ow + 63) / 64, (c.oh + 3) / 4, n * a.planes);
         hipLaunchKernelGGL(generic_kernel, grid, dim3(kBlock), 0, st, a);
     }
     return hipGetLastError() == hipSuccess ? TTS_OK : TTS_ERR_PROCESSING_FAILED;
@@ -518,7 +705,11 @@ int tts_plan_create(const tts_geom *g, tts_plan **out)
     tts_plan *p = new (std::nothrow) tts_plan();
     if (!p) return TTS_ERR_INITIALIZATION_FAILED;
     p->g = *g; p->device = dev;
-    for (int ci = 0; ci < 2 && rc == TTS_OK; ++ci) rc = build_class(*g, ci, p->cls[ci]);
+    int cus = 0;
+    if (hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) == hipSuccess && cus > 0) p->n_cus = cus;
+    std::vector<uint32_t> tab;
+    for (int ci = 0; ci < 2 && rc == TTS_OK; ++ci) rc = build_class(*g, ci, p->cls[ci], tab);
+    if (rc == TTS_OK && !upload(p->d_tab, tab)) rc = TTS_ERR_INITIALIZATION_FAILED;
     if (rc) {
         if (rc == TTS_ERR_INITIALIZATION_FAILED) g_last_error = std::string("table upload: ") + hipGetErrorString(hipGetLastError());
         tts_plan_destroy(p);
@@ -532,6 +723,7 @@ void tts_plan_destroy(tts_plan *p)
 {
     if (!p) return;
     free_class(p->cls[0]); free_class(p->cls[1]);
+    (void)hipFree(p->d_tab);
     delete p;
 }
 
@@ -583,9 +775,24 @@ int tts_run_batch(const tts_plan *p, const void *src, size_t src_pitch, void *ds
     if (n_frames == 0) return TTS_OK;
     if (!src || !dst) return TTS_ERR_INVALID_INPUT;
     const tts_geom &g = p->g;
-    if (src_pitch < tts_frame_bytes(g.in_w, g.in_h) || dst_pitch < tts_frame_bytes(g.out_w, g.out_h)) return TTS_ERR_INVALID_INPUT;
+    const size_t sbytes = tts_frame_bytes(g.in_w, g.in_h), dbytes = tts_frame_bytes(g.out_w, g.out_h);
+    if (src_pitch < sbytes || dst_pitch < dbytes) return TTS_ERR_INVALID_INPUT;
     if (src_pitch >= (size_t(1) << 31) || dst_pitch >= (size_t(1) << 31)) return TTS_ERR_UNSUPPORTED;
     hipStream_t st = static_cast<hipStream_t>(hip_stream);
+
+    FrameAddr addr{};
+    addr.src_pitch = uint32_t(src_pitch); addr.dst_pitch = uint32_t(dst_pitch);
+    int sstride[2], dstride[2];
+    uint32_t splane = 0, dplane = 0;
+    for (int k = 0; k < 3; ++k) {
+        const int ci = k ? 1 : 0;
+        const ClassPlan &c = p->cls[ci];
+        sstride[ci] = ceil_shift(g.in_w, ci); dstride[ci] = ceil_shift(g.out_w, ci);
+        addr.src_plane[k] = splane + uint32_t(g.pre_y >> ci) * sstride[ci] + uint32_t(g.pre_x >> ci);
+        addr.dst_plane[k] = dplane + uint32_t(c.pad_y) * dstride[ci] + uint32_t(c.pad_x);
+        splane += uint32_t(sstride[ci]) * ceil_shift(g.in_h, ci);
+        dplane += uint32_t(dstride[ci]) * ceil_shift(g.out_h, ci);
+    }
     // 32-bit lane offsets: keep each launch's span under 4 GiB
     const size_t span = size_t(0xF0000000u);
     const int chunk = int(std::max<size_t>(1, std::min(span / src_pitch, span / dst_pitch)));
@@ -593,25 +800,9 @@ int tts_run_batch(const tts_plan *p, const void *src, size_t src_pitch, void *ds
         const int n = std::min(chunk, n_frames - f0);
         const uint8_t *s = static_cast<const uint8_t *>(src) + size_t(f0) * src_pitch;
         uint8_t *d = static_cast<uint8_t *>(dst) + size_t(f0) * dst_pitch;
-        for (int ci = 0; ci < 2; ++ci) {
-            const ClassPlan &c = p->cls[ci];
-            const int sstride = ceil_shift(g.in_w, ci), dstride = ceil_shift(g.out_w, ci);
-            PlaneAddr addr{};
-            addr.src_pitch = uint32_t(src_pitch); addr.dst_pitch = uint32_t(dst_pitch);
-            const uint32_t s_y = uint32_t(g.in_w) * g.in_h, s_c = uint32_t(ceil_shift(g.in_w, 1)) * ceil_shift(g.in_h, 1);
-            const uint32_t d_y = uint32_t(g.out_w) * g.out_h, d_c = uint32_t(ceil_shift(g.out_w, 1)) * ceil_shift(g.out_h, 1);
-            const uint32_t s_in = uint32_t(g.pre_y >> ci) * sstride + uint32_t(g.pre_x >> ci);
-            const uint32_t d_in = uint32_t(c.pad_y) * dstride + uint32_t(c.pad_x);
-            if (ci == 0) { addr.src_plane[0] = s_in; addr.dst_plane[0] = d_in; }
-            else {
-                addr.src_plane[0] = s_y + s_in;       addr.dst_plane[0] = d_y + d_in;
-                addr.src_plane[1] = s_y + s_c + s_in; addr.dst_plane[1] = d_y + d_c + d_in;
-            }
-            const uint32_t sspan = uint32_t(size_t(n - 1) * src_pitch + tts_frame_bytes(g.in_w, g.in_h));
-            const uint32_t dspan = uint32_t(size_t(n - 1) * dst_pitch + tts_frame_bytes(g.out_w, g.out_h));
-            const int rc = launch_class(p, ci, s, d, n, sstride, dstride, sspan, dspan, addr, st);
-            if (rc) return rc;
-        }
+        const int rc = launch_all(p, s, d, n, sstride, dstride, uint32_t(size_t(n - 1) * src_pitch + sbytes),
+                                  uint32_t(size_t(n - 1) * dst_pitch + dbytes), addr, st);
+        if (rc) return rc;
     }
     return TTS_OK;
 }
@@ -650,33 +841,25 @@ int tts_run(const tts_plan *p, const tts_frame *src, const tts_frame *dst, int n
             smin = a; smax = b; dmin = c2; dmax = e;
             ++n;
         }
-        for (int ci = 0; ci < 2; ++ci) {
-            const ClassPlan &c = p->cls[ci];
-            const int sstride = src[f0].stride[ci], dstride = dst[f0].stride[ci];
-            PlaneAddr addr{};
-            addr.use_table = 1;
-            const uint32_t s_in = uint32_t(g.pre_y >> ci) * sstride + uint32_t(g.pre_x >> ci);
-            const uint32_t d_in = uint32_t(c.pad_y) * dstride + uint32_t(c.pad_x);
-            for (int i = 0; i < n; ++i)
-                for (int k = 0; k < (ci ? 2 : 1); ++k) {
-                    addr.src_tab[k][i] = uint32_t(uintptr_t(src[f0 + i].plane[ci + k]) - smin) + s_in;
-                    addr.dst_tab[k][i] = uint32_t(uintptr_t(dst[f0 + i].plane[ci + k]) - dmin) + d_in;
-                }
-            // bytes reachable from the common bases: furthest plane end of the group
-            size_t sspan = 0, dspan = 0;
-            for (int i = 0; i < n; ++i)
-                for (int k = 0; k < 3; ++k) {
-                    const int sub = k ? 1 : 0;
-                    sspan = std::max(sspan, size_t(uintptr_t(src[f0 + i].plane[k]) - smin) +
-                                            size_t(src[f0 + i].stride[k]) * (ceil_shift(g.in_h, sub) - 1) + ceil_shift(g.in_w, sub));
-                    dspan = std::max(dspan, size_t(uintptr_t(dst[f0 + i].plane[k]) - dmin) +
-                                            size_t(dst[f0 + i].stride[k]) * (ceil_shift(g.out_h, sub) - 1) + ceil_shift(g.out_w, sub));
-                }
-            const int rc = launch_class(p, ci, reinterpret_cast<const uint8_t *>(smin), reinterpret_cast<uint8_t *>(dmin),
-                                        n, sstride, dstride, uint32_t(std::min<size_t>(sspan, 0xFFFFFFFFu)),
-                                        uint32_t(std::min<size_t>(dspan, 0xFFFFFFFFu)), addr, st);
-            if (rc) return rc;
-        }
+        FrameAddr addr{};
+        addr.use_table = 1;
+        const int sstride[2] = {src[f0].stride[0], src[f0].stride[1]};
+        const int dstride[2] = {dst[f0].stride[0], dst[f0].stride[1]};
+        size_t sspan = 0, dspan = 0;    // bytes reachable from the common bases: furthest plane end of the group
+        for (int i = 0; i < n; ++i)
+            for (int k = 0; k < 3; ++k) {
+                const int ci = k ? 1 : 0;
+                const ClassPlan &c = p->cls[ci];
+                const size_t so = size_t(uintptr_t(src[f0 + i].plane[k]) - smin), dof = size_t(uintptr_t(dst[f0 + i].plane[k]) - dmin);
+                addr.src_tab[k][i] = uint32_t(so) + uint32_t(g.pre_y >> ci) * sstride[ci] + uint32_t(g.pre_x >> ci);
+                addr.dst_tab[k][i] = uint32_t(dof) + uint32_t(c.pad_y) * dstride[ci] + uint32_t(c.pad_x);
+                sspan = std::max(sspan, so + size_t(sstride[ci]) * (ceil_shift(g.in_h, ci) - 1) + ceil_shift(g.in_w, ci));
+                dspan = std::max(dspan, dof + size_t(dstride[ci]) * (ceil_shift(g.out_h, ci) - 1) + ceil_shift(g.out_w, ci));
+            }
+        const int rc = launch_all(p, reinterpret_cast<const uint8_t *>(smin), reinterpret_cast<uint8_t *>(dmin), n,
+                                  sstride, dstride, uint32_t(std::min<size_t>(sspan, 0xFFFFFFFFu)),
+                                  uint32_t(std::min<size_t>(dspan, 0xFFFFFFFFu)), addr, st);
+        if (rc) return rc;
         f0 += n;
     }
     return TTS_OK;
@@ -684,8 +867,9 @@ int tts_run(const tts_plan *p, const tts_frame *src, const tts_frame *dst, int n
 
 int tts_run_host(const tts_plan *p, const void *src, void *dst, int n_frames)
 {
-    if (!p || !src || !dst || n_frames < 0) return TTS_ERR_INVALID_INPUT;
+    if (!p || n_frames < 0) return TTS_ERR_INVALID_INPUT;
     if (n_frames == 0) return TTS_OK;
+    if (!src || !dst) return TTS_ERR_INVALID_INPUT;
     const size_t sb = tts_frame_bytes(p->g.in_w, p->g.in_h), db = tts_frame_bytes(p->g.out_w, p->g.out_h);
     void *ds = nullptr, *dd = nullptr;
     int rc = TTS_OK;

@@ -1,0 +1,73 @@
+#!/usr/bin/env python3
+"""Tuning sweep for the strip kernel: env knobs x geometries, one process, interleaved rounds.
+Usage: python tools/sweep.py [--frames 300] [--rounds 5] [--case portrait|thumb|4k|720p]"""
+import argparse
+import itertools
+import os
+import sys
+import time
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import torch
+import tiktoken_amd as tts
+
+CASES = {
+    "portrait": ("scale=1080:1920:force_original_aspect_ratio=increase,crop=1080:1920", 1920, 1080, 4095360),
+    "4k": ("scale=1080:1920:force_original_aspect_ratio=increase,crop=1080:1920", 3840, 2160, 7050240),
+    "720p": ("scale=1080:1920:force_original_aspect_ratio=increase,crop=1080:1920", 1280, 720, 3548880),
+    "thumb": ("scale=320:568:flags=area", 1080, 1920, 3383040),
+}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--frames", type=int, default=300)
+    ap.add_argument("--rounds", type=int, default=5)
+    ap.add_argument("--iters", type=int, default=5)
+    ap.add_argument("--case", default="portrait")
+    ap.add_argument("--segs", default="0,16,32,48,64,128")
+    ap.add_argument("--ns", default="16,8")
+    ap.add_argument("--extra", default="", help="comma list of ENV=V1|V2 knobs to cross")
+    args = ap.parse_args()
+    vf, iw, ih, algo = CASES[args.case]
+    knobs = {"TTS_SEG_ROWS": args.segs.split(","), "TTS_STRIP_N": args.ns.split(",")}
+    for e in filter(None, args.extra.split(",")):
+        k, v = e.split("=")
+        knobs[k] = v.split("|")
+    names = list(knobs)
+    combos = list(itertools.product(*[knobs[k] for k in names]))
+    plans = {}
+    src = None
+    for combo in combos:
+        for k, v in zip(names, combo):
+            os.environ[k] = v
+        plans[combo] = tts.Plan.from_vf(vf, iw, ih)
+    p0 = plans[combos[0]]
+    src = torch.randint(0, 256, (args.frames, p0.in_bytes), dtype=torch.uint8, device="cuda")
+    dst = torch.empty((args.frames, p0.out_bytes), dtype=torch.uint8, device="cuda")
+    times = {c: [] for c in combos}
+    for rnd in range(args.rounds + 1):
+        for combo in combos:
+            for k, v in zip(names, combo):
+                os.environ[k] = v
+            p = plans[combo]
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record()
+            for _ in range(args.iters):
+                p.run_batch(src, dst)
+            e1.record()
+            torch.cuda.synchronize()
+            if rnd:
+                times[combo].append(e0.elapsed_time(e1) / args.iters)
+    print("case %s frames %d  (ms per batch: median / min ; algorithmic GB/s at median ; %% of 8 TB/s)" % (args.case, args.frames))
+    for combo in sorted(combos, key=lambda c: sorted(times[c])[len(times[c]) // 2]):
+        t = sorted(times[combo])
+        med = t[len(t) // 2]
+        gbs = algo * args.frames / (med * 1e-3) / 1e9
+        print("  %-60s %8.4f / %8.4f   %8.1f GB/s  %5.1f%%   %.0f fps" % (
+            " ".join("%s=%s" % (k.replace("TTS_", ""), v) for k, v in zip(names, combo)), med, t[0], gbs, gbs / 80.0,
+            args.frames / (med * 1e-3)))
+
+
+if __name__ == "__main__":
+    main()
