@@ -1,0 +1,70 @@
+#!/usr/bin/env python3
+"""Regenerates tests/golden/*.npz from the CPU oracle (oracle/swscale_oracle.c).
+
+The reference (forestrebel/tiktoken) holds no pixel vectors and FFmpeg is not available
+(SURVEY.md 8c), so these are regression vectors of the project's own oracle: PARITY UNPINNED
+against real swscale.  Inputs are the seeded synthetic frames of tests/synth.py.
+
+    python tests/golden/make_golden.py
+"""
+import os
+import sys
+
+import numpy as np
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+ROOT = os.path.dirname(os.path.dirname(HERE))
+sys.path.insert(0, ROOT)
+sys.path.insert(0, os.path.join(ROOT, "tests"))
+import synth  # noqa: E402
+from oracle import oracle  # noqa: E402
+
+# (name, geometry dict) -- geometry spelled out so that this file does not depend on the product's parser
+def geom(in_w, in_h, sc_w, sc_h, alg=0, pre=None, crop=None, pad=None, fill=(16, 128, 128)):
+    pre = pre or (0, 0, in_w, in_h)
+    crop = crop or (0, 0, sc_w, sc_h)
+    g = dict(in_w=in_w, in_h=in_h, pre_x=pre[0], pre_y=pre[1], pre_w=pre[2], pre_h=pre[3],
+             do_scale=int((sc_w, sc_h) != (pre[2], pre[3])), alg=alg, sc_w=sc_w, sc_h=sc_h,
+             crop_x=crop[0], crop_y=crop[1], crop_w=crop[2], crop_h=crop[3],
+             do_pad=0, pad_x=0, pad_y=0, out_w=crop[2], out_h=crop[3],
+             fill_y=fill[0], fill_u=fill[1], fill_v=fill[2])
+    if pad:
+        g.update(do_pad=1, pad_x=pad[0], pad_y=pad[1], out_w=pad[2], out_h=pad[3])
+    return g
+
+
+CASES = {
+    # scaled-down relatives of the reference's and BASELINE.json's chains (same ratios, same phases)
+    "portrait_192x108": geom(192, 108, 341, 192, crop=(116, 0, 108, 192)),          # 1080p->portrait / 10
+    "portrait_from_4k_384x216": geom(384, 216, 341, 192, crop=(116, 0, 108, 192)),
+    "stretch_96x170_to_144x256": geom(96, 170, 144, 256),                            # processVideos.js:96 / 5
+    "thumb_pad_72x128": geom(72, 128, 101, 180, pad=(108, 0, 320, 180)),             # video.js:329-332, small source
+    "thumb_area_108x192": geom(108, 192, 32, 57, alg=1),                             # 320x568 area / 10
+    "bilinear_half": geom(128, 72, 64, 36, alg=2),
+    "precrop_scale": geom(100, 60, 128, 96, pre=(10, 6, 64, 32)),
+    "identity": geom(64, 48, 64, 48),
+}
+PATTERNS = ("random", "impulse", "zone")
+
+
+def main():
+    for name, g in CASES.items():
+        arrs = {"geom": np.array([g[k] for k in sorted(g)], np.int32), "geom_keys": np.array(sorted(g))}
+        for pat in PATTERNS:
+            src = synth.frames(pat, g["in_w"], g["in_h"], 1)
+            arrs["out_" + pat] = oracle.run_chain(g, src)[0]
+        np.savez_compressed(os.path.join(HERE, name + ".npz"), **arrs)
+        print(name, {k: v.shape for k, v in arrs.items() if k.startswith("out_")})
+    # coefficient tables of the headline geometries (first/last rows are where the border rules bite)
+    tabs = {}
+    for (s, d, one, alg) in [(1920, 3413, 1 << 14, 0), (1080, 1920, 1 << 12, 0), (960, 1707, 1 << 14, 0),
+                             (3840, 3413, 1 << 14, 0), (1080, 320, 1 << 14, 1), (1920, 568, 1 << 12, 1),
+                             (720, 101, 1 << 14, 0), (1280, 180, 1 << 12, 0)]:
+        c, p = oracle.filter_table(s, d, one, alg)
+        tabs["c_%d_%d_%d_%d" % (s, d, one, alg)] = c
+        tabs["p_%d_%d_%d_%d" % (s, d, one, alg)] = p
+    np.savez_compressed(os.path.join(HERE, "filter_tables.npz"), **tabs)
+
+
+if __name__ == "__main__":
+    main()

@@ -70,6 +70,7 @@ struct StripClass {
 struct StripArgs {
     StripClass c[2];
     uint32_t src_span, dst_span;   // bytes reachable from the base pointers (buffer range check)
+    int32_t  touch;                // rows of lead for the L1 line touch (0 = off)
     FrameAddr addr;
 };
 
@@ -111,6 +112,29 @@ __device__ __forceinline__ uint32_t pack4(int v0, int v1, int v2, int v3)
     return b01 | (b23 << 16);
 }
 
+// Output stores are issued from inline asm.  hipcc's s_waitcnt pass counts the vector-memory
+// operations it can see; with stores visible inside the variable-trip emission loop it can no
+// longer count and falls back to vmcnt(0) before every use of a prefetched row, which drains the
+// rows still in flight AND every store acknowledgement once per source row.  Stores it cannot see
+// leave it counting the row loads alone, vmcnt((D-1)*loads), which (the counter retires in issue
+// order) is never too weak: the hidden stores only make the wait retire a few more operations.
+template <int AUX>
+__device__ __forceinline__ void store_b128(u32x4_t v, u32x4_t rs, uint32_t off, int soff)
+{
+    if constexpr (AUX == 2) asm volatile("buffer_store_dwordx4 %0, %1, %2, %3 offen nt" :: "v"(v), "v"(off), "s"(rs), "s"(soff));
+    else asm volatile("buffer_store_dwordx4 %0, %1, %2, %3 offen" :: "v"(v), "v"(off), "s"(rs), "s"(soff));
+}
+template <int AUX>
+__device__ __forceinline__ void store_b64(u32x2_t v, u32x4_t rs, uint32_t off, int soff)
+{
+    if constexpr (AUX == 2) asm volatile("buffer_store_dwordx2 %0, %1, %2, %3 offen nt" :: "v"(v), "v"(off), "s"(rs), "s"(soff));
+    else asm volatile("buffer_store_dwordx2 %0, %1, %2, %3 offen" :: "v"(v), "v"(off), "s"(rs), "s"(soff));
+}
+__device__ __forceinline__ void store_b8(uint32_t v, u32x4_t rs, uint32_t off, int soff)
+{
+    asm volatile("buffer_store_byte %0, %1, %2, %3 offen" :: "v"(v), "v"(off), "s"(rs), "s"(soff));
+}
+
 // How a lane fetches the source bytes of its N columns from one source row:
 //   kGroup4 (taps <= 4, 4 columns span <= 8 bytes): one 8-byte window per 4 columns; each column
 //           picks its taps out of the window with a per-lane byte selector (v_perm).
@@ -122,16 +146,16 @@ template <int LW, int N, bool kGroup4> struct RowWin {
     static constexpr int WD = kGroup4 ? 2 : LW / 4;       // dwords per load
 };
 
-template <int NL, int WD>
+template <int NL, int WD, int AUX>
 __device__ __forceinline__ void load_row(uint32_t (&w)[NL][WD], __amdgpu_buffer_rsrc_t srs,
                                          const uint32_t (&off)[NL], int rowoff)
 {
 #pragma unroll
     for (int i = 0; i < NL; ++i) {
         if constexpr (WD == 1) {
-            w[i][0] = __builtin_amdgcn_raw_buffer_load_b32(srs, off[i], rowoff, 0);
+            w[i][0] = __builtin_amdgcn_raw_buffer_load_b32(srs, off[i], rowoff, AUX);
         } else {
-            const u32x2_t t = __builtin_amdgcn_raw_buffer_load_b64(srs, off[i], rowoff, 0);
+            const u32x2_t t = __builtin_amdgcn_raw_buffer_load_b64(srs, off[i], rowoff, AUX);
             w[i][0] = t.x; w[i][1] = t.y;
         }
     }
@@ -145,7 +169,23 @@ __device__ __forceinline__ void load_row(uint32_t (&w)[NL][WD], __amdgpu_buffer_
 //   emit   [nseg][maxrows]      output rows completed by the k-th source row of the segment
 //   vcoef  [oh][R/2]            vertical taps by ring slot ((row - first row of segment) % R), int16 pairs
 // `tab` is a __restrict__ kernel argument so the wave-uniform reads become scalar loads.
-template <int LW, int R, int N, int D, bool G4>
+typedef __attribute__((address_space(3))) void lds_void_t;
+
+// Bring the 128-byte lines that hold this wave's windows of a LATER source row into the vector L1,
+// one request per distinct line: only the first lane whose window starts in a line asks for it (as an
+// LDS-DMA dword into a sink, so no VGPR is in flight).  The gathers that follow `lead` rows later
+// then hit; without this every new line is first met by a burst of overlapping window reads and the
+// L1 stalls its whole pipe (stores included) on each hit-under-miss.
+__device__ __forceinline__ void touch_lines(__amdgpu_buffer_rsrc_t srs, uint32_t off0, int rowoff, uint32_t *sink)
+{
+#if defined(__HIP_DEVICE_COMPILE__)
+    const uint32_t line = (off0 + uint32_t(rowoff)) >> 7;
+    const uint32_t prev = uint32_t(__builtin_amdgcn_update_dpp(-1, int(line), 0x138 /* wave_shr:1 */, 0xf, 0xf, false));
+    if (line != prev) __builtin_amdgcn_raw_ptr_buffer_load_lds(srs, (lds_void_t *)sink, 4, off0, rowoff, 0, 0);
+#endif
+}
+
+template <int LW, int R, int N, int D, bool G4, int LAUX = 0, int SAUX = 0>
 __global__ __launch_bounds__(kBlock) void strip_kernel(const uint8_t *__restrict__ src, uint8_t *__restrict__ dst,
                                                        const uint32_t *__restrict__ tab, const StripArgs a)
 {
@@ -217,12 +257,16 @@ __global__ __launch_bounds__(kBlock) void strip_kernel(const uint8_t *__restrict
     // Buffer addressing: wave-uniform descriptor + per-lane 32-bit byte offset + scalar row
     // offset, so a row step costs no vector instructions; reads past the span return 0.
     const __amdgpu_buffer_rsrc_t srs = __builtin_amdgcn_make_buffer_rsrc(const_cast<uint8_t *>(src), 0, a.src_span, 0x00020000);
-    const __amdgpu_buffer_rsrc_t drs = __builtin_amdgcn_make_buffer_rsrc(dst, 0, a.dst_span, 0x00020000);
+    const uint64_t dbase = reinterpret_cast<uint64_t>(dst);
+    const u32x4_t drs = {uni(uint32_t(dbase)), uni(uint32_t(dbase >> 32) & 0xffffu), uni(a.dst_span), 0x00020000u};
 
     // D source rows are kept in flight so a row's bytes are requested D iterations before use.
+    __shared__ uint32_t touch_sink[kBlock];
+    uint32_t *sink = &touch_sink[__builtin_amdgcn_readfirstlane(int(threadIdx.x) & ~63)];
+    const int lead = a.touch;
     uint32_t w[D][RW::NL][RW::WD];
 #pragma unroll
-    for (int d = 0; d < D; ++d) load_row<RW::NL, RW::WD>(w[d], srs, off, (rstart + min(d, nrows - 1)) * c.src_stride);
+    for (int d = 0; d < D; ++d) load_row<RW::NL, RW::WD, LAUX>(w[d], srs, off, (rstart + min(d, nrows - 1)) * c.src_stride);
     int cnt_next = int(uni(emit[0]));
 
     for (int k0 = 0; k0 < nrows; k0 += R) {
@@ -233,6 +277,7 @@ __global__ __launch_bounds__(kBlock) void strip_kernel(const uint8_t *__restrict
             const int cnt = cnt_next;
             cnt_next = int(uni(emit[min(k + 1, nrows - 1)]));
             uint32_t (&wk)[RW::NL][RW::WD] = w[s % D];
+            if (lead > 0 && k + lead < nrows) touch_lines(srs, off[0], (rstart + k + lead) * c.src_stride, sink);
 #pragma unroll
             for (int i = 0; i < N; ++i) {
                 int acc = 0;
@@ -251,7 +296,7 @@ __global__ __launch_bounds__(kBlock) void strip_kernel(const uint8_t *__restrict
                                          : __builtin_amdgcn_perm(ring[i][s / 2], t, 0x07060100);
             }
             // refill the slot just consumed with row k + D (rows past the segment re-read its last row)
-            load_row<RW::NL, RW::WD>(wk, srs, off, (rstart + min(k + D, nrows - 1)) * c.src_stride);
+            load_row<RW::NL, RW::WD, LAUX>(wk, srs, off, (rstart + min(k + D, nrows - 1)) * c.src_stride);
             for (int e = 0; e < cnt; ++e) {                     // wave-uniform
                 uint32_t vk[R / 2];
 #pragma unroll
@@ -272,19 +317,234 @@ __global__ __launch_bounds__(kBlock) void strip_kernel(const uint8_t *__restrict
                 const int outoff = y * c.dst_stride;
                 if (all_full || cols == N) {
                     if constexpr (N == 16) {
-                        __builtin_amdgcn_raw_buffer_store_b128(u32x4_t{o[0], o[1], o[2], o[3]}, drs, doff, outoff, 0);
+                        store_b128<SAUX>(u32x4_t{o[0], o[1], o[2], o[3]}, drs, doff, outoff);
                     } else {
-                        __builtin_amdgcn_raw_buffer_store_b64(u32x2_t{o[0], o[1]}, drs, doff, outoff, 0);
+                        store_b64<SAUX>(u32x2_t{o[0], o[1]}, drs, doff, outoff);
                     }
                 } else {
 #pragma unroll
                     for (int i = 0; i < N; ++i)
-                        if (i < cols) __builtin_amdgcn_raw_buffer_store_b8(uint8_t(o[i / 4] >> (8 * (i % 4))), drs, doff + i, outoff, 0);
+                        if (i < cols) store_b8(o[i / 4] >> (8 * (i % 4)), drs, doff + i, outoff);
                 }
                 ++y;
             }
         }
     }
+}
+
+// ---- LDS-staged variant of the strip kernel (taps <= 4, grouped windows) ----------------------
+// Same walk as strip_kernel, but a wave first copies the run of source bytes that holds all of its
+// lanes' windows HBM/L2 -> LDS with ONE lane-contiguous 16-byte-per-lane LDS-DMA
+// (`buffer_load_dwordx4 ... lds`): every 128-byte line is requested exactly once, by one coalesced
+// instruction, instead of being met by dozens of overlapping per-lane window reads (each new line
+// then stalls the vector L1's pipe, stores included, on hit-under-miss).  The lanes pick their
+// 8-byte windows out of the wave's private LDS slot with ds_read_b64.  A wave's 64 strips may
+// straddle the end of a plane row (items are flattened over frames), so the run is one or two
+// pieces; more than two (rows shorter than a wave's run) fall back to strip_kernel.
+// Nothing in flight lives in VGPRs and hipcc does not order LDS reads behind LDS-DMA, so the waits
+// are ours: before row k is read we wait, exactly, until only the operations issued after row k's
+// DMA are outstanding -- the DMAs of the D-1 later rows plus the stores issued since (counted at
+// run time; gfx950 retires vector-memory operations in issue order).
+template <int V>
+__device__ __forceinline__ void wait_vm() { asm volatile("s_waitcnt vmcnt(%0)" ::"n"(V) : "memory"); }
+
+// wait until at most B + extra vector-memory operations are outstanding (extra clamped to 0..7;
+// a smaller count is always safe)
+template <int B>
+__device__ __forceinline__ void wait_vm_plus(int extra)
+{
+    switch (extra) {
+    case 0: wait_vm<B>(); break;
+    case 1: wait_vm<B + 1>(); break;
+    case 2: wait_vm<B + 2>(); break;
+    case 3: wait_vm<B + 3>(); break;
+    case 4: wait_vm<B + 4>(); break;
+    case 5: wait_vm<B + 5>(); break;
+    case 6: wait_vm<B + 6>(); break;
+    default: wait_vm<B + 7>(); break;
+    }
+}
+
+template <int R, int N, int D, int SAUX = 0>
+__global__ __launch_bounds__(kBlock) void strip_lds_kernel(const uint8_t *__restrict__ src, uint8_t *__restrict__ dst,
+                                                           const uint32_t *__restrict__ tab, const StripArgs a)
+{
+    static_assert(R % 2 == 0 && (N == 8 || N == 16) && R % D == 0, "see strip_kernel");
+#if defined(__HIP_DEVICE_COMPILE__)   // the LDS-DMA builtin exists in the device pass only
+    constexpr int NL = N / 4;                        // windows per row per lane
+    constexpr int kSlotBytes = 1024 + 16;
+    __shared__ __attribute__((aligned(16))) uint8_t lds[kBlock / 64][D][kSlotBytes];
+
+    uint32_t lb = xcd_remap(blockIdx.x, gridDim.x);
+    const int ci = lb >= a.c[0].nblocks ? 1 : 0;
+    if (ci) lb -= a.c[0].nblocks;
+    const StripClass &c = a.c[ci];
+
+    const int seg = int(lb % uint32_t(c.nseg));
+    const int sb  = int(lb / uint32_t(c.nseg));
+    int       g   = sb * kBlock + int(threadIdx.x);
+    const bool live = g < c.n_items;
+    if (!live) g = c.n_items - 1;
+    const int wave = __builtin_amdgcn_readfirstlane(int(threadIdx.x) >> 6);
+    const int lane = int(threadIdx.x) & 63;
+
+    const int strip = g % c.strips;
+    const int fp    = g / c.strips;
+    const int plane = c.plane0 + fp % c.planes;
+    const int frame = fp / c.planes;
+    uint32_t soff, doff;
+    if (a.addr.use_table) {
+        soff = a.addr.src_tab[plane][frame];
+        doff = a.addr.dst_tab[plane][frame];
+    } else {
+        soff = uint32_t(frame) * a.addr.src_pitch + a.addr.src_plane[plane];
+        doff = uint32_t(frame) * a.addr.dst_pitch + a.addr.dst_plane[plane];
+    }
+    doff += uint32_t(strip) * N;
+
+    uint32_t off[NL];
+    uint32_t hc[N][2];
+    uint32_t sel[N][2];
+    {
+        const uint32_t *ho = tab + c.hoff + strip * NL;
+        const uint32_t *hk = tab + c.hcoef + strip * N * 2;
+        const uint32_t *hs = tab + c.hsel + strip * N * 2;
+#pragma unroll
+        for (int i = 0; i < NL; ++i) off[i] = ho[i] + soff;
+#pragma unroll
+        for (int i = 0; i < N; ++i) {
+            hc[i][0] = hk[2 * i]; hc[i][1] = hk[2 * i + 1];
+            sel[i][0] = hs[2 * i]; sel[i][1] = hs[2 * i + 1];
+        }
+    }
+
+    // The wave's run of source bytes: piece A starts at lane 0's first window, piece B (if any)
+    // at the first lane whose windows restart in another plane row.  Both are 16-byte granular.
+    const uint32_t first = off[0], last = off[NL - 1] + 8;          // this lane's bytes: [first, last)
+    const uint32_t prev_first = uint32_t(__builtin_amdgcn_update_dpp(int(first), int(first), 0x138 /* wave_shr:1 */, 0xf, 0xf, false));
+    const bool restart = lane > 0 && (first < prev_first || first - prev_first > 256u);
+    const uint64_t rmask = __builtin_amdgcn_ballot_w64(restart);
+    const int bl = rmask ? __builtin_ctzll(rmask) : 64;               // first lane of piece B
+    const uint32_t a_start = uni(first) & ~15u;
+    const uint32_t a_last  = uint32_t(__builtin_amdgcn_readlane(int(last), bl - 1));
+    const uint32_t n_a     = (a_last - a_start + 15u) >> 4;           // 16-byte chunks of piece A
+    const uint32_t b_start = (bl < 64 ? uint32_t(__builtin_amdgcn_readlane(int(first), bl & 63)) : a_start) & ~15u;
+    const uint32_t b_last  = uint32_t(__builtin_amdgcn_readlane(int(last), 63));
+    const uint32_t n_b     = bl < 64 ? (b_last - b_start + 15u) >> 4 : 0u;
+    // two pieces at most, and they must fit the 64 x 16-byte slot (the host only picks this kernel
+    // for geometries where they do; anything else here would be silent corruption, so trap)
+    if (__builtin_popcountll(rmask) > 1 || n_a + n_b > 64u) __builtin_trap();
+
+    // chunk `lane` of the run -> where this lane's DMA reads from; window j -> where it lands in LDS
+    const uint32_t chunk_src = uint32_t(lane) < n_a ? a_start + 16u * uint32_t(lane)
+                                                    : b_start + 16u * min(uint32_t(lane) - n_a, n_b ? n_b - 1u : 0u);
+    uint32_t lpos[NL];
+#pragma unroll
+    for (int j = 0; j < NL; ++j) lpos[j] = lane < bl ? off[j] - a_start : 16u * n_a + (off[j] - b_start);
+    const uint32_t lds_wave = uint32_t(reinterpret_cast<uintptr_t>((lds_void_t *)&lds[wave][0][0]));   // LDS byte address
+#pragma unroll
+    for (int j = 0; j < NL; ++j) lpos[j] += lds_wave;
+
+    uint32_t ring[N][R / 2];
+#pragma unroll
+    for (int i = 0; i < N; ++i)
+#pragma unroll
+        for (int k = 0; k < R / 2; ++k) ring[i][k] = 0;
+
+    const int rstart = int(uni(tab[c.seginfo + 2 * seg]));
+    const int nrows  = int(uni(tab[c.seginfo + 2 * seg + 1]));
+    const uint32_t *emit = tab + c.emit + seg * c.maxrows;
+    const uint32_t *vco  = tab + c.vcoef;
+    int y = seg * c.seg_rows;
+    const int cols = live ? min(N, c.ow - strip * N) : 0;
+    const bool all_full = __builtin_amdgcn_ballot_w64(cols != N) == 0;   // wave-uniform
+
+    const __amdgpu_buffer_rsrc_t srs = __builtin_amdgcn_make_buffer_rsrc(const_cast<uint8_t *>(src), 0, a.src_span, 0x00020000);
+    const uint64_t dbase = reinterpret_cast<uint64_t>(dst);
+    const u32x4_t drs = {uni(uint32_t(dbase)), uni(uint32_t(dbase >> 32) & 0xffffu), uni(a.dst_span), 0x00020000u};
+
+#pragma unroll
+    for (int d = 0; d < D; ++d)
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(srs, (lds_void_t *)&lds[wave][d][0], 16, chunk_src,
+                                                 (rstart + min(d, nrows - 1)) * c.src_stride, 0, 0);
+    int cnt_next = int(uni(emit[0]));
+    int hist[D];                                   // stores issued in each of the last D iterations
+#pragma unroll
+    for (int d = 0; d < D; ++d) hist[d] = 0;
+
+    for (int k0 = 0; k0 < nrows; k0 += R) {
+#pragma unroll
+        for (int s = 0; s < R; ++s) {
+            const int k = k0 + s;
+            if (k >= nrows) break;                              // wave-uniform
+            const int cnt = cnt_next;
+            cnt_next = int(uni(emit[min(k + 1, nrows - 1)]));
+            // row k's DMA is followed by D-1 younger DMAs and the stores of the last D iterations
+            int younger = 0;
+#pragma unroll
+            for (int d = 0; d < D; ++d) younger += hist[d];
+            wait_vm_plus<D - 1>(all_full ? min(younger, 7) : 0);
+            // The window reads are inline asm: an LDS read hipcc can see gets its own vmcnt(0) (it orders
+            // LDS reads behind every outstanding LDS-DMA), which would undo the counted wait above.
+            // Reads and their lgkmcnt wait sit in ONE asm statement, so no output register exists,
+            // as far as the compiler can tell, before its data has landed.
+            u32x2_t wv[NL];
+            if constexpr (NL == 2) {
+                asm volatile("ds_read_b64 %0, %2 offset:%4\n\tds_read_b64 %1, %3 offset:%4\n\ts_waitcnt lgkmcnt(0)"
+                             : "=&v"(wv[0]), "=&v"(wv[1]) : "v"(lpos[0]), "v"(lpos[1]), "n"((s % D) * kSlotBytes) : "memory");
+            } else {
+                asm volatile("ds_read_b64 %0, %4 offset:%8\n\tds_read_b64 %1, %5 offset:%8\n\t"
+                             "ds_read_b64 %2, %6 offset:%8\n\tds_read_b64 %3, %7 offset:%8\n\ts_waitcnt lgkmcnt(0)"
+                             : "=&v"(wv[0]), "=&v"(wv[1]), "=&v"(wv[2]), "=&v"(wv[3])
+                             : "v"(lpos[0]), "v"(lpos[1]), "v"(lpos[2]), "v"(lpos[3]), "n"((s % D) * kSlotBytes) : "memory");
+            }
+            uint32_t wk[NL][2];
+#pragma unroll
+            for (int j = 0; j < NL; ++j) { wk[j][0] = wv[j].x; wk[j][1] = wv[j].y; }
+#pragma unroll
+            for (int i = 0; i < N; ++i) {
+                int acc = 0;
+                acc = dot2(__builtin_amdgcn_perm(wk[i / 4][1], wk[i / 4][0], sel[i][0]), hc[i][0], acc);
+                acc = dot2(__builtin_amdgcn_perm(wk[i / 4][1], wk[i / 4][0], sel[i][1]), hc[i][1], acc);
+                const uint32_t t = hfinish(acc);
+                ring[i][s / 2] = (s & 1) ? __builtin_amdgcn_perm(t, ring[i][s / 2], 0x05040100)
+                                         : __builtin_amdgcn_perm(ring[i][s / 2], t, 0x07060100);
+            }
+            // the slot is free again (its bytes sit in registers): request row k + D into it
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(srs, (lds_void_t *)&lds[wave][s % D][0], 16, chunk_src,
+                                                     (rstart + min(k + D, nrows - 1)) * c.src_stride, 0, 0);
+            for (int e = 0; e < cnt; ++e) {                     // wave-uniform
+                uint32_t vk[R / 2];
+#pragma unroll
+                for (int q = 0; q < R / 2; ++q) vk[q] = uni(vco[y * (R / 2) + q]);
+                uint32_t o[N / 4];
+#pragma unroll
+                for (int q = 0; q < N / 4; ++q) {
+                    int v[4];
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) {
+                        int acc = 64 << 12;
+#pragma unroll
+                        for (int p = 0; p < R / 2; ++p) acc = dot2(ring[4 * q + j][p], vk[p], acc);
+                        v[j] = acc;
+                    }
+                    o[q] = pack4(v[0], v[1], v[2], v[3]);
+                }
+                const int outoff = y * c.dst_stride;
+                if (all_full || cols == N) {
+                    if constexpr (N == 16) store_b128<SAUX>(u32x4_t{o[0], o[1], o[2], o[3]}, drs, doff, outoff);
+                    else store_b64<SAUX>(u32x2_t{o[0], o[1]}, drs, doff, outoff);
+                } else {
+#pragma unroll
+                    for (int i = 0; i < N; ++i)
+                        if (i < cols) store_b8(o[i / 4] >> (8 * (i % 4)), drs, doff + i, outoff);
+                }
+                ++y;
+            }
+            hist[s % D] = cnt;
+        }
+    }
+#endif
 }
 
 struct GenericArgs {
@@ -387,6 +647,7 @@ struct ClassPlan {
     uint32_t hoff = 0, hcoef = 0;      // dword offsets into the table buffer (columns padded to 16)
     bool g4 = false;                   // grouped 8-byte windows usable (taps <= 4, every 4 columns span <= 8 bytes)
     uint32_t hoff4 = 0, hsel4 = 0, hcoef4 = 0;
+    bool lds_ok[2] = {false, false};   // LDS-staged kernel usable with N = 8 / N = 16 columns per lane
     std::vector<SegTables> segs;
     // generic tables
     int32_t *d_hpos = nullptr, *d_vpos = nullptr;
@@ -528,6 +789,22 @@ int build_class(const tts_geom &g, int sub, ClassPlan &c, std::vector<uint32_t> 
             tab[c.hcoef4 + 2 * size_t(i) + 1] = pack16(t4[2], t4[3]);
         }
     }
+    // LDS-staged kernel: any 64 consecutive strips (they may wrap once into the next plane row) must
+    // need at most two runs of source bytes that together fit 64 sixteen-byte chunks.
+    for (int v = 0; v < 2 && c.g4; ++v) {
+        const int N = v ? 16 : 8, NL = N / 4, strips = (c.ow + N - 1) / N;
+        bool ok = strips >= 64;
+        auto chunks = [&](int s0, int s1) {   // strips [s0, s1] of one row
+            const uint32_t lo = uint32_t(glo[s0 * NL]), hi = uint32_t(glo[s1 * NL + NL - 1]) + 8u;
+            return (hi - lo + 30u) >> 4;      // worst case over the run's 16-byte alignment
+        };
+        for (int s0 = 0; s0 < strips && ok; ++s0) {
+            const int s1 = s0 + 63;
+            const uint32_t n = s1 < strips ? chunks(s0, s1) : chunks(s0, strips - 1) + chunks(0, s1 - strips);
+            ok = n <= 64u;
+        }
+        c.lds_ok[v] = ok && !env_int("TTS_NO_LDS", 0);
+    }
     std::vector<int> opts(kSegOptions, kSegOptions + kNumSegOptions);
     const int forced = env_int("TTS_SEG_ROWS", 0);
     if (forced > 0) opts.assign(1, forced);
@@ -546,20 +823,36 @@ void free_class(ClassPlan &c)
 
 typedef void (*strip_fn)(const uint8_t *, uint8_t *, const uint32_t *, const StripArgs);
 
-struct StripChoice { int LW, R, N; bool g4; };
+struct StripChoice { int LW, R, N; bool g4, lds; };
 
 StripChoice strip_choice(const ClassPlan &c)
 {
-    StripChoice ch{c.LW, c.R, 8, c.g4};
+    StripChoice ch{c.LW, c.R, 8, c.g4, false};
     if (c.LW == 4 && c.R == 4) ch.N = env_int("TTS_STRIP_N", 8) == 16 ? 16 : 8;
+    ch.lds = c.g4 && c.R == 4 && c.lds_ok[ch.N == 16];
     return ch;
 }
 
 strip_fn pick_strip(const StripChoice &ch)
 {
     const int D = env_int("TTS_STRIP_D", 0);
+    if (ch.lds) {
+        if (ch.N == 16 && D == 4) return strip_lds_kernel<4, 16, 4>;
+        if (ch.N == 16) return strip_lds_kernel<4, 16, 2>;
+        if (D == 4) return strip_lds_kernel<4, 8, 4>;
+        if (D == 1) return strip_lds_kernel<4, 8, 1>;
+        return strip_lds_kernel<4, 8, 2>;
+    }
     if (ch.LW == 4 && ch.R == 4 && ch.g4) {
         if (ch.N == 16) return D == 1 ? strip_kernel<4, 4, 16, 1, true> : strip_kernel<4, 4, 16, 2, true>;
+        const int la = env_int("TTS_LD_AUX", 0), sa = env_int("TTS_ST_AUX", 0);   // cache-policy experiments
+        if (la == 2 && sa == 0) return strip_kernel<4, 4, 8, 2, true, 2, 0>;
+        if (la == 16 && sa == 0) return strip_kernel<4, 4, 8, 2, true, 16, 0>;
+        if (la == 1 && sa == 0) return strip_kernel<4, 4, 8, 2, true, 1, 0>;
+        if (la == 17 && sa == 0) return strip_kernel<4, 4, 8, 2, true, 17, 0>;
+        if (la == 2 && sa == 2) return strip_kernel<4, 4, 8, 2, true, 2, 2>;
+        if (la == 0 && sa == 2) return strip_kernel<4, 4, 8, 2, true, 0, 2>;
+        if (la == 16 && sa == 2) return strip_kernel<4, 4, 8, 2, true, 16, 2>;
         return D == 1 ? strip_kernel<4, 4, 8, 1, true> : D == 4 ? strip_kernel<4, 4, 8, 4, true> : strip_kernel<4, 4, 8, 2, true>;
     }
     if (ch.LW == 4 && ch.R == 4) return ch.N == 16 ? strip_kernel<4, 4, 16, 1, false> : strip_kernel<4, 4, 8, 2, false>;
@@ -581,7 +874,7 @@ void fill_strip_class(const tts_plan *p, int ci, int n, int N, bool g4, int src_
     sc.strips = (c.ow + N - 1) / N;
     sc.planes = ci ? 2 : 1; sc.plane0 = ci ? 1 : 0;
     sc.n_items = n * sc.planes * sc.strips;
-    sc.ow = c.ow; sc.oh = c.oh; sc.src_stride = src_stride; sc.dst_stride = dst_stride;
+    sc.ow = c.ow; sc.oh = c.oh; sc.src_stride = env_int("TTS_EXP_STRIDE0", 0) ? 0 : src_stride; sc.dst_stride = dst_stride;
     sc.nblocks = uint32_t((sc.n_items + kBlock - 1) / kBlock) * uint32_t(st.nseg);
 }
 
@@ -635,11 +928,12 @@ int launch_all(const tts_plan *p, const uint8_t *src, uint8_t *dst, int n, const
     bool merged = false;
     if (ns == 2 && !env_int("TTS_NO_MERGE", 0)) {
         const StripChoice a0 = strip_choice(p->cls[0]), a1 = strip_choice(p->cls[1]);
-        merged = a0.LW == a1.LW && a0.R == a1.R && a0.N == a1.N && a0.g4 == a1.g4;
+        merged = a0.LW == a1.LW && a0.R == a1.R && a0.N == a1.N && a0.g4 == a1.g4 && a0.lds == a1.lds;
     }
     for (int k = 0; k < ns; ++k) {
         StripArgs a{};
         a.src_span = src_span; a.dst_span = dst_span; a.addr = addr;
+        a.touch = env_int("TTS_TOUCH", 0);
         const int ci = strip_cls[k];
         const StripChoice ch = strip_choice(p->cls[ci]);
         strip_fn fn = pick_strip(ch);
