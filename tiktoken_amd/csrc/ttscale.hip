@@ -218,7 +218,7 @@ __global__ __launch_bounds__(kBlock) void strip_kernel(const uint8_t *__restrict
         soff = uint32_t(frame) * a.addr.src_pitch + a.addr.src_plane[plane];
         doff = uint32_t(frame) * a.addr.dst_pitch + a.addr.dst_plane[plane];
     }
-    doff += uint32_t(strip) * N;
+    doff += uint32_t(min(strip * N, max(c.ow - N, 0)));      // the last strip is slid left, not cut short
 
     // per-lane horizontal tables stay in registers for the whole walk
     uint32_t off[RW::NL];
@@ -251,7 +251,7 @@ __global__ __launch_bounds__(kBlock) void strip_kernel(const uint8_t *__restrict
     const uint32_t *emit = tab + c.emit + seg * c.maxrows;
     const uint32_t *vco  = tab + c.vcoef;
     int y = seg * c.seg_rows;
-    const int cols = live ? min(N, c.ow - strip * N) : 0;      // valid columns of this strip
+    const int cols = live ? min(N, c.ow) : 0;                  // < N only for planes narrower than a strip
     const bool all_full = __builtin_amdgcn_ballot_w64(cols != N) == 0;   // wave-uniform
 
     // Buffer addressing: wave-uniform descriptor + per-lane 32-bit byte offset + scalar row
@@ -400,7 +400,7 @@ __global__ __launch_bounds__(kBlock) void strip_lds_kernel(const uint8_t *__rest
         soff = uint32_t(frame) * a.addr.src_pitch + a.addr.src_plane[plane];
         doff = uint32_t(frame) * a.addr.dst_pitch + a.addr.dst_plane[plane];
     }
-    doff += uint32_t(strip) * N;
+    doff += uint32_t(min(strip * N, max(c.ow - N, 0)));      // the last strip is slid left, not cut short
 
     uint32_t off[NL];
     uint32_t hc[N][2];
@@ -456,7 +456,7 @@ __global__ __launch_bounds__(kBlock) void strip_lds_kernel(const uint8_t *__rest
     const uint32_t *emit = tab + c.emit + seg * c.maxrows;
     const uint32_t *vco  = tab + c.vcoef;
     int y = seg * c.seg_rows;
-    const int cols = live ? min(N, c.ow - strip * N) : 0;
+    const int cols = live ? min(N, c.ow) : 0;                  // < N only for planes narrower than a strip
     const bool all_full = __builtin_amdgcn_ballot_w64(cols != N) == 0;   // wave-uniform
 
     const __amdgpu_buffer_rsrc_t srs = __builtin_amdgcn_make_buffer_rsrc(const_cast<uint8_t *>(src), 0, a.src_span, 0x00020000);
@@ -635,6 +635,15 @@ struct SegTables {
     int total_src_rows = 0;                        // sum over segments (halo cost model)
 };
 
+// Horizontal tables of one plane class for one strip width (dword offsets into the table buffer).
+struct HTables {
+    int strips = 0;
+    uint32_t hoff = 0, hcoef = 0;                  // one window per column
+    bool g4 = false;                               // grouped 8-byte windows usable (taps <= 4, 4 columns span <= 8 bytes)
+    uint32_t hoff4 = 0, hsel4 = 0, hcoef4 = 0;
+    bool lds_ok = false;                           // LDS-staged kernel usable
+};
+
 struct ClassPlan {
     tts::AxisFilter h, v;
     int sub = 0;
@@ -644,10 +653,7 @@ struct ClassPlan {
     int pad_x = 0, pad_y = 0;
     int kind = 0;                      // 0 generic, 1 strip
     int LW = 0, R = 0;
-    uint32_t hoff = 0, hcoef = 0;      // dword offsets into the table buffer (columns padded to 16)
-    bool g4 = false;                   // grouped 8-byte windows usable (taps <= 4, every 4 columns span <= 8 bytes)
-    uint32_t hoff4 = 0, hsel4 = 0, hcoef4 = 0;
-    bool lds_ok[2] = {false, false};   // LDS-staged kernel usable with N = 8 / N = 16 columns per lane
+    HTables ht[2];                     // horizontal tables for N = 8 and N = 16 columns per lane
     std::vector<SegTables> segs;
     // generic tables
     int32_t *d_hpos = nullptr, *d_vpos = nullptr;
@@ -747,63 +753,68 @@ int build_class(const tts_geom &g, int sub, ClassPlan &c, std::vector<uint32_t> 
     if (!strip_ok) { c.kind = 0; return TTS_OK; }
     c.kind = 1; c.LW = LW; c.R = R;
 
-    // horizontal tables, columns padded to a multiple of 16 so N = 8 and N = 16 share them
-    const int ncols = (c.ow + 15) / 16 * 16;
-    c.hoff = uint32_t(tab.size());
-    tab.resize(tab.size() + ncols);
-    c.hcoef = uint32_t(tab.size());
-    tab.resize(tab.size() + size_t(ncols) * (LW / 2), 0);
-    for (int i = 0; i < ncols; ++i) {
-        const int vx = c.x0 + std::min(i, c.ow - 1);
-        const int pos = c.h.pos[vx];
-        const int lo = std::min(pos, c.src_w - LW);           // keep the window inside the row
-        int16_t slot[8] = {0, 0, 0, 0, 0, 0, 0, 0};
-        for (int j = 0; j < HT; ++j) slot[pos - lo + j] = c.h.taps[size_t(vx) * HT + j];
-        tab[c.hoff + i] = uint32_t(lo);
-        for (int k = 0; k < LW / 2; ++k) tab[c.hcoef + size_t(i) * (LW / 2) + k] = pack16(slot[2 * k], slot[2 * k + 1]);
-    }
-    // grouped windows: one 8-byte window per 4 columns, taps picked by per-lane byte selectors
-    c.g4 = LW == 4 && c.src_w >= 8 && !env_int("TTS_NO_G4", 0);
-    std::vector<int> glo(ncols / 4);
-    for (int q = 0; q < ncols / 4 && c.g4; ++q) {
-        const int vx0 = c.x0 + std::min(4 * q, c.ow - 1), vx3 = c.x0 + std::min(4 * q + 3, c.ow - 1);
-        glo[q] = std::min(c.h.pos[vx0], c.src_w - 8);
-        if (c.h.pos[vx3] + HT - glo[q] > 8 || c.h.pos[vx0] < glo[q]) c.g4 = false;
-    }
-    if (c.g4) {
-        c.hoff4 = uint32_t(tab.size());
+    // Horizontal tables, one set per strip width N.  Strip s covers columns [xs, xs + N) with
+    // xs = min(s * N, ow - N): the last strip is slid left over its neighbour instead of being cut
+    // short (the shared columns are simply produced twice, identically), so every lane stores N
+    // full bytes and the kernels need no ragged-edge path unless the plane is narrower than N.
+    for (int v = 0; v < 2; ++v) {
+        HTables &t = c.ht[v];
+        const int N = v ? 16 : 8, NL = N / 4;
+        t.strips = (c.ow + N - 1) / N;
+        const int ncols = t.strips * N;
+        auto column = [&](int i) { return c.x0 + std::min(std::min((i / N) * N, std::max(c.ow - N, 0)) + i % N, c.ow - 1); };
+        t.hoff = uint32_t(tab.size());
+        tab.resize(tab.size() + ncols);
+        t.hcoef = uint32_t(tab.size());
+        tab.resize(tab.size() + size_t(ncols) * (LW / 2), 0);
+        for (int i = 0; i < ncols; ++i) {
+            const int vx = column(i);
+            const int pos = c.h.pos[vx];
+            const int lo = std::min(pos, c.src_w - LW);           // keep the window inside the row
+            int16_t slot[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+            for (int j = 0; j < HT; ++j) slot[pos - lo + j] = c.h.taps[size_t(vx) * HT + j];
+            tab[t.hoff + i] = uint32_t(lo);
+            for (int k = 0; k < LW / 2; ++k) tab[t.hcoef + size_t(i) * (LW / 2) + k] = pack16(slot[2 * k], slot[2 * k + 1]);
+        }
+        // grouped windows: one 8-byte window per 4 columns, taps picked by per-lane byte selectors
+        t.g4 = LW == 4 && c.src_w >= 8 && !env_int("TTS_NO_G4", 0);
+        std::vector<int> glo(ncols / 4);
+        for (int q = 0; q < ncols / 4 && t.g4; ++q) {
+            const int vx0 = column(4 * q), vx3 = column(4 * q + 3);
+            glo[q] = std::min(c.h.pos[vx0], c.src_w - 8);
+            if (c.h.pos[vx3] + HT - glo[q] > 8 || c.h.pos[vx0] < glo[q]) t.g4 = false;
+        }
+        if (!t.g4) continue;
+        t.hoff4 = uint32_t(tab.size());
         tab.resize(tab.size() + ncols / 4);
-        c.hsel4 = uint32_t(tab.size());
+        t.hsel4 = uint32_t(tab.size());
         tab.resize(tab.size() + size_t(ncols) * 2);
-        c.hcoef4 = uint32_t(tab.size());
+        t.hcoef4 = uint32_t(tab.size());
         tab.resize(tab.size() + size_t(ncols) * 2, 0);
         for (int i = 0; i < ncols; ++i) {
-            const int vx = c.x0 + std::min(i, c.ow - 1);
+            const int vx = column(i);
             const uint32_t d = uint32_t(c.h.pos[vx] - glo[i / 4]);          // 0..4: first tap's byte in the window
             int16_t t4[4] = {0, 0, 0, 0};
             for (int j = 0; j < HT; ++j) t4[j] = c.h.taps[size_t(vx) * HT + j];
-            if (i % 4 == 0) tab[c.hoff4 + i / 4] = uint32_t(glo[i / 4]);
-            tab[c.hsel4 + 2 * size_t(i)]     = 0x0c000c00u | d | ((d + 1) << 16);
-            tab[c.hsel4 + 2 * size_t(i) + 1] = 0x0c000c00u | (d + 2) | ((d + 3) << 16);
-            tab[c.hcoef4 + 2 * size_t(i)]     = pack16(t4[0], t4[1]);
-            tab[c.hcoef4 + 2 * size_t(i) + 1] = pack16(t4[2], t4[3]);
+            if (i % 4 == 0) tab[t.hoff4 + i / 4] = uint32_t(glo[i / 4]);
+            tab[t.hsel4 + 2 * size_t(i)]     = 0x0c000c00u | d | ((d + 1) << 16);
+            tab[t.hsel4 + 2 * size_t(i) + 1] = 0x0c000c00u | (d + 2) | ((d + 3) << 16);
+            tab[t.hcoef4 + 2 * size_t(i)]     = pack16(t4[0], t4[1]);
+            tab[t.hcoef4 + 2 * size_t(i) + 1] = pack16(t4[2], t4[3]);
         }
-    }
-    // LDS-staged kernel: any 64 consecutive strips (they may wrap once into the next plane row) must
-    // need at most two runs of source bytes that together fit 64 sixteen-byte chunks.
-    for (int v = 0; v < 2 && c.g4; ++v) {
-        const int N = v ? 16 : 8, NL = N / 4, strips = (c.ow + N - 1) / N;
-        bool ok = strips >= 64;
+        // LDS-staged kernel: any 64 consecutive strips (they may wrap once into the next plane row)
+        // must need at most two runs of source bytes that together fit 64 sixteen-byte chunks.
+        bool ok = t.strips >= 64 && c.ow >= N && R == 4;
         auto chunks = [&](int s0, int s1) {   // strips [s0, s1] of one row
             const uint32_t lo = uint32_t(glo[s0 * NL]), hi = uint32_t(glo[s1 * NL + NL - 1]) + 8u;
             return (hi - lo + 30u) >> 4;      // worst case over the run's 16-byte alignment
         };
-        for (int s0 = 0; s0 < strips && ok; ++s0) {
+        for (int s0 = 0; s0 < t.strips && ok; ++s0) {
             const int s1 = s0 + 63;
-            const uint32_t n = s1 < strips ? chunks(s0, s1) : chunks(s0, strips - 1) + chunks(0, s1 - strips);
+            const uint32_t n = s1 < t.strips ? chunks(s0, s1) : chunks(s0, t.strips - 1) + chunks(0, s1 - t.strips);
             ok = n <= 64u;
         }
-        c.lds_ok[v] = ok && !env_int("TTS_NO_LDS", 0);
+        t.lds_ok = ok && !env_int("TTS_NO_LDS", 0);
     }
     std::vector<int> opts(kSegOptions, kSegOptions + kNumSegOptions);
     const int forced = env_int("TTS_SEG_ROWS", 0);
@@ -827,9 +838,11 @@ struct StripChoice { int LW, R, N; bool g4, lds; };
 
 StripChoice strip_choice(const ClassPlan &c)
 {
-    StripChoice ch{c.LW, c.R, 8, c.g4, false};
+    StripChoice ch{c.LW, c.R, 8, false, false};
     if (c.LW == 4 && c.R == 4) ch.N = env_int("TTS_STRIP_N", 8) == 16 ? 16 : 8;
-    ch.lds = c.g4 && c.R == 4 && c.lds_ok[ch.N == 16];
+    const HTables &t = c.ht[ch.N == 16];
+    ch.g4 = t.g4;
+    ch.lds = t.g4 && c.R == 4 && t.lds_ok;
     return ch;
 }
 
@@ -868,10 +881,11 @@ void fill_strip_class(const tts_plan *p, int ci, int n, int N, bool g4, int src_
                       const SegTables &st, StripClass &sc)
 {
     const ClassPlan &c = p->cls[ci];
-    sc.hoff = g4 ? c.hoff4 : c.hoff; sc.hcoef = g4 ? c.hcoef4 : c.hcoef; sc.hsel = c.hsel4;
+    const HTables &t = c.ht[N == 16];
+    sc.hoff = g4 ? t.hoff4 : t.hoff; sc.hcoef = g4 ? t.hcoef4 : t.hcoef; sc.hsel = t.hsel4;
     sc.seginfo = st.seginfo; sc.emit = st.emit; sc.vcoef = st.vcoef;
     sc.maxrows = st.maxrows; sc.nseg = st.nseg; sc.seg_rows = st.seg_rows;
-    sc.strips = (c.ow + N - 1) / N;
+    sc.strips = t.strips;
     sc.planes = ci ? 2 : 1; sc.plane0 = ci ? 1 : 0;
     sc.n_items = n * sc.planes * sc.strips;
     sc.ow = c.ow; sc.oh = c.oh; sc.src_stride = env_int("TTS_EXP_STRIDE0", 0) ? 0 : src_stride; sc.dst_stride = dst_stride;

@@ -11,9 +11,9 @@ acc = defaultdict(lambda: defaultdict(list))
 for f in glob.glob(os.path.join(out, "p*", "**", "*counter_collection.csv"), recursive=True):
     for r in csv.DictReader(open(f)):
         k = r["Kernel_Name"]
-        if "strip_kernel" not in k and "generic_kernel" not in k:
+        if "strip_" not in k and "generic_kernel" not in k:
             continue
-        k = k[k.index("strip_kernel") if "strip_kernel" in k else 0:][:28]
+        k = k[k.index("strip_") if "strip_" in k else 0:][:32]
         acc[k][r["Counter_Name"]].append(float(r["Counter_Value"]))
 lines = []
 for k, cs in acc.items():
