@@ -29,7 +29,9 @@
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <mutex>
 #include <new>
+#include <utility>
 #include <string>
 #include <vector>
 
@@ -70,7 +72,6 @@ struct StripClass {
 struct StripArgs {
     StripClass c[2];
     uint32_t src_span, dst_span;   // bytes reachable from the base pointers (buffer range check)
-    int32_t  touch;                // rows of lead for the L1 line touch (0 = off)
     FrameAddr addr;
 };
 
@@ -118,17 +119,13 @@ __device__ __forceinline__ uint32_t pack4(int v0, int v1, int v2, int v3)
 // rows still in flight AND every store acknowledgement once per source row.  Stores it cannot see
 // leave it counting the row loads alone, vmcnt((D-1)*loads), which (the counter retires in issue
 // order) is never too weak: the hidden stores only make the wait retire a few more operations.
-template <int AUX>
 __device__ __forceinline__ void store_b128(u32x4_t v, u32x4_t rs, uint32_t off, int soff)
 {
-    if constexpr (AUX == 2) asm volatile("buffer_store_dwordx4 %0, %1, %2, %3 offen nt" :: "v"(v), "v"(off), "s"(rs), "s"(soff));
-    else asm volatile("buffer_store_dwordx4 %0, %1, %2, %3 offen" :: "v"(v), "v"(off), "s"(rs), "s"(soff));
+    asm volatile("buffer_store_dwordx4 %0, %1, %2, %3 offen" :: "v"(v), "v"(off), "s"(rs), "s"(soff));
 }
-template <int AUX>
 __device__ __forceinline__ void store_b64(u32x2_t v, u32x4_t rs, uint32_t off, int soff)
 {
-    if constexpr (AUX == 2) asm volatile("buffer_store_dwordx2 %0, %1, %2, %3 offen nt" :: "v"(v), "v"(off), "s"(rs), "s"(soff));
-    else asm volatile("buffer_store_dwordx2 %0, %1, %2, %3 offen" :: "v"(v), "v"(off), "s"(rs), "s"(soff));
+    asm volatile("buffer_store_dwordx2 %0, %1, %2, %3 offen" :: "v"(v), "v"(off), "s"(rs), "s"(soff));
 }
 __device__ __forceinline__ void store_b8(uint32_t v, u32x4_t rs, uint32_t off, int soff)
 {
@@ -146,16 +143,16 @@ template <int LW, int N, bool kGroup4> struct RowWin {
     static constexpr int WD = kGroup4 ? 2 : LW / 4;       // dwords per load
 };
 
-template <int NL, int WD, int AUX>
+template <int NL, int WD>
 __device__ __forceinline__ void load_row(uint32_t (&w)[NL][WD], __amdgpu_buffer_rsrc_t srs,
                                          const uint32_t (&off)[NL], int rowoff)
 {
 #pragma unroll
     for (int i = 0; i < NL; ++i) {
         if constexpr (WD == 1) {
-            w[i][0] = __builtin_amdgcn_raw_buffer_load_b32(srs, off[i], rowoff, AUX);
+            w[i][0] = __builtin_amdgcn_raw_buffer_load_b32(srs, off[i], rowoff, 0);
         } else {
-            const u32x2_t t = __builtin_amdgcn_raw_buffer_load_b64(srs, off[i], rowoff, AUX);
+            const u32x2_t t = __builtin_amdgcn_raw_buffer_load_b64(srs, off[i], rowoff, 0);
             w[i][0] = t.x; w[i][1] = t.y;
         }
     }
@@ -171,21 +168,7 @@ __device__ __forceinline__ void load_row(uint32_t (&w)[NL][WD], __amdgpu_buffer_
 // `tab` is a __restrict__ kernel argument so the wave-uniform reads become scalar loads.
 typedef __attribute__((address_space(3))) void lds_void_t;
 
-// Bring the 128-byte lines that hold this wave's windows of a LATER source row into the vector L1,
-// one request per distinct line: only the first lane whose window starts in a line asks for it (as an
-// LDS-DMA dword into a sink, so no VGPR is in flight).  The gathers that follow `lead` rows later
-// then hit; without this every new line is first met by a burst of overlapping window reads and the
-// L1 stalls its whole pipe (stores included) on each hit-under-miss.
-__device__ __forceinline__ void touch_lines(__amdgpu_buffer_rsrc_t srs, uint32_t off0, int rowoff, uint32_t *sink)
-{
-#if defined(__HIP_DEVICE_COMPILE__)
-    const uint32_t line = (off0 + uint32_t(rowoff)) >> 7;
-    const uint32_t prev = uint32_t(__builtin_amdgcn_update_dpp(-1, int(line), 0x138 /* wave_shr:1 */, 0xf, 0xf, false));
-    if (line != prev) __builtin_amdgcn_raw_ptr_buffer_load_lds(srs, (lds_void_t *)sink, 4, off0, rowoff, 0, 0);
-#endif
-}
-
-template <int LW, int R, int N, int D, bool G4, int LAUX = 0, int SAUX = 0>
+template <int LW, int R, int N, int D, bool G4>
 __global__ __launch_bounds__(kBlock) void strip_kernel(const uint8_t *__restrict__ src, uint8_t *__restrict__ dst,
                                                        const uint32_t *__restrict__ tab, const StripArgs a)
 {
@@ -261,12 +244,9 @@ __global__ __launch_bounds__(kBlock) void strip_kernel(const uint8_t *__restrict
     const u32x4_t drs = {uni(uint32_t(dbase)), uni(uint32_t(dbase >> 32) & 0xffffu), uni(a.dst_span), 0x00020000u};
 
     // D source rows are kept in flight so a row's bytes are requested D iterations before use.
-    __shared__ uint32_t touch_sink[kBlock];
-    uint32_t *sink = &touch_sink[__builtin_amdgcn_readfirstlane(int(threadIdx.x) & ~63)];
-    const int lead = a.touch;
     uint32_t w[D][RW::NL][RW::WD];
 #pragma unroll
-    for (int d = 0; d < D; ++d) load_row<RW::NL, RW::WD, LAUX>(w[d], srs, off, (rstart + min(d, nrows - 1)) * c.src_stride);
+    for (int d = 0; d < D; ++d) load_row<RW::NL, RW::WD>(w[d], srs, off, (rstart + min(d, nrows - 1)) * c.src_stride);
     int cnt_next = int(uni(emit[0]));
 
     for (int k0 = 0; k0 < nrows; k0 += R) {
@@ -277,7 +257,6 @@ __global__ __launch_bounds__(kBlock) void strip_kernel(const uint8_t *__restrict
             const int cnt = cnt_next;
             cnt_next = int(uni(emit[min(k + 1, nrows - 1)]));
             uint32_t (&wk)[RW::NL][RW::WD] = w[s % D];
-            if (lead > 0 && k + lead < nrows) touch_lines(srs, off[0], (rstart + k + lead) * c.src_stride, sink);
 #pragma unroll
             for (int i = 0; i < N; ++i) {
                 int acc = 0;
@@ -296,7 +275,7 @@ __global__ __launch_bounds__(kBlock) void strip_kernel(const uint8_t *__restrict
                                          : __builtin_amdgcn_perm(ring[i][s / 2], t, 0x07060100);
             }
             // refill the slot just consumed with row k + D (rows past the segment re-read its last row)
-            load_row<RW::NL, RW::WD, LAUX>(wk, srs, off, (rstart + min(k + D, nrows - 1)) * c.src_stride);
+            load_row<RW::NL, RW::WD>(wk, srs, off, (rstart + min(k + D, nrows - 1)) * c.src_stride);
             for (int e = 0; e < cnt; ++e) {                     // wave-uniform
                 uint32_t vk[R / 2];
 #pragma unroll
@@ -317,9 +296,9 @@ __global__ __launch_bounds__(kBlock) void strip_kernel(const uint8_t *__restrict
                 const int outoff = y * c.dst_stride;
                 if (all_full || cols == N) {
                     if constexpr (N == 16) {
-                        store_b128<SAUX>(u32x4_t{o[0], o[1], o[2], o[3]}, drs, doff, outoff);
+                        store_b128(u32x4_t{o[0], o[1], o[2], o[3]}, drs, doff, outoff);
                     } else {
-                        store_b64<SAUX>(u32x2_t{o[0], o[1]}, drs, doff, outoff);
+                        store_b64(u32x2_t{o[0], o[1]}, drs, doff, outoff);
                     }
                 } else {
 #pragma unroll
@@ -348,24 +327,19 @@ __global__ __launch_bounds__(kBlock) void strip_kernel(const uint8_t *__restrict
 template <int V>
 __device__ __forceinline__ void wait_vm() { asm volatile("s_waitcnt vmcnt(%0)" ::"n"(V) : "memory"); }
 
-// wait until at most B + extra vector-memory operations are outstanding (extra clamped to 0..7;
-// a smaller count is always safe)
+// wait until at most B + min(extra, 3) vector-memory operations are outstanding (a smaller count
+// than the true one is always safe, it only waits for a little more)
 template <int B>
 __device__ __forceinline__ void wait_vm_plus(int extra)
 {
-    switch (extra) {
-    case 0: wait_vm<B>(); break;
-    case 1: wait_vm<B + 1>(); break;
-    case 2: wait_vm<B + 2>(); break;
-    case 3: wait_vm<B + 3>(); break;
-    case 4: wait_vm<B + 4>(); break;
-    case 5: wait_vm<B + 5>(); break;
-    case 6: wait_vm<B + 6>(); break;
-    default: wait_vm<B + 7>(); break;
+    if (extra >= 2) {
+        if (extra >= 3) wait_vm<B + 3>(); else wait_vm<B + 2>();
+    } else {
+        if (extra == 1) wait_vm<B + 1>(); else wait_vm<B>();
     }
 }
 
-template <int R, int N, int D, int SAUX = 0>
+template <int R, int N, int D>
 __global__ __launch_bounds__(kBlock) void strip_lds_kernel(const uint8_t *__restrict__ src, uint8_t *__restrict__ dst,
                                                            const uint32_t *__restrict__ tab, const StripArgs a)
 {
@@ -483,7 +457,7 @@ __global__ __launch_bounds__(kBlock) void strip_lds_kernel(const uint8_t *__rest
             int younger = 0;
 #pragma unroll
             for (int d = 0; d < D; ++d) younger += hist[d];
-            wait_vm_plus<D - 1>(all_full ? min(younger, 7) : 0);
+            wait_vm_plus<D - 1>(all_full ? younger : 0);
             // The window reads are inline asm: an LDS read hipcc can see gets its own vmcnt(0) (it orders
             // LDS reads behind every outstanding LDS-DMA), which would undo the counted wait above.
             // Reads and their lgkmcnt wait sit in ONE asm statement, so no output register exists,
@@ -532,8 +506,8 @@ __global__ __launch_bounds__(kBlock) void strip_lds_kernel(const uint8_t *__rest
                 }
                 const int outoff = y * c.dst_stride;
                 if (all_full || cols == N) {
-                    if constexpr (N == 16) store_b128<SAUX>(u32x4_t{o[0], o[1], o[2], o[3]}, drs, doff, outoff);
-                    else store_b64<SAUX>(u32x2_t{o[0], o[1]}, drs, doff, outoff);
+                    if constexpr (N == 16) store_b128(u32x4_t{o[0], o[1], o[2], o[3]}, drs, doff, outoff);
+                    else store_b64(u32x2_t{o[0], o[1]}, drs, doff, outoff);
                 } else {
 #pragma unroll
                     for (int i = 0; i < N; ++i)
@@ -626,7 +600,7 @@ __global__ __launch_bounds__(kBlock) void fill_kernel(const FillArgs a)
 
 namespace {
 
-constexpr int kSegOptions[] = {16, 24, 32, 48, 64, 96, 128, 256};
+constexpr int kSegOptions[] = {16, 24, 32, 40, 48, 56, 64, 72, 80, 96, 112, 128, 160, 192, 256};
 constexpr int kNumSegOptions = int(sizeof(kSegOptions) / sizeof(kSegOptions[0]));
 
 struct SegTables {
@@ -848,25 +822,14 @@ StripChoice strip_choice(const ClassPlan &c)
 
 strip_fn pick_strip(const StripChoice &ch)
 {
-    const int D = env_int("TTS_STRIP_D", 0);
+    const int D = env_int("TTS_STRIP_D", 0);          // rows in flight (tuning knob; defaults below)
     if (ch.lds) {
-        if (ch.N == 16 && D == 4) return strip_lds_kernel<4, 16, 4>;
-        if (ch.N == 16) return strip_lds_kernel<4, 16, 2>;
-        if (D == 4) return strip_lds_kernel<4, 8, 4>;
-        if (D == 1) return strip_lds_kernel<4, 8, 1>;
-        return strip_lds_kernel<4, 8, 2>;
+        if (ch.N == 16) return D == 4 ? strip_lds_kernel<4, 16, 4> : D == 2 ? strip_lds_kernel<4, 16, 2> : strip_lds_kernel<4, 16, 1>;
+        return D == 4 ? strip_lds_kernel<4, 8, 4> : D == 2 ? strip_lds_kernel<4, 8, 2> : strip_lds_kernel<4, 8, 1>;
     }
     if (ch.LW == 4 && ch.R == 4 && ch.g4) {
-        if (ch.N == 16) return D == 1 ? strip_kernel<4, 4, 16, 1, true> : strip_kernel<4, 4, 16, 2, true>;
-        const int la = env_int("TTS_LD_AUX", 0), sa = env_int("TTS_ST_AUX", 0);   // cache-policy experiments
-        if (la == 2 && sa == 0) return strip_kernel<4, 4, 8, 2, true, 2, 0>;
-        if (la == 16 && sa == 0) return strip_kernel<4, 4, 8, 2, true, 16, 0>;
-        if (la == 1 && sa == 0) return strip_kernel<4, 4, 8, 2, true, 1, 0>;
-        if (la == 17 && sa == 0) return strip_kernel<4, 4, 8, 2, true, 17, 0>;
-        if (la == 2 && sa == 2) return strip_kernel<4, 4, 8, 2, true, 2, 2>;
-        if (la == 0 && sa == 2) return strip_kernel<4, 4, 8, 2, true, 0, 2>;
-        if (la == 16 && sa == 2) return strip_kernel<4, 4, 8, 2, true, 16, 2>;
-        return D == 1 ? strip_kernel<4, 4, 8, 1, true> : D == 4 ? strip_kernel<4, 4, 8, 4, true> : strip_kernel<4, 4, 8, 2, true>;
+        if (ch.N == 16) return strip_kernel<4, 4, 16, 1, true>;
+        return D == 4 ? strip_kernel<4, 4, 8, 4, true> : D == 2 ? strip_kernel<4, 4, 8, 2, true> : strip_kernel<4, 4, 8, 1, true>;
     }
     if (ch.LW == 4 && ch.R == 4) return ch.N == 16 ? strip_kernel<4, 4, 16, 1, false> : strip_kernel<4, 4, 8, 2, false>;
     if (ch.LW == 4 && ch.R == 6) return ch.g4 ? strip_kernel<4, 6, 8, 2, true> : strip_kernel<4, 6, 8, 2, false>;
@@ -892,29 +855,42 @@ void fill_strip_class(const tts_plan *p, int ci, int n, int N, bool g4, int src_
     sc.nblocks = uint32_t((sc.n_items + kBlock - 1) / kBlock) * uint32_t(st.nseg);
 }
 
-// Pick the row-segment length: enough workgroups to keep every CU busy with little tail, but
-// segments long enough that the (taps-1)-row halo at each segment start stays cheap.
-const SegTables &pick_seg(const tts_plan *p, const int *cis, int ncls, int n, int N, int idx_of_class_to_return)
+// Resident workgroups per CU of a strip kernel (VGPR- and LDS-limited); asked once per kernel.
+int blocks_per_cu(strip_fn fn)
 {
-    const ClassPlan &ret = p->cls[cis[idx_of_class_to_return]];
-    if (ret.segs.size() == 1) return ret.segs[0];
-    double best = 1e300; size_t best_i = 0;
-    const double slots = double(p->n_cus) * 4.0;               // resident workgroups (4 per CU at <=128 VGPRs)
-    for (size_t i = 0; i < ret.segs.size(); ++i) {
-        double blocks = 0, work = 0;
+    static std::mutex mu;
+    static std::vector<std::pair<strip_fn, int>> cache;
+    std::lock_guard<std::mutex> lock(mu);
+    for (auto &e : cache) if (e.first == fn) return e.second;
+    int nb = 0;
+    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, fn, kBlock, 0) != hipSuccess || nb < 1) nb = 4;
+    cache.emplace_back(fn, nb);
+    return nb;
+}
+
+// Pick the row-segment length (one for both plane classes).  Long segments amortise the (taps-1)-row
+// halo repeated at every segment start; short ones give enough workgroups to fill the chip and to
+// keep the tail short when the last ones drain.  Measured on MI355X the time is flat from 64 to 96
+// rows once there are >= ~3 workgroups per resident slot, so: the longest segment <= 96 rows that
+// still leaves that many workgroups, else the shortest on offer.
+void choose_segs(const tts_plan *p, const int *cis, int ncls, int n, int N, strip_fn fn, size_t out_idx[2])
+{
+    out_idx[0] = out_idx[1] = 0;
+    const size_t nopt = p->cls[cis[0]].segs.size();
+    if (nopt == 1) return;
+    const double slots = double(p->n_cus) * blocks_per_cu(fn);
+    size_t best = 0;
+    for (size_t i = 0; i < nopt; ++i) {
+        if (p->cls[cis[0]].segs[i].seg_rows > 96) break;
+        double blocks = 0;
         for (int k = 0; k < ncls; ++k) {
             const ClassPlan &c = p->cls[cis[k]];
-            const SegTables &st = c.segs[i];
-            const double sb = double((int64_t(n) * (cis[k] ? 2 : 1) * ((c.ow + N - 1) / N) + kBlock - 1) / kBlock);
-            blocks += sb * st.nseg;
-            work += sb * (st.total_src_rows + 1.5 * c.oh);      // row cost units: H pass ~1, V pass ~1.5 per out row... relative
+            const double sb = double((int64_t(n) * (cis[k] ? 2 : 1) * c.ht[N == 16].strips + kBlock - 1) / kBlock);
+            blocks += sb * c.segs[i].nseg;
         }
-        const double rounds = blocks / slots;
-        const double eff = rounds / std::max(1.0, std::ceil(rounds - 0.15));
-        const double cost = work / std::min(1.0, eff);
-        if (cost < best) { best = cost; best_i = i; }
+        if (i == 0 || blocks >= 3.0 * slots) best = i;
     }
-    return ret.segs[best_i];
+    out_idx[0] = out_idx[1] = best;
 }
 
 // One launch set: frames [0, n) addressed by `addr` relative to (src, dst).
@@ -947,17 +923,25 @@ int launch_all(const tts_plan *p, const uint8_t *src, uint8_t *dst, int n, const
     for (int k = 0; k < ns; ++k) {
         StripArgs a{};
         a.src_span = src_span; a.dst_span = dst_span; a.addr = addr;
-        a.touch = env_int("TTS_TOUCH", 0);
+        // timing experiments (outputs are wrong): a zero-record descriptor makes the range check drop that
+        // buffer's traffic while the instruction stream stays
+        if (env_int("TTS_EXP_NOSRC", 0)) a.src_span = 0;
+        if (env_int("TTS_EXP_SRCPITCH0", 0)) a.addr.src_pitch = 0;    // every frame reads frame 0: source stays in L2
+        if (env_int("TTS_EXP_DSTPITCH0", 0)) a.addr.dst_pitch = 0;    // every frame writes frame 0: output stays in L2
+        if (env_int("TTS_EXP_NODST", 0)) a.dst_span = 0;
         const int ci = strip_cls[k];
         const StripChoice ch = strip_choice(p->cls[ci]);
         strip_fn fn = pick_strip(ch);
         if (!fn) return TTS_ERR_UNSUPPORTED;
+        size_t si[2];
         if (merged) {
+            choose_segs(p, strip_cls, 2, n, ch.N, fn, si);
             for (int j = 0; j < 2; ++j)
-                fill_strip_class(p, j, n, ch.N, ch.g4, src_stride[j], dst_stride[j], pick_seg(p, strip_cls, 2, n, ch.N, j), a.c[j]);
+                fill_strip_class(p, j, n, ch.N, ch.g4, src_stride[j], dst_stride[j], p->cls[j].segs[si[j]], a.c[j]);
         } else {
             // a single class rides in slot 0; slot 1 is empty
-            fill_strip_class(p, ci, n, ch.N, ch.g4, src_stride[ci], dst_stride[ci], pick_seg(p, &ci, 1, n, ch.N, 0), a.c[0]);
+            choose_segs(p, &ci, 1, n, ch.N, fn, si);
+            fill_strip_class(p, ci, n, ch.N, ch.g4, src_stride[ci], dst_stride[ci], p->cls[ci].segs[si[0]], a.c[0]);
             a.c[1] = a.c[0]; a.c[1].nblocks = 0;
         }
         const uint32_t blocks = a.c[0].nblocks + (merged ? a.c[1].nblocks : 0);
