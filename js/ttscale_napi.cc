@@ -1,0 +1,114 @@
+// ttscale.node -- N-API binding of libttscale.so for the reference's Node scripts.
+//
+// scripts/processVideos.js:3,71-108 drives the scale step through fluent-ffmpeg and a spawned
+// `ffmpeg`; this addon puts the same step behind a function call on raw yuv420p buffers.
+//   parseVf(vf, iw, ih)            -> { in_w, in_h, sc_w, ..., out_w, out_h }
+//   frameBytes(w, h)               -> bytes of a packed I420 frame
+//   runHost(vf, iw, ih, srcBuffer) -> Buffer with the processed frames (packed I420)
+// Errors are thrown as Error whose message carries INVALID_INPUT / INVALID_FORMAT /
+// INITIALIZATION_FAILED / PROCESSING_FAILED (web/src/tests/video/compression.test.js:62-90).
+#include <node_api.h>
+
+#include <cstdint>
+#include <cstring>
+#include <string>
+
+#include "../include/ttscale.h"
+
+namespace {
+
+napi_value throw_status(napi_env env, const char *what, int rc)
+{
+    std::string msg = std::string(tts_strerror(rc)) + ": " + what;
+    if (*tts_last_error()) msg += std::string(" (") + tts_last_error() + ")";
+    napi_throw_error(env, tts_strerror(rc), msg.c_str());
+    return nullptr;
+}
+
+bool get_string(napi_env env, napi_value v, std::string &out)
+{
+    size_t len = 0;
+    if (napi_get_value_string_utf8(env, v, nullptr, 0, &len) != napi_ok) return false;
+    out.resize(len);
+    return napi_get_value_string_utf8(env, v, &out[0], len + 1, &len) == napi_ok;
+}
+
+bool parse_common(napi_env env, napi_callback_info info, size_t want, napi_value *argv, std::string &vf, int32_t &iw, int32_t &ih)
+{
+    size_t argc = want;
+    if (napi_get_cb_info(env, info, &argc, argv, nullptr, nullptr) != napi_ok || argc < want) return false;
+    return get_string(env, argv[0], vf) && napi_get_value_int32(env, argv[1], &iw) == napi_ok &&
+           napi_get_value_int32(env, argv[2], &ih) == napi_ok;
+}
+
+napi_value ParseVf(napi_env env, napi_callback_info info)
+{
+    napi_value argv[3];
+    std::string vf; int32_t iw, ih;
+    if (!parse_common(env, info, 3, argv, vf, iw, ih)) return throw_status(env, "parseVf(vf, iw, ih)", TTS_ERR_INVALID_INPUT);
+    tts_geom g;
+    const int rc = tts_parse_vf(vf.c_str(), iw, ih, &g);
+    if (rc) return throw_status(env, "filter chain", rc);
+    napi_value obj;
+    napi_create_object(env, &obj);
+    const char *names[] = {"in_w", "in_h", "pre_x", "pre_y", "pre_w", "pre_h", "do_scale", "alg", "sc_w", "sc_h",
+                           "crop_x", "crop_y", "crop_w", "crop_h", "do_pad", "pad_x", "pad_y", "out_w", "out_h",
+                           "fill_y", "fill_u", "fill_v"};
+    const int32_t *vals = &g.in_w;
+    for (size_t i = 0; i < sizeof(names) / sizeof(names[0]); ++i) {
+        napi_value v;
+        napi_create_int32(env, vals[i], &v);
+        napi_set_named_property(env, obj, names[i], v);
+    }
+    return obj;
+}
+
+napi_value FrameBytes(napi_env env, napi_callback_info info)
+{
+    size_t argc = 2; napi_value argv[2]; int32_t w = 0, h = 0;
+    napi_get_cb_info(env, info, &argc, argv, nullptr, nullptr);
+    if (argc < 2 || napi_get_value_int32(env, argv[0], &w) != napi_ok || napi_get_value_int32(env, argv[1], &h) != napi_ok)
+        return throw_status(env, "frameBytes(w, h)", TTS_ERR_INVALID_INPUT);
+    napi_value out;
+    napi_create_double(env, double(tts_frame_bytes(w, h)), &out);
+    return out;
+}
+
+napi_value RunHost(napi_env env, napi_callback_info info)
+{
+    napi_value argv[4];
+    std::string vf; int32_t iw, ih;
+    if (!parse_common(env, info, 4, argv, vf, iw, ih)) return throw_status(env, "runHost(vf, iw, ih, buffer)", TTS_ERR_INVALID_INPUT);
+    void *src = nullptr; size_t len = 0;
+    if (napi_get_buffer_info(env, argv[3], &src, &len) != napi_ok) return throw_status(env, "frames must be a Buffer", TTS_ERR_INVALID_INPUT);
+    tts_geom g;
+    int rc = tts_parse_vf(vf.c_str(), iw, ih, &g);
+    if (rc) return throw_status(env, "filter chain", rc);
+    const size_t sb = tts_frame_bytes(g.in_w, g.in_h), db = tts_frame_bytes(g.out_w, g.out_h);
+    if (len == 0 || len % sb) return throw_status(env, "buffer is not a whole number of frames", TTS_ERR_INVALID_INPUT);
+    const int n = int(len / sb);
+    tts_plan *plan = nullptr;
+    rc = tts_plan_create(&g, &plan);
+    if (rc) return throw_status(env, "plan", rc);
+    napi_value out; void *dst = nullptr;
+    if (napi_create_buffer(env, db * n, &dst, &out) != napi_ok) { tts_plan_destroy(plan); return throw_status(env, "allocation", TTS_ERR_PROCESSING_FAILED); }
+    rc = tts_run_host(plan, src, dst, n);
+    tts_plan_destroy(plan);
+    if (rc) return throw_status(env, "run", rc);
+    return out;
+}
+
+napi_value Init(napi_env env, napi_value exports)
+{
+    napi_property_descriptor props[] = {
+        {"parseVf", nullptr, ParseVf, nullptr, nullptr, nullptr, napi_default, nullptr},
+        {"frameBytes", nullptr, FrameBytes, nullptr, nullptr, nullptr, napi_default, nullptr},
+        {"runHost", nullptr, RunHost, nullptr, nullptr, nullptr, napi_default, nullptr},
+    };
+    napi_define_properties(env, exports, sizeof(props) / sizeof(props[0]), props);
+    return exports;
+}
+
+}  // namespace
+
+NAPI_MODULE(ttscale, Init)

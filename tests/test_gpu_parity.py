@@ -178,3 +178,54 @@ def test_full_size_thumbnails_match_oracle_sample(tts, oracle):
     src = synth.frames("random", 1080, 1920, 2)
     got = plan.run_batch(torch.from_numpy(src).cuda()).cpu().numpy()
     assert np.array_equal(got, oracle.run_chain(plan.geom, src))
+
+
+# ---- committed golden vectors and the multi-clip path ---------------------------------------------
+
+import glob as _glob
+import os as _os
+
+_GOLDEN = _os.path.join(_os.path.dirname(_os.path.abspath(__file__)), "golden")
+
+
+@pytest.mark.parametrize("path", sorted(p for p in _glob.glob(_os.path.join(_GOLDEN, "*.npz")) if "filter_tables" not in p))
+def test_hip_matches_golden_vectors(tts, path):
+    import torch
+    z = np.load(path)
+    g = dict(zip([str(k) for k in z["geom_keys"]], [int(v) for v in z["geom"]]))
+    geom = tts.Geom(**g)
+    plan = tts.Plan(geom)
+    for key in z.files:
+        if key.startswith("out_"):
+            src = synth.frames(key[4:], g["in_w"], g["in_h"], 1)
+            got = plan.run_batch(torch.from_numpy(src).cuda()).cpu().numpy()[0]
+            assert np.array_equal(got, z[key]), "%s %s" % (path, key)
+
+
+def test_plan_tables_match_oracle(tts, oracle):
+    plan = tts.Plan.from_vf(PORTRAIT, 1920, 1080)
+    for cls, (sw, dw, sh, dh) in enumerate([(1920, 3413, 1080, 1920), (960, 1707, 540, 960)]):
+        for axis, (s, d, one) in enumerate([(sw, dw, 1 << 14), (sh, dh, 1 << 12)]):
+            c, p = plan.filter(cls, axis)
+            oc, op = oracle.filter_table(s, d, one, 0)
+            assert np.array_equal(c, oc) and np.array_equal(p, op)
+
+
+def test_clip_shard_runner(tts, oracle):
+    """One rank's share of a small mixed corpus through tiktoken_amd.shard.run_shard."""
+    import torch
+    from tiktoken_amd.shard import Clip, assign, run_shard
+    clips = [Clip("a", 128, 72, 5), Clip("b", 192, 108, 3), Clip("c", 128, 72, 9)]
+    vf = "scale=108:192:force_original_aspect_ratio=increase,crop=108:192"
+    shards = assign(clips, 2, (108, 192))
+
+    def frames(c, first, n):
+        return torch.from_numpy(synth.frames("random", c.width, c.height, c.frames)[first:first + n]).cuda()
+
+    sums = {}
+    for r in range(2):
+        sums.update(run_shard(clips, shards[r], vf, frames, batch=4))
+    for c in clips:
+        g = tts.parse_vf(vf, c.width, c.height)
+        want = int(oracle.run_chain(g, synth.frames("random", c.width, c.height, c.frames)).astype(np.int64).sum())
+        assert sums[c.name] == want

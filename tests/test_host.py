@@ -1,0 +1,102 @@
+"""Host logic of libttscale that needs no GPU: the library loads and exports every symbol the header
+declares, the filter-string parser resolves the reference's chains like libavfilter would, and the
+product's own integer tables equal the oracle's."""
+import ctypes
+import os
+import re
+
+import numpy as np
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def test_library_exports_every_declared_symbol(tts):
+    header = open(os.path.join(ROOT, "include", "ttscale.h")).read()
+    declared = set(re.findall(r"\b(tts_[a-z_]+)\s*\(", header))
+    assert declared, "no declarations found in include/ttscale.h"
+    handle = ctypes.CDLL(tts.LIB_PATH)
+    for name in sorted(declared):
+        assert hasattr(handle, name), "libttscale.so does not export %s" % name
+    assert declared == set(tts.SYMBOLS), "python binding and header disagree: %s" % (declared ^ set(tts.SYMBOLS))
+    assert tts._lib.lib().tts_version().decode().startswith("ttscale")
+
+
+def test_missing_library_fails_loudly(tts, monkeypatch):
+    monkeypatch.setattr(tts._lib, "_lib", None)
+    monkeypatch.setattr(tts._lib, "LIB_PATH", "/nonexistent/libttscale.so")
+    with pytest.raises(RuntimeError, match="no CPU fallback"):
+        tts._lib.lib()
+
+
+# (vf, iw, ih) -> expected fields.  First three rows are the reference's own strings.
+PARSE_CASES = [
+    ("scale=w=720:h=1280", 480, 854,                                       # scripts/processVideos.js:96 via fluent-ffmpeg
+     dict(do_scale=1, alg=0, sc_w=720, sc_h=1280, out_w=720, out_h=1280, do_pad=0)),
+    ("scale=320x180:force_original_aspect_ratio=decrease,pad=320x180:-1:-1:color=black,format=yuv420p", 720, 1280,
+     dict(sc_w=101, sc_h=180, do_pad=1, pad_x=108, pad_y=0, out_w=320, out_h=180, fill_y=16, fill_u=128, fill_v=128)),
+    ("scale=320x180:force_original_aspect_ratio=decrease,pad=320x180:-1:-1:color=black,format=yuv420p", 1920, 1080,
+     dict(sc_w=320, sc_h=180, do_pad=1, pad_x=0, pad_y=0, out_w=320, out_h=180)),
+    ("scale='min(720,iw)':'min(1280,ih)':force_original_aspect_ratio=decrease", 720, 2560,   # portrait.test.js:133-147
+     dict(sc_w=360, sc_h=1280, out_w=360, out_h=1280)),
+    ("scale=min(720\\,iw):min(1280\\,ih):force_original_aspect_ratio=decrease", 1080, 1080,  # portrait.test.js:85-97
+     dict(sc_w=720, sc_h=720)),
+    ("scale=1080:1920:force_original_aspect_ratio=increase,crop=1080:1920", 1920, 1080,      # BASELINE.json configs[1]
+     dict(sc_w=3413, sc_h=1920, crop_x=1166, crop_y=0, crop_w=1080, crop_h=1920, out_w=1080, out_h=1920)),
+    ("scale=1080:1920:force_original_aspect_ratio=increase,crop=1080:1920", 3840, 2160,
+     dict(sc_w=3413, sc_h=1920, crop_x=1166)),
+    ("scale=320:568:flags=area", 1080, 1920, dict(alg=1, sc_w=320, sc_h=568)),
+    ("scale=-2:360:flags=bilinear", 1280, 720, dict(alg=2, sc_w=640, sc_h=360)),
+    ("scale=iw/2:ih/2", 1280, 720, dict(sc_w=640, sc_h=360)),
+    ("crop=64:32:10:6,scale=128:96", 100, 60, dict(pre_x=10, pre_y=6, pre_w=64, pre_h=32, sc_w=128, sc_h=96)),
+    ("crop=in_w-21:in_h", 101, 60, dict(pre_w=80, pre_h=60, pre_x=10, out_w=80)),       # 10.5 -> lrint 10 -> even
+    ("pad=640:480:-1:-1:color=white", 320, 240, dict(do_pad=1, pad_x=160, pad_y=120, fill_y=235, fill_u=128, fill_v=128)),
+    ("format=yuv420p", 64, 48, dict(do_scale=0, do_pad=0, out_w=64, out_h=48)),
+    ("scale=64:48", 64, 48, dict(do_scale=0)),
+]
+
+
+@pytest.mark.parametrize("vf,iw,ih,want", PARSE_CASES)
+def test_parse_vf(tts, vf, iw, ih, want):
+    g = tts.parse_vf(vf, iw, ih).as_dict()
+    for k, v in want.items():
+        assert g[k] == v, "%s: %s = %d, want %d" % (vf, k, g[k], v)
+
+
+@pytest.mark.parametrize("vf,name", [
+    ("hflip", "INVALID_FORMAT"), ("scale=abc:def", "INVALID_FORMAT"), ("scale=10:10:flags=lanczos", "UNSUPPORTED"),
+    ("format=rgb24", "UNSUPPORTED"), ("crop=4000:10", "INVALID_INPUT"), ("pad=10:10", "INVALID_INPUT"),
+    ("scale=64:64,scale=32:32", "UNSUPPORTED"), ("scale=100:100:unknown=1", "INVALID_FORMAT"),
+])
+def test_parse_errors_carry_the_web_spec_names(tts, vf, name):
+    # web/src/tests/video/compression.test.js:62-90 expects these words in thrown messages
+    with pytest.raises(tts.TtsError, match=name):
+        tts.parse_vf(vf, 640, 360)
+    with pytest.raises(tts.TtsError, match="INVALID_INPUT"):
+        tts.parse_vf("scale=10:10", 0, 10)
+
+
+def test_parser_agrees_with_oracle_geometry(tts, oracle):
+    for iw, ih, w, h, foar in [(1920, 1080, 1080, 1920, 2), (1280, 720, 1080, 1920, 2), (720, 1280, 320, 180, 1),
+                               (1080, 1080, 320, 180, 1), (853, 481, 333, 777, 1), (853, 481, 333, 777, 2)]:
+        word = {1: "decrease", 2: "increase"}[foar]
+        g = tts.parse_vf("scale=%d:%d:force_original_aspect_ratio=%s" % (w, h, word), iw, ih)
+        assert (g.sc_w, g.sc_h) == oracle.scale_dims(iw, ih, w, h, foar)
+    for inn, out in [(3413, 1080), (1920, 1080), (101, 100), (3413, 1082)]:
+        g = tts.parse_vf("crop=%d:2" % out, inn, 4)          # a crop with no scale before it is a source crop
+        assert g.pre_x == oracle.crop_offset(inn, out)
+
+
+@pytest.mark.parametrize("src,dst", [(1920, 3413), (1080, 1920), (960, 1707), (540, 960), (3840, 3413), (2160, 1920),
+                                     (1280, 3413), (720, 1920), (720, 101), (1280, 180), (1080, 320), (1920, 568),
+                                     (100, 100), (101, 100), (7, 3), (3, 7), (2, 5), (1, 4), (4, 1), (5, 64)])
+def test_product_tables_equal_oracle_tables(tts, oracle, src, dst):
+    for alg in (0, 1, 2):
+        for one in (1 << 14, 1 << 12):
+            a, b = oracle.filter_table(src, dst, one, alg), tts.build_filter(src, dst, one, alg)
+            assert a[0].shape == b[0].shape and np.array_equal(a[0], b[0]) and np.array_equal(a[1], b[1])
+
+
+def test_frame_bytes(tts):
+    assert tts.frame_bytes(1920, 1080) == 3110400
+    assert tts.frame_bytes(101, 57) == 101 * 57 + 2 * 51 * 29

