@@ -44,6 +44,8 @@ namespace {
 // ------------------------------------------------------------------------------------
 
 constexpr int kBlock = 256;
+constexpr size_t kMaxSpan = 0xFF000000u;   // bytes one launch may address from its base pointers
+[[maybe_unused]] constexpr uint32_t kDiscard = 0xFFFFFF00u; // a lane offset the buffer range check always rejects (> kMaxSpan)
 constexpr int kMaxTableFrames = 32;   // frames addressed through the in-kernarg offset table
 
 typedef short short2_t __attribute__((ext_vector_type(2)));
@@ -320,10 +322,15 @@ __global__ __launch_bounds__(kBlock) void strip_kernel(const uint8_t *__restrict
 // 8-byte windows out of the wave's private LDS slot with ds_read_b64.  A wave's 64 strips may
 // straddle the end of a plane row (items are flattened over frames), so the run is one or two
 // pieces; more than two (rows shorter than a wave's run) fall back to strip_kernel.
-// Nothing in flight lives in VGPRs and hipcc does not order LDS reads behind LDS-DMA, so the waits
-// are ours: before row k is read we wait, exactly, until only the operations issued after row k's
-// DMA are outstanding -- the DMAs of the D-1 later rows plus the stores issued since (counted at
-// run time; gfx950 retires vector-memory operations in issue order).
+// Nothing in flight lives in VGPRs, and an LDS read hipcc can see is ordered behind EVERY LDS-DMA
+// still in flight (vmcnt(0)), so the window reads are inline asm and the waits are ours: before row
+// k is read we wait, exactly, until only the operations issued after row k's DMA are outstanding
+// -- the DMAs of the D-1 later rows plus the stores issued since (counted at run time; gfx950
+// retires vector-memory operations in issue order).
+// Output alignment is what this kernel's speed depends on most (tools/micro/pattern*.hip): a wave
+// stores 512 contiguous bytes per row; when rows are 1080 bytes the chunk ends fall inside 64-byte
+// sectors shared with the neighbouring wave on 7 rows of 8 and the job runs at ~42 % of the HBM
+// roofline, with 1024-byte rows (every chunk line-aligned) the same kernel reaches ~50 %.
 template <int V>
 __device__ __forceinline__ void wait_vm() { asm volatile("s_waitcnt vmcnt(%0)" ::"n"(V) : "memory"); }
 
@@ -340,7 +347,7 @@ __device__ __forceinline__ void wait_vm_plus(int extra)
 }
 
 template <int R, int N, int D>
-__global__ __launch_bounds__(kBlock) void strip_lds_kernel(const uint8_t *__restrict__ src, uint8_t *__restrict__ dst,
+__global__ __launch_bounds__(kBlock, N == 8 ? 8 : 4) void strip_lds_kernel(const uint8_t *__restrict__ src, uint8_t *__restrict__ dst,
                                                            const uint32_t *__restrict__ tab, const StripArgs a)
 {
     static_assert(R % 2 == 0 && (N == 8 || N == 16) && R % D == 0, "see strip_kernel");
@@ -358,12 +365,11 @@ __global__ __launch_bounds__(kBlock) void strip_lds_kernel(const uint8_t *__rest
     const int sb  = int(lb / uint32_t(c.nseg));
     int       g   = sb * kBlock + int(threadIdx.x);
     const bool live = g < c.n_items;
-    if (!live) g = c.n_items - 1;
-    const int wave = __builtin_amdgcn_readfirstlane(int(threadIdx.x) >> 6);
-    const int lane = int(threadIdx.x) & 63;
-
+    if (!live) g = c.n_items - 1;                  // dead lanes (a suffix of the last workgroup) shadow the last live one
     const int strip = g % c.strips;
     const int fp    = g / c.strips;
+    const int wave = __builtin_amdgcn_readfirstlane(int(threadIdx.x) >> 6);
+    const int lane = int(threadIdx.x) & 63;
     const int plane = c.plane0 + fp % c.planes;
     const int frame = fp / c.planes;
     uint32_t soff, doff;
@@ -374,7 +380,10 @@ __global__ __launch_bounds__(kBlock) void strip_lds_kernel(const uint8_t *__rest
         soff = uint32_t(frame) * a.addr.src_pitch + a.addr.src_plane[plane];
         doff = uint32_t(frame) * a.addr.dst_pitch + a.addr.dst_plane[plane];
     }
-    doff += uint32_t(min(strip * N, max(c.ow - N, 0)));      // the last strip is slid left, not cut short
+    doff += uint32_t(min(strip * N, c.ow - N));              // the last strip is slid left, not cut short
+    // Dead lanes run the same instruction stream (so the wave's store count stays uniform) with an
+    // offset past the end of the buffer: the descriptor's range check discards their stores.
+    if (!live) doff = kDiscard;
 
     uint32_t off[NL];
     uint32_t hc[N][2];
@@ -429,9 +438,11 @@ __global__ __launch_bounds__(kBlock) void strip_lds_kernel(const uint8_t *__rest
     const int nrows  = int(uni(tab[c.seginfo + 2 * seg + 1]));
     const uint32_t *emit = tab + c.emit + seg * c.maxrows;
     const uint32_t *vco  = tab + c.vcoef;
-    int y = seg * c.seg_rows;
-    const int cols = live ? min(N, c.ow) : 0;                  // < N only for planes narrower than a strip
-    const bool all_full = __builtin_amdgcn_ballot_w64(cols != N) == 0;   // wave-uniform
+    int y = seg * c.seg_rows;                                  // (the host picks this kernel only if ow >= N: no ragged strips)
+    // class fields used inside the loop, read once (the asm statements below clobber "memory", which
+    // would otherwise make the compiler reload them from the kernel arguments every row)
+    const int src_stride = int(uni(uint32_t(c.src_stride))), dst_stride = int(uni(uint32_t(c.dst_stride)));
+    const int last_y = c.oh - 1;
 
     const __amdgpu_buffer_rsrc_t srs = __builtin_amdgcn_make_buffer_rsrc(const_cast<uint8_t *>(src), 0, a.src_span, 0x00020000);
     const uint64_t dbase = reinterpret_cast<uint64_t>(dst);
@@ -440,8 +451,11 @@ __global__ __launch_bounds__(kBlock) void strip_lds_kernel(const uint8_t *__rest
 #pragma unroll
     for (int d = 0; d < D; ++d)
         __builtin_amdgcn_raw_ptr_buffer_load_lds(srs, (lds_void_t *)&lds[wave][d][0], 16, chunk_src,
-                                                 (rstart + min(d, nrows - 1)) * c.src_stride, 0, 0);
+                                                 (rstart + min(d, nrows - 1)) * src_stride, 0, 0);
     int cnt_next = int(uni(emit[0]));
+    uint32_t vk_next[R / 2];                       // vertical taps of the next output row, requested a row ahead
+#pragma unroll
+    for (int q = 0; q < R / 2; ++q) vk_next[q] = uni(vco[y * (R / 2) + q]);
     int hist[D];                                   // stores issued in each of the last D iterations
 #pragma unroll
     for (int d = 0; d < D; ++d) hist[d] = 0;
@@ -457,7 +471,7 @@ __global__ __launch_bounds__(kBlock) void strip_lds_kernel(const uint8_t *__rest
             int younger = 0;
 #pragma unroll
             for (int d = 0; d < D; ++d) younger += hist[d];
-            wait_vm_plus<D - 1>(all_full ? younger : 0);
+            wait_vm_plus<D - 1>(younger);
             // The window reads are inline asm: an LDS read hipcc can see gets its own vmcnt(0) (it orders
             // LDS reads behind every outstanding LDS-DMA), which would undo the counted wait above.
             // Reads and their lgkmcnt wait sit in ONE asm statement, so no output register exists,
@@ -486,11 +500,14 @@ __global__ __launch_bounds__(kBlock) void strip_lds_kernel(const uint8_t *__rest
             }
             // the slot is free again (its bytes sit in registers): request row k + D into it
             __builtin_amdgcn_raw_ptr_buffer_load_lds(srs, (lds_void_t *)&lds[wave][s % D][0], 16, chunk_src,
-                                                     (rstart + min(k + D, nrows - 1)) * c.src_stride, 0, 0);
+                                                     (rstart + min(k + D, nrows - 1)) * src_stride, 0, 0);
             for (int e = 0; e < cnt; ++e) {                     // wave-uniform
                 uint32_t vk[R / 2];
 #pragma unroll
-                for (int q = 0; q < R / 2; ++q) vk[q] = uni(vco[y * (R / 2) + q]);
+                for (int q = 0; q < R / 2; ++q) vk[q] = vk_next[q];
+                const int yn = min(y + 1, last_y);
+#pragma unroll
+                for (int q = 0; q < R / 2; ++q) vk_next[q] = uni(vco[yn * (R / 2) + q]);
                 uint32_t o[N / 4];
 #pragma unroll
                 for (int q = 0; q < N / 4; ++q) {
@@ -504,15 +521,9 @@ __global__ __launch_bounds__(kBlock) void strip_lds_kernel(const uint8_t *__rest
                     }
                     o[q] = pack4(v[0], v[1], v[2], v[3]);
                 }
-                const int outoff = y * c.dst_stride;
-                if (all_full || cols == N) {
-                    if constexpr (N == 16) store_b128(u32x4_t{o[0], o[1], o[2], o[3]}, drs, doff, outoff);
-                    else store_b64(u32x2_t{o[0], o[1]}, drs, doff, outoff);
-                } else {
-#pragma unroll
-                    for (int i = 0; i < N; ++i)
-                        if (i < cols) store_b8(o[i / 4] >> (8 * (i % 4)), drs, doff + i, outoff);
-                }
+                const int outoff = y * dst_stride;
+                if constexpr (N == 16) store_b128(u32x4_t{o[0], o[1], o[2], o[3]}, drs, doff, outoff);
+                else store_b64(u32x2_t{o[0], o[1]}, drs, doff, outoff);
                 ++y;
             }
             hist[s % D] = cnt;
@@ -1085,9 +1096,9 @@ int tts_run_batch(const tts_plan *p, const void *src, size_t src_pitch, void *ds
         splane += uint32_t(sstride[ci]) * ceil_shift(g.in_h, ci);
         dplane += uint32_t(dstride[ci]) * ceil_shift(g.out_h, ci);
     }
-    // 32-bit lane offsets: keep each launch's span under 4 GiB
-    const size_t span = size_t(0xF0000000u);
-    const int chunk = int(std::max<size_t>(1, std::min(span / src_pitch, span / dst_pitch)));
+    // 32-bit lane offsets: keep each launch's span under kMaxSpan (offsets above it mean "discard")
+    if (sbytes > kMaxSpan || dbytes > kMaxSpan) return TTS_ERR_UNSUPPORTED;
+    const int chunk = int(std::min<size_t>(1 + std::min((kMaxSpan - sbytes) / src_pitch, (kMaxSpan - dbytes) / dst_pitch), size_t(1) << 30));
     for (int f0 = 0; f0 < n_frames; f0 += chunk) {
         const int n = std::min(chunk, n_frames - f0);
         const uint8_t *s = static_cast<const uint8_t *>(src) + size_t(f0) * src_pitch;
@@ -1124,12 +1135,18 @@ int tts_run(const tts_plan *p, const tts_frame *src, const tts_frame *dst, int n
             const tts_frame &s = src[f0 + n], &d = dst[f0 + n];
             if (n && (s.stride[0] != src[f0].stride[0] || s.stride[1] != src[f0].stride[1] ||
                       d.stride[0] != dst[f0].stride[0] || d.stride[1] != dst[f0].stride[1])) break;
-            uintptr_t a = smin, b = smax, c2 = dmin, e = dmax;
+            uintptr_t a = smin, b = smax, c2 = dmin, e = dmax;     // [min start, max end) over the group's planes
             for (int k = 0; k < 3; ++k) {
-                a = std::min(a, uintptr_t(s.plane[k])); b = std::max(b, uintptr_t(s.plane[k]));
-                c2 = std::min(c2, uintptr_t(d.plane[k])); e = std::max(e, uintptr_t(d.plane[k]));
+                const int ci = k ? 1 : 0;
+                const size_t sext = size_t(s.stride[k]) * (ceil_shift(g.in_h, ci) - 1) + ceil_shift(g.in_w, ci);
+                const size_t dext = size_t(d.stride[k]) * (ceil_shift(g.out_h, ci) - 1) + ceil_shift(g.out_w, ci);
+                a = std::min(a, uintptr_t(s.plane[k])); b = std::max(b, uintptr_t(s.plane[k]) + sext);
+                c2 = std::min(c2, uintptr_t(d.plane[k])); e = std::max(e, uintptr_t(d.plane[k]) + dext);
             }
-            if (n && (b - a >= 0xE0000000u || e - c2 >= 0xE0000000u)) break;
+            if (b - a > kMaxSpan || e - c2 > kMaxSpan) {
+                if (n) break;
+                return TTS_ERR_UNSUPPORTED;             // one frame whose planes lie further apart than 32-bit offsets reach
+            }
             smin = a; smax = b; dmin = c2; dmax = e;
             ++n;
         }
@@ -1149,8 +1166,7 @@ int tts_run(const tts_plan *p, const tts_frame *src, const tts_frame *dst, int n
                 dspan = std::max(dspan, dof + size_t(dstride[ci]) * (ceil_shift(g.out_h, ci) - 1) + ceil_shift(g.out_w, ci));
             }
         const int rc = launch_all(p, reinterpret_cast<const uint8_t *>(smin), reinterpret_cast<uint8_t *>(dmin), n,
-                                  sstride, dstride, uint32_t(std::min<size_t>(sspan, 0xFFFFFFFFu)),
-                                  uint32_t(std::min<size_t>(dspan, 0xFFFFFFFFu)), addr, st);
+                                  sstride, dstride, uint32_t(sspan), uint32_t(dspan), addr, st);
         if (rc) return rc;
         f0 += n;
     }

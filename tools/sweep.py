@@ -15,6 +15,7 @@ CASES = {
     "portrait": ("scale=1080:1920:force_original_aspect_ratio=increase,crop=1080:1920", 1920, 1080, 4095360),
     "4k": ("scale=1080:1920:force_original_aspect_ratio=increase,crop=1080:1920", 3840, 2160, 7050240),
     "720p": ("scale=1080:1920:force_original_aspect_ratio=increase,crop=1080:1920", 1280, 720, 3548880),
+    "aligned": ("scale=1080:1920:force_original_aspect_ratio=increase,crop=1024:1920", 1920, 1080, 3882240),
     "thumb": ("scale=320:568:flags=area", 1080, 1920, 3383040),
 }
 
