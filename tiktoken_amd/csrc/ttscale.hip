@@ -346,15 +346,59 @@ __device__ __forceinline__ void wait_vm_plus(int extra)
     }
 }
 
-template <int R, int N, int D>
-__global__ __launch_bounds__(kBlock, N == 8 ? 8 : 4) void strip_lds_kernel(const uint8_t *__restrict__ src, uint8_t *__restrict__ dst,
-                                                           const uint32_t *__restrict__ tab, const StripArgs a)
+// Window reads of one source row out of the wave's LDS slot.  A window starts at any byte, and a
+// misaligned ds_read costs ~64 LDS cycles (one lane at a time; SQ_LDS_UNALIGNED_STALL showed the
+// LDS pipe 70-95 % busy with nothing else), so every window is fetched as the three ALIGNED dwords
+// that contain it (ds_read2_b32 + ds_read_b32 at addr & ~3) and the byte phase is folded into the
+// v_perm selectors / a v_alignbyte afterwards.  Reads and their lgkmcnt wait sit in the SAME asm
+// statement: no output register exists, as far as the compiler can tell, before its data landed.
+struct Win3 { u32x2_t lo; uint32_t hi; };
+[[maybe_unused]] __device__ __forceinline__ void lds_read_win3(Win3 (&w)[2], const uint32_t (&p)[2])
 {
-    static_assert(R % 2 == 0 && (N == 8 || N == 16) && R % D == 0, "see strip_kernel");
+    asm volatile("ds_read2_b32 %0, %4 offset1:1\n\tds_read_b32 %1, %4 offset:8\n\t"
+                 "ds_read2_b32 %2, %5 offset1:1\n\tds_read_b32 %3, %5 offset:8\n\ts_waitcnt lgkmcnt(0)"
+                 : "=&v"(w[0].lo), "=&v"(w[0].hi), "=&v"(w[1].lo), "=&v"(w[1].hi) : "v"(p[0]), "v"(p[1]) : "memory");
+}
+[[maybe_unused]] __device__ __forceinline__ void lds_read_win3(Win3 (&w)[8], const uint32_t (&p)[8])
+{
+    asm volatile("ds_read2_b32 %0, %16 offset1:1\n\tds_read_b32 %1, %16 offset:8\n\t"
+                 "ds_read2_b32 %2, %17 offset1:1\n\tds_read_b32 %3, %17 offset:8\n\t"
+                 "ds_read2_b32 %4, %18 offset1:1\n\tds_read_b32 %5, %18 offset:8\n\t"
+                 "ds_read2_b32 %6, %19 offset1:1\n\tds_read_b32 %7, %19 offset:8\n\t"
+                 "ds_read2_b32 %8, %20 offset1:1\n\tds_read_b32 %9, %20 offset:8\n\t"
+                 "ds_read2_b32 %10, %21 offset1:1\n\tds_read_b32 %11, %21 offset:8\n\t"
+                 "ds_read2_b32 %12, %22 offset1:1\n\tds_read_b32 %13, %22 offset:8\n\t"
+                 "ds_read2_b32 %14, %23 offset1:1\n\tds_read_b32 %15, %23 offset:8\n\ts_waitcnt lgkmcnt(0)"
+                 : "=&v"(w[0].lo), "=&v"(w[0].hi), "=&v"(w[1].lo), "=&v"(w[1].hi), "=&v"(w[2].lo), "=&v"(w[2].hi),
+                   "=&v"(w[3].lo), "=&v"(w[3].hi), "=&v"(w[4].lo), "=&v"(w[4].hi), "=&v"(w[5].lo), "=&v"(w[5].hi),
+                   "=&v"(w[6].lo), "=&v"(w[6].hi), "=&v"(w[7].lo), "=&v"(w[7].hi)
+                 : "v"(p[0]), "v"(p[1]), "v"(p[2]), "v"(p[3]), "v"(p[4]), "v"(p[5]), "v"(p[6]), "v"(p[7]) : "memory");
+}
+// 4-byte windows lie inside two aligned dwords
+[[maybe_unused]] __device__ __forceinline__ void lds_read_win2(u32x2_t (&w)[8], const uint32_t (&p)[8])
+{
+    asm volatile("ds_read2_b32 %0, %8 offset1:1\n\tds_read2_b32 %1, %9 offset1:1\n\tds_read2_b32 %2, %10 offset1:1\n\t"
+                 "ds_read2_b32 %3, %11 offset1:1\n\tds_read2_b32 %4, %12 offset1:1\n\tds_read2_b32 %5, %13 offset1:1\n\t"
+                 "ds_read2_b32 %6, %14 offset1:1\n\tds_read2_b32 %7, %15 offset1:1\n\ts_waitcnt lgkmcnt(0)"
+                 : "=&v"(w[0]), "=&v"(w[1]), "=&v"(w[2]), "=&v"(w[3]), "=&v"(w[4]), "=&v"(w[5]), "=&v"(w[6]), "=&v"(w[7])
+                 : "v"(p[0]), "v"(p[1]), "v"(p[2]), "v"(p[3]), "v"(p[4]), "v"(p[5]), "v"(p[6]), "v"(p[7]) : "memory");
+}
+
+constexpr int kMaxPieces = 8;      // source runs a wave's 64 strips may need (they wrap over plane rows)
+
+// LW, R as in strip_kernel; G4: grouped windows (two 8-byte windows per lane, taps <= 4), else one
+// LW-byte window per column; NDMA: 1 KiB LDS-DMAs per source row (the wave's runs hold <= 64 * NDMA
+// sixteen-byte chunks).  Eight columns per lane.
+template <int LW, int R, bool G4, int NDMA>
+__global__ __launch_bounds__(kBlock, (G4 && R == 4) ? 8 : 4) void strip_lds_kernel(const uint8_t *__restrict__ src, uint8_t *__restrict__ dst,
+                                                                               const uint32_t *__restrict__ tab, const StripArgs a)
+{
+    static_assert(R % 2 == 0 && (LW == 4 || LW == 8) && (!G4 || LW == 4) && (NDMA == 1 || NDMA == 2), "see strip_kernel");
 #if defined(__HIP_DEVICE_COMPILE__)   // the LDS-DMA builtin exists in the device pass only
-    constexpr int NL = N / 4;                        // windows per row per lane
-    constexpr int kSlotBytes = 1024 + 16;
-    __shared__ __attribute__((aligned(16))) uint8_t lds[kBlock / 64][D][kSlotBytes];
+    constexpr int N = 8;
+    constexpr int NW = G4 ? 2 : N;                   // windows per row per lane
+    constexpr int kSlotBytes = NDMA * 1024 + 16;
+    __shared__ __attribute__((aligned(16))) uint8_t lds[kBlock / 64][kSlotBytes];
 
     uint32_t lb = xcd_remap(blockIdx.x, gridDim.x);
     const int ci = lb >= a.c[0].nblocks ? 1 : 0;
@@ -370,6 +414,7 @@ __global__ __launch_bounds__(kBlock, N == 8 ? 8 : 4) void strip_lds_kernel(const
     const int fp    = g / c.strips;
     const int wave = __builtin_amdgcn_readfirstlane(int(threadIdx.x) >> 6);
     const int lane = int(threadIdx.x) & 63;
+
     const int plane = c.plane0 + fp % c.planes;
     const int frame = fp / c.planes;
     uint32_t soff, doff;
@@ -385,48 +430,71 @@ __global__ __launch_bounds__(kBlock, N == 8 ? 8 : 4) void strip_lds_kernel(const
     // offset past the end of the buffer: the descriptor's range check discards their stores.
     if (!live) doff = kDiscard;
 
-    uint32_t off[NL];
-    uint32_t hc[N][2];
-    uint32_t sel[N][2];
+    uint32_t off[NW];                                // first source byte of each window
+    uint32_t hc[N][LW / 2];
+    uint32_t sel[G4 ? N : 1][2];
     {
-        const uint32_t *ho = tab + c.hoff + strip * NL;
-        const uint32_t *hk = tab + c.hcoef + strip * N * 2;
-        const uint32_t *hs = tab + c.hsel + strip * N * 2;
+        const uint32_t *ho = tab + c.hoff + strip * NW;
+        const uint32_t *hk = tab + c.hcoef + strip * N * (LW / 2);
 #pragma unroll
-        for (int i = 0; i < NL; ++i) off[i] = ho[i] + soff;
+        for (int i = 0; i < NW; ++i) off[i] = ho[i] + soff;
 #pragma unroll
-        for (int i = 0; i < N; ++i) {
-            hc[i][0] = hk[2 * i]; hc[i][1] = hk[2 * i + 1];
-            sel[i][0] = hs[2 * i]; sel[i][1] = hs[2 * i + 1];
+        for (int i = 0; i < N; ++i)
+#pragma unroll
+            for (int k = 0; k < LW / 2; ++k) hc[i][k] = hk[i * (LW / 2) + k];
+        if constexpr (G4) {
+            const uint32_t *hs = tab + c.hsel + strip * N * 2;
+#pragma unroll
+            for (int i = 0; i < N; ++i) { sel[i][0] = hs[2 * i]; sel[i][1] = hs[2 * i + 1]; }
         }
     }
 
-    // The wave's run of source bytes: piece A starts at lane 0's first window, piece B (if any)
-    // at the first lane whose windows restart in another plane row.  Both are 16-byte granular.
-    const uint32_t first = off[0], last = off[NL - 1] + 8;          // this lane's bytes: [first, last)
-    const uint32_t prev_first = uint32_t(__builtin_amdgcn_update_dpp(int(first), int(first), 0x138 /* wave_shr:1 */, 0xf, 0xf, false));
-    const bool restart = lane > 0 && (first < prev_first || first - prev_first > 256u);
-    const uint64_t rmask = __builtin_amdgcn_ballot_w64(restart);
-    const int bl = rmask ? __builtin_ctzll(rmask) : 64;               // first lane of piece B
-    const uint32_t a_start = uni(first) & ~15u;
-    const uint32_t a_last  = uint32_t(__builtin_amdgcn_readlane(int(last), bl - 1));
-    const uint32_t n_a     = (a_last - a_start + 15u) >> 4;           // 16-byte chunks of piece A
-    const uint32_t b_start = (bl < 64 ? uint32_t(__builtin_amdgcn_readlane(int(first), bl & 63)) : a_start) & ~15u;
-    const uint32_t b_last  = uint32_t(__builtin_amdgcn_readlane(int(last), 63));
-    const uint32_t n_b     = bl < 64 ? (b_last - b_start + 15u) >> 4 : 0u;
-    // two pieces at most, and they must fit the 64 x 16-byte slot (the host only picks this kernel
-    // for geometries where they do; anything else here would be silent corruption, so trap)
-    if (__builtin_popcountll(rmask) > 1 || n_a + n_b > 64u) __builtin_trap();
+    // The wave's source bytes are one run per plane row its 64 strips touch ("pieces": a new one
+    // starts at every lane whose windows restart in another plane).  Piece p covers lanes [l0, l1),
+    // bytes [start, end) rounded out to 16-byte chunks, and takes the next n chunks of the slot;
+    // chunk c of the slot is fetched by lane c % 64 of DMA c / 64.
+    constexpr uint32_t kWin = G4 ? 8u : uint32_t(LW);
+    const uint32_t first = off[0], last = off[NW - 1] + kWin;          // this lane's bytes: [first, last)
+    const bool restart = lane > 0 && strip == 0 && live;               // a new plane row begins at this lane
+    uint64_t pm = __builtin_amdgcn_ballot_w64(restart) | 1ull;
+    uint32_t csrc[NDMA];
+    uint32_t lbase = 0, prefix = 0;
+#pragma unroll
+    for (int d = 0; d < NDMA; ++d) csrc[d] = uni(first) & ~15u;       // spare lanes re-fetch the first chunk
+    for (int p = 0; p < kMaxPieces && pm; ++p) {
+        const int l0 = __builtin_ctzll(pm);
+        pm &= pm - 1;
+        const int l1 = pm ? __builtin_ctzll(pm) : 64;
+        const uint32_t start = uint32_t(__builtin_amdgcn_readlane(int(first), l0)) & ~15u;
+        const uint32_t end   = uint32_t(__builtin_amdgcn_readlane(int(last), l1 - 1));
+        const uint32_t n     = (end - start + 15u) >> 4;
+        if (lane >= l0 && lane < l1) lbase = 16u * prefix - start;
+#pragma unroll
+        for (int d = 0; d < NDMA; ++d) {
+            const uint32_t ch = uint32_t(lane) + 64u * d;
+            if (ch >= prefix && ch < prefix + n) csrc[d] = start + 16u * (ch - prefix);
+        }
+        prefix += n;
+    }
+    // the host picks this kernel only for geometries whose runs fit; anything else here would be
+    // silent corruption, so trap
+    if (pm || prefix > 64u * NDMA) __builtin_trap();
 
-    // chunk `lane` of the run -> where this lane's DMA reads from; window j -> where it lands in LDS
-    const uint32_t chunk_src = uint32_t(lane) < n_a ? a_start + 16u * uint32_t(lane)
-                                                    : b_start + 16u * min(uint32_t(lane) - n_a, n_b ? n_b - 1u : 0u);
-    uint32_t lpos[NL];
+    const uint32_t lds_wave = uint32_t(reinterpret_cast<uintptr_t>((lds_void_t *)&lds[wave][0]));   // LDS byte address
+    uint32_t lpos[NW];                               // aligned LDS address of each window's first dword
+    uint32_t phase[G4 ? NW : 1];                     // G4: byte phase of the window inside it (v_alignbyte uses bits 1:0)
+    uint32_t psel[G4 ? 1 : N][2];                    // per-column windows: the phase folded into v_perm selectors
 #pragma unroll
-    for (int j = 0; j < NL; ++j) lpos[j] = lane < bl ? off[j] - a_start : 16u * n_a + (off[j] - b_start);
-    const uint32_t lds_wave = uint32_t(reinterpret_cast<uintptr_t>((lds_void_t *)&lds[wave][0][0]));   // LDS byte address
-#pragma unroll
-    for (int j = 0; j < NL; ++j) lpos[j] += lds_wave;
+    for (int j = 0; j < NW; ++j) {
+        const uint32_t pos = off[j] + lbase + lds_wave;
+        lpos[j] = pos & ~3u;
+        if constexpr (G4) phase[j] = pos;
+        else {
+            const uint32_t o = pos & 3u;             // taps 2q, 2q+1 (as 16-bit lanes) sit at bytes o, o+1 / o+2, o+3 of a dword pair
+            psel[j][0] = 0x0c000c00u | o | ((o + 1u) << 16);
+            psel[j][1] = 0x0c000c00u | (o + 2u) | ((o + 3u) << 16);
+        }
+    }
 
     uint32_t ring[N][R / 2];
 #pragma unroll
@@ -449,16 +517,13 @@ __global__ __launch_bounds__(kBlock, N == 8 ? 8 : 4) void strip_lds_kernel(const
     const u32x4_t drs = {uni(uint32_t(dbase)), uni(uint32_t(dbase >> 32) & 0xffffu), uni(a.dst_span), 0x00020000u};
 
 #pragma unroll
-    for (int d = 0; d < D; ++d)
-        __builtin_amdgcn_raw_ptr_buffer_load_lds(srs, (lds_void_t *)&lds[wave][d][0], 16, chunk_src,
-                                                 (rstart + min(d, nrows - 1)) * src_stride, 0, 0);
+    for (int d = 0; d < NDMA; ++d)
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(srs, (lds_void_t *)&lds[wave][d * 1024], 16, csrc[d], rstart * src_stride, 0, 0);
     int cnt_next = int(uni(emit[0]));
     uint32_t vk_next[R / 2];                       // vertical taps of the next output row, requested a row ahead
 #pragma unroll
     for (int q = 0; q < R / 2; ++q) vk_next[q] = uni(vco[y * (R / 2) + q]);
-    int hist[D];                                   // stores issued in each of the last D iterations
-#pragma unroll
-    for (int d = 0; d < D; ++d) hist[d] = 0;
+    int prev_cnt = 0;                              // stores issued since the DMA of the row about to be read
 
     for (int k0 = 0; k0 < nrows; k0 += R) {
 #pragma unroll
@@ -467,40 +532,48 @@ __global__ __launch_bounds__(kBlock, N == 8 ? 8 : 4) void strip_lds_kernel(const
             if (k >= nrows) break;                              // wave-uniform
             const int cnt = cnt_next;
             cnt_next = int(uni(emit[min(k + 1, nrows - 1)]));
-            // row k's DMA is followed by D-1 younger DMAs and the stores of the last D iterations
-            int younger = 0;
+            wait_vm_plus<0>(prev_cnt);                          // row k's DMA has landed; younger stores may still fly
+            uint32_t wk[NW][3];                                 // the aligned dwords holding each window
+            if constexpr (LW == 8 || G4) {
+                Win3 wv[NW];
+                lds_read_win3(wv, lpos);
 #pragma unroll
-            for (int d = 0; d < D; ++d) younger += hist[d];
-            wait_vm_plus<D - 1>(younger);
-            // The window reads are inline asm: an LDS read hipcc can see gets its own vmcnt(0) (it orders
-            // LDS reads behind every outstanding LDS-DMA), which would undo the counted wait above.
-            // Reads and their lgkmcnt wait sit in ONE asm statement, so no output register exists,
-            // as far as the compiler can tell, before its data has landed.
-            u32x2_t wv[NL];
-            if constexpr (NL == 2) {
-                asm volatile("ds_read_b64 %0, %2 offset:%4\n\tds_read_b64 %1, %3 offset:%4\n\ts_waitcnt lgkmcnt(0)"
-                             : "=&v"(wv[0]), "=&v"(wv[1]) : "v"(lpos[0]), "v"(lpos[1]), "n"((s % D) * kSlotBytes) : "memory");
+                for (int j = 0; j < NW; ++j) { wk[j][0] = wv[j].lo.x; wk[j][1] = wv[j].lo.y; wk[j][2] = wv[j].hi; }
             } else {
-                asm volatile("ds_read_b64 %0, %4 offset:%8\n\tds_read_b64 %1, %5 offset:%8\n\t"
-                             "ds_read_b64 %2, %6 offset:%8\n\tds_read_b64 %3, %7 offset:%8\n\ts_waitcnt lgkmcnt(0)"
-                             : "=&v"(wv[0]), "=&v"(wv[1]), "=&v"(wv[2]), "=&v"(wv[3])
-                             : "v"(lpos[0]), "v"(lpos[1]), "v"(lpos[2]), "v"(lpos[3]), "n"((s % D) * kSlotBytes) : "memory");
-            }
-            uint32_t wk[NL][2];
+                u32x2_t wv[NW];
+                lds_read_win2(wv, lpos);
 #pragma unroll
-            for (int j = 0; j < NL; ++j) { wk[j][0] = wv[j].x; wk[j][1] = wv[j].y; }
+                for (int j = 0; j < NW; ++j) { wk[j][0] = wv[j].x; wk[j][1] = wv[j].y; wk[j][2] = 0; }
+            }
+            if constexpr (G4) {                                 // rebuild the two 8-byte windows
+#pragma unroll
+                for (int j = 0; j < NW; ++j) {
+                    wk[j][0] = __builtin_amdgcn_alignbyte(wk[j][1], wk[j][0], phase[j]);
+                    wk[j][1] = __builtin_amdgcn_alignbyte(wk[j][2], wk[j][1], phase[j]);
+                }
+            }
+            // the slot is free again (its bytes sit in registers): request row k + 1 into it
+#pragma unroll
+            for (int d = 0; d < NDMA; ++d)
+                __builtin_amdgcn_raw_ptr_buffer_load_lds(srs, (lds_void_t *)&lds[wave][d * 1024], 16, csrc[d],
+                                                         (rstart + min(k + 1, nrows - 1)) * src_stride, 0, 0);
 #pragma unroll
             for (int i = 0; i < N; ++i) {
                 int acc = 0;
-                acc = dot2(__builtin_amdgcn_perm(wk[i / 4][1], wk[i / 4][0], sel[i][0]), hc[i][0], acc);
-                acc = dot2(__builtin_amdgcn_perm(wk[i / 4][1], wk[i / 4][0], sel[i][1]), hc[i][1], acc);
+                if constexpr (G4) {
+                    acc = dot2(__builtin_amdgcn_perm(wk[i / 4][1], wk[i / 4][0], sel[i][0]), hc[i][0], acc);
+                    acc = dot2(__builtin_amdgcn_perm(wk[i / 4][1], wk[i / 4][0], sel[i][1]), hc[i][1], acc);
+                } else {
+#pragma unroll
+                    for (int q = 0; q < LW / 4; ++q) {          // taps 4q .. 4q+3 start at byte o of dwords q, q+1
+                        acc = dot2(__builtin_amdgcn_perm(wk[i][q + 1], wk[i][q], psel[i][0]), hc[i][2 * q], acc);
+                        acc = dot2(__builtin_amdgcn_perm(wk[i][q + 1], wk[i][q], psel[i][1]), hc[i][2 * q + 1], acc);
+                    }
+                }
                 const uint32_t t = hfinish(acc);
                 ring[i][s / 2] = (s & 1) ? __builtin_amdgcn_perm(t, ring[i][s / 2], 0x05040100)
                                          : __builtin_amdgcn_perm(ring[i][s / 2], t, 0x07060100);
             }
-            // the slot is free again (its bytes sit in registers): request row k + D into it
-            __builtin_amdgcn_raw_ptr_buffer_load_lds(srs, (lds_void_t *)&lds[wave][s % D][0], 16, chunk_src,
-                                                     (rstart + min(k + D, nrows - 1)) * src_stride, 0, 0);
             for (int e = 0; e < cnt; ++e) {                     // wave-uniform
                 uint32_t vk[R / 2];
 #pragma unroll
@@ -521,12 +594,10 @@ __global__ __launch_bounds__(kBlock, N == 8 ? 8 : 4) void strip_lds_kernel(const
                     }
                     o[q] = pack4(v[0], v[1], v[2], v[3]);
                 }
-                const int outoff = y * dst_stride;
-                if constexpr (N == 16) store_b128(u32x4_t{o[0], o[1], o[2], o[3]}, drs, doff, outoff);
-                else store_b64(u32x2_t{o[0], o[1]}, drs, doff, outoff);
+                store_b64(u32x2_t{o[0], o[1]}, drs, doff, y * dst_stride);
                 ++y;
             }
-            hist[s % D] = cnt;
+            prev_cnt = cnt;
         }
     }
 #endif
@@ -626,7 +697,8 @@ struct HTables {
     uint32_t hoff = 0, hcoef = 0;                  // one window per column
     bool g4 = false;                               // grouped 8-byte windows usable (taps <= 4, 4 columns span <= 8 bytes)
     uint32_t hoff4 = 0, hsel4 = 0, hcoef4 = 0;
-    bool lds_ok = false;                           // LDS-staged kernel usable
+    int lds_g4 = 0, lds_col = 0;                   // LDS-staged kernel: 1 KiB DMAs per row it needs with grouped /
+                                                   // per-column windows (0 = not usable)
 };
 
 struct ClassPlan {
@@ -712,6 +784,33 @@ void build_seg_tables(const ClassPlan &c, int seg_rows, std::vector<uint32_t> &t
     }
 }
 
+// LDS-staged kernel: how many 1 KiB LDS-DMAs per source row does a wave need?  Any 64 consecutive
+// strips of the flattened (plane, strip) order -- they wrap over plane rows -- need one run of source
+// bytes per row touched, each rounded out to 16-byte chunks (worst case over the run's alignment);
+// the runs must fit 64 chunks per DMA and kMaxPieces runs.  `lo` holds the first byte of each of the
+// `nw` windows of a strip, `win` their width.  0 = not usable.
+int lds_dmas(const ClassPlan &c, const HTables &t, int N, const int *lo, int nw, int win)
+{
+    if (N != 8 || c.ow < N || t.strips < 2 || env_int("TTS_NO_LDS", 0)) return 0;
+    auto chunks = [&](int s0, int s1) {   // strips [s0, s1] of one row
+        const uint32_t b = uint32_t(lo[size_t(s0) * nw]), e = uint32_t(lo[size_t(s1) * nw + nw - 1] + win);
+        return (e - b + 30u) >> 4;
+    };
+    uint32_t worst = 0;
+    for (int s0 = 0; s0 < t.strips; ++s0) {
+        uint32_t n = 0;
+        int pieces = 0, s = s0, left = 64;
+        while (left > 0) {
+            const int take = std::min(left, t.strips - s);
+            n += chunks(s, s + take - 1);
+            ++pieces; left -= take; s = 0;
+        }
+        if (pieces > kMaxPieces) return 0;
+        worst = std::max(worst, n);
+    }
+    return worst <= 64u ? 1 : worst <= 128u ? 2 : 0;
+}
+
 int build_class(const tts_geom &g, int sub, ClassPlan &c, std::vector<uint32_t> &tab)
 {
     c.sub = sub;
@@ -787,19 +886,14 @@ int build_class(const tts_geom &g, int sub, ClassPlan &c, std::vector<uint32_t> 
             tab[t.hcoef4 + 2 * size_t(i)]     = pack16(t4[0], t4[1]);
             tab[t.hcoef4 + 2 * size_t(i) + 1] = pack16(t4[2], t4[3]);
         }
-        // LDS-staged kernel: any 64 consecutive strips (they may wrap once into the next plane row)
-        // must need at most two runs of source bytes that together fit 64 sixteen-byte chunks.
-        bool ok = t.strips >= 64 && c.ow >= N && R == 4;
-        auto chunks = [&](int s0, int s1) {   // strips [s0, s1] of one row
-            const uint32_t lo = uint32_t(glo[s0 * NL]), hi = uint32_t(glo[s1 * NL + NL - 1]) + 8u;
-            return (hi - lo + 30u) >> 4;      // worst case over the run's 16-byte alignment
-        };
-        for (int s0 = 0; s0 < t.strips && ok; ++s0) {
-            const int s1 = s0 + 63;
-            const uint32_t n = s1 < t.strips ? chunks(s0, s1) : chunks(s0, t.strips - 1) + chunks(0, s1 - t.strips);
-            ok = n <= 64u;
-        }
-        t.lds_ok = ok && !env_int("TTS_NO_LDS", 0);
+        t.lds_g4 = lds_dmas(c, t, N, glo.data(), NL, 8);
+    }
+    for (int v = 0; v < 2; ++v) {
+        HTables &t = c.ht[v];
+        const int N = v ? 16 : 8;
+        std::vector<int> lo(size_t(t.strips) * N);
+        for (size_t i = 0; i < lo.size(); ++i) lo[i] = int(tab[t.hoff + i]);
+        t.lds_col = lds_dmas(c, t, N, lo.data(), N, LW);
     }
     std::vector<int> opts(kSegOptions, kSegOptions + kNumSegOptions);
     const int forced = env_int("TTS_SEG_ROWS", 0);
@@ -819,24 +913,30 @@ void free_class(ClassPlan &c)
 
 typedef void (*strip_fn)(const uint8_t *, uint8_t *, const uint32_t *, const StripArgs);
 
-struct StripChoice { int LW, R, N; bool g4, lds; };
+struct StripChoice { int LW, R, N; bool g4; int lds; };   // lds: LDS-DMAs per row of the LDS-staged kernel, 0 = register kernel
 
 StripChoice strip_choice(const ClassPlan &c)
 {
-    StripChoice ch{c.LW, c.R, 8, false, false};
+    StripChoice ch{c.LW, c.R, 8, false, 0};
     if (c.LW == 4 && c.R == 4) ch.N = env_int("TTS_STRIP_N", 8) == 16 ? 16 : 8;
     const HTables &t = c.ht[ch.N == 16];
     ch.g4 = t.g4;
-    ch.lds = t.g4 && c.R == 4 && t.lds_ok;
+    ch.lds = t.g4 ? t.lds_g4 : t.lds_col;
+    if (t.g4 && ch.lds != 1) { ch.lds = t.lds_col; if (ch.lds) ch.g4 = false; }   // grouped windows ride in one DMA only
     return ch;
 }
 
 strip_fn pick_strip(const StripChoice &ch)
 {
-    const int D = env_int("TTS_STRIP_D", 0);          // rows in flight (tuning knob; defaults below)
+    const int D = env_int("TTS_STRIP_D", 0);          // rows in flight of the register kernels (tuning knob)
+    if (ch.lds && ch.g4) {
+        return ch.R == 4 ? strip_lds_kernel<4, 4, true, 1> : ch.R == 6 ? strip_lds_kernel<4, 6, true, 1> : strip_lds_kernel<4, 8, true, 1>;
+    }
     if (ch.lds) {
-        if (ch.N == 16) return D == 4 ? strip_lds_kernel<4, 16, 4> : D == 2 ? strip_lds_kernel<4, 16, 2> : strip_lds_kernel<4, 16, 1>;
-        return D == 4 ? strip_lds_kernel<4, 8, 4> : D == 2 ? strip_lds_kernel<4, 8, 2> : strip_lds_kernel<4, 8, 1>;
+#define TTS_LDS_PICK(LW_, R_) (ch.lds == 1 ? strip_lds_kernel<LW_, R_, false, 1> : strip_lds_kernel<LW_, R_, false, 2>)
+        if (ch.LW == 4) return ch.R == 4 ? TTS_LDS_PICK(4, 4) : ch.R == 6 ? TTS_LDS_PICK(4, 6) : TTS_LDS_PICK(4, 8);
+        return ch.R == 4 ? TTS_LDS_PICK(8, 4) : ch.R == 6 ? TTS_LDS_PICK(8, 6) : TTS_LDS_PICK(8, 8);
+#undef TTS_LDS_PICK
     }
     if (ch.LW == 4 && ch.R == 4 && ch.g4) {
         if (ch.N == 16) return strip_kernel<4, 4, 16, 1, true>;
