@@ -355,12 +355,14 @@ __device__ __forceinline__ void wait_vm_plus(int extra)
 // v_perm selectors / a v_alignbyte afterwards.  Reads and their lgkmcnt wait sit in the SAME asm
 // statement: no output register exists, as far as the compiler can tell, before its data landed.
 struct Win3 { u32x2_t lo; uint32_t hi; };
-[[maybe_unused]] __device__ __forceinline__ void lds_read_win3(Win3 (&w)[2], const uint32_t (&p)[2])
-{
-    asm volatile("ds_read2_b32 %0, %4 offset1:1\n\tds_read_b32 %1, %4 offset:8\n\t"
-                 "ds_read2_b32 %2, %5 offset1:1\n\tds_read_b32 %3, %5 offset:8\n\ts_waitcnt lgkmcnt(0)"
-                 : "=&v"(w[0].lo), "=&v"(w[0].hi), "=&v"(w[1].lo), "=&v"(w[1].hi) : "v"(p[0]), "v"(p[1]) : "memory");
-}
+// (the two-window reader takes the slot's byte offset as an immediate: with D > 1 rows in flight the
+// slot changes from row to row, and ds_read2's 8-bit dword offsets cannot reach the second slot)
+#define TTS_LDS_READ_WIN3_X2(w, p, off)                                                                          \
+    asm volatile("ds_read_b32 %0, %6 offset:%8\n\tds_read_b32 %1, %6 offset:%8+4\n\tds_read_b32 %2, %6 offset:%8+8\n\t" \
+                 "ds_read_b32 %3, %7 offset:%8\n\tds_read_b32 %4, %7 offset:%8+4\n\tds_read_b32 %5, %7 offset:%8+8\n\t" \
+                 "s_waitcnt lgkmcnt(0)"                                                                           \
+                 : "=&v"(w[0][0]), "=&v"(w[0][1]), "=&v"(w[0][2]), "=&v"(w[1][0]), "=&v"(w[1][1]), "=&v"(w[1][2])   \
+                 : "v"(p[0]), "v"(p[1]), "n"(off) : "memory")
 [[maybe_unused]] __device__ __forceinline__ void lds_read_win3(Win3 (&w)[8], const uint32_t (&p)[8])
 {
     asm volatile("ds_read2_b32 %0, %16 offset1:1\n\tds_read_b32 %1, %16 offset:8\n\t"
@@ -391,17 +393,18 @@ constexpr int kMaxPieces = 8;      // source runs a wave's 64 strips may need (t
 // LW, R as in strip_kernel; G4: grouped windows (two 8-byte windows per lane, taps <= 4), else one
 // LW-byte window per column; NDMA: 1 KiB LDS-DMAs per source row (the wave's runs hold <= 64 * NDMA
 // sixteen-byte chunks).  Eight columns per lane.
-template <int LW, int R, bool G4, int NDMA>
+template <int LW, int R, bool G4, int NDMA, int D>
 __global__ __launch_bounds__(kMaxLdsBlock, (G4 && R == 4) ? 8 : 4) void strip_lds_kernel(const uint8_t *__restrict__ src, uint8_t *__restrict__ dst,
                                                                                const uint32_t *__restrict__ tab, const StripArgs a)
 {
     static_assert(R % 2 == 0 && (LW == 4 || LW == 8) && (!G4 || LW == 4) && (NDMA == 1 || NDMA == 2), "see strip_kernel");
+    static_assert(D >= 1 && R % D == 0, "D source rows in flight, one LDS slot each, rotating with the ring");
 #if defined(__HIP_DEVICE_COMPILE__)   // the LDS-DMA builtin exists in the device pass only
     constexpr int N = 8;
     constexpr int NW = G4 ? 2 : N;                   // windows per row per lane
     constexpr int kSlotBytes = NDMA * 1024 + 16;
-    extern __shared__ __attribute__((aligned(16))) uint8_t lds_raw[];      // (blockDim.x / 64) slots
-    uint8_t (*lds)[kSlotBytes] = reinterpret_cast<uint8_t (*)[kSlotBytes]>(lds_raw);
+    extern __shared__ __attribute__((aligned(16))) uint8_t lds_raw[];      // (blockDim.x / 64) x D slots
+    uint8_t (*lds)[D][kSlotBytes] = reinterpret_cast<uint8_t (*)[D][kSlotBytes]>(lds_raw);
 
     uint32_t lb = xcd_remap(blockIdx.x, gridDim.x);
     const int ci = lb >= a.c[0].nblocks ? 1 : 0;
@@ -484,7 +487,7 @@ __global__ __launch_bounds__(kMaxLdsBlock, (G4 && R == 4) ? 8 : 4) void strip_ld
     // silent corruption, so trap
     if (pm || prefix > 64u * NDMA) __builtin_trap();
 
-    const uint32_t lds_wave = uint32_t(reinterpret_cast<uintptr_t>((lds_void_t *)&lds[wave][0]));   // LDS byte address
+    const uint32_t lds_wave = uint32_t(reinterpret_cast<uintptr_t>((lds_void_t *)&lds[wave][0][0]));   // LDS byte address
     uint32_t lpos[NW];                               // aligned LDS address of each window's first dword
     uint32_t phase[G4 ? NW : 1];                     // G4: byte phase of the window inside it (v_alignbyte uses bits 1:0)
     uint32_t psel[G4 ? 1 : N][2];                    // per-column windows: the phase folded into v_perm selectors
@@ -522,13 +525,18 @@ __global__ __launch_bounds__(kMaxLdsBlock, (G4 && R == 4) ? 8 : 4) void strip_ld
     const u32x4_t drs = {uni(uint32_t(dbase)), uni(uint32_t(dbase >> 32) & 0xffffu), uni(a.dst_span), 0x00020000u};
 
 #pragma unroll
-    for (int d = 0; d < NDMA; ++d)
-        __builtin_amdgcn_raw_ptr_buffer_load_lds(srs, (lds_void_t *)&lds[wave][d * 1024], 16, csrc[d], rstart * src_stride, 0, 0);
+    for (int r = 0; r < D; ++r)
+#pragma unroll
+        for (int d = 0; d < NDMA; ++d)
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(srs, (lds_void_t *)&lds[wave][r][d * 1024], 16, csrc[d],
+                                                     (rstart + min(r, nrows - 1)) * src_stride, 0, 0);
     int cnt_next = int(uni(emit[0]));
     uint32_t vk_next[R / 2];                       // vertical taps of the next output row, requested a row ahead
 #pragma unroll
     for (int q = 0; q < R / 2; ++q) vk_next[q] = uni(vco[y * (R / 2) + q]);
-    int prev_cnt = 0;                              // stores issued since the DMA of the row about to be read
+    int hist[D];                                   // stores issued in each of the last D iterations
+#pragma unroll
+    for (int r = 0; r < D; ++r) hist[r] = 0;
 
     for (int k0 = 0; k0 < nrows; k0 += R) {
 #pragma unroll
@@ -537,9 +545,16 @@ __global__ __launch_bounds__(kMaxLdsBlock, (G4 && R == 4) ? 8 : 4) void strip_ld
             if (k >= nrows) break;                              // wave-uniform
             const int cnt = cnt_next;
             cnt_next = int(uni(emit[min(k + 1, nrows - 1)]));
-            wait_vm_plus<0>(prev_cnt);                          // row k's DMA has landed; younger stores may still fly
+            // row k's DMA is followed by the DMAs of D-1 younger rows and the stores of the last D iterations
+            int younger = 0;
+#pragma unroll
+            for (int r = 0; r < D; ++r) younger += hist[r];
+            wait_vm_plus<(D - 1) * NDMA>(younger);
             uint32_t wk[NW][3];                                 // the aligned dwords holding each window
-            if constexpr (LW == 8 || G4) {
+            if constexpr (G4) {
+                TTS_LDS_READ_WIN3_X2(wk, lpos, (s % D) * kSlotBytes);
+            } else if constexpr (LW == 8) {
+                static_assert(G4 || D == 1, "per-column readers address slot 0 only");
                 Win3 wv[NW];
                 lds_read_win3(wv, lpos);
 #pragma unroll
@@ -557,11 +572,11 @@ __global__ __launch_bounds__(kMaxLdsBlock, (G4 && R == 4) ? 8 : 4) void strip_ld
                     wk[j][1] = __builtin_amdgcn_alignbyte(wk[j][2], wk[j][1], phase[j]);
                 }
             }
-            // the slot is free again (its bytes sit in registers): request row k + 1 into it
+            // the slot is free again (its bytes sit in registers): request row k + D into it
 #pragma unroll
             for (int d = 0; d < NDMA; ++d)
-                __builtin_amdgcn_raw_ptr_buffer_load_lds(srs, (lds_void_t *)&lds[wave][d * 1024], 16, csrc[d],
-                                                         (rstart + min(k + 1, nrows - 1)) * src_stride, 0, 0);
+                __builtin_amdgcn_raw_ptr_buffer_load_lds(srs, (lds_void_t *)&lds[wave][s % D][d * 1024], 16, csrc[d],
+                                                         (rstart + min(k + D, nrows - 1)) * src_stride, 0, 0);
 #pragma unroll
             for (int i = 0; i < N; ++i) {
                 int acc = 0;
@@ -603,7 +618,7 @@ __global__ __launch_bounds__(kMaxLdsBlock, (G4 && R == 4) ? 8 : 4) void strip_ld
                 store_b64(u32x2_t{o[0], o[1]}, drs, doff, y * dst_stride);
                 ++y;
             }
-            prev_cnt = cnt;
+            hist[s % D] = cnt;
         }
     }
 #endif
@@ -919,16 +934,18 @@ void free_class(ClassPlan &c)
 
 typedef void (*strip_fn)(const uint8_t *, uint8_t *, const uint32_t *, const StripArgs);
 
-struct StripChoice { int LW, R, N; bool g4; int lds; };   // lds: LDS-DMAs per row of the LDS-staged kernel, 0 = register kernel
+// lds: LDS-DMAs per row of the LDS-staged kernel, 0 = register kernel; depth: its source rows in flight
+struct StripChoice { int LW, R, N; bool g4; int lds; int depth; };
 
 StripChoice strip_choice(const ClassPlan &c)
 {
-    StripChoice ch{c.LW, c.R, 8, false, 0};
+    StripChoice ch{c.LW, c.R, 8, false, 0, 1};
     if (c.LW == 4 && c.R == 4) ch.N = env_int("TTS_STRIP_N", 8) == 16 ? 16 : 8;
     const HTables &t = c.ht[ch.N == 16];
     ch.g4 = t.g4;
     ch.lds = t.g4 ? t.lds_g4 : t.lds_col;
     if (t.g4 && ch.lds != 1) { ch.lds = t.lds_col; if (ch.lds) ch.g4 = false; }   // grouped windows ride in one DMA only
+    if (ch.lds && ch.g4 && ch.R == 4) ch.depth = env_int("TTS_STRIP_D", 1) == 2 ? 2 : 1;
     return ch;
 }
 
@@ -936,10 +953,11 @@ strip_fn pick_strip(const StripChoice &ch)
 {
     const int D = env_int("TTS_STRIP_D", 0);          // rows in flight of the register kernels (tuning knob)
     if (ch.lds && ch.g4) {
-        return ch.R == 4 ? strip_lds_kernel<4, 4, true, 1> : ch.R == 6 ? strip_lds_kernel<4, 6, true, 1> : strip_lds_kernel<4, 8, true, 1>;
+        if (ch.R == 4) return ch.depth == 2 ? strip_lds_kernel<4, 4, true, 1, 2> : strip_lds_kernel<4, 4, true, 1, 1>;
+        return ch.R == 6 ? strip_lds_kernel<4, 6, true, 1, 1> : strip_lds_kernel<4, 8, true, 1, 1>;
     }
     if (ch.lds) {
-#define TTS_LDS_PICK(LW_, R_) (ch.lds == 1 ? strip_lds_kernel<LW_, R_, false, 1> : strip_lds_kernel<LW_, R_, false, 2>)
+#define TTS_LDS_PICK(LW_, R_) (ch.lds == 1 ? strip_lds_kernel<LW_, R_, false, 1, 1> : strip_lds_kernel<LW_, R_, false, 2, 1>)
         if (ch.LW == 4) return ch.R == 4 ? TTS_LDS_PICK(4, 4) : ch.R == 6 ? TTS_LDS_PICK(4, 6) : TTS_LDS_PICK(4, 8);
         return ch.R == 4 ? TTS_LDS_PICK(8, 4) : ch.R == 6 ? TTS_LDS_PICK(8, 6) : TTS_LDS_PICK(8, 8);
 #undef TTS_LDS_PICK
@@ -1009,7 +1027,7 @@ BlockShape block_shape(const tts_plan *p, int ci, const StripChoice &ch, int dst
     paced = env_int("TTS_PACED", paced);
     int t = env_int("TTS_LDS_BLOCK", paced ? kMaxLdsBlock : kBlock);
     t = std::min(std::max(t / 64 * 64, 64), kMaxLdsBlock);
-    return {t, size_t(t / 64) * (size_t(ch.lds) * 1024 + 16), paced};
+    return {t, size_t(t / 64) * ch.depth * (size_t(ch.lds) * 1024 + 16), paced};
 }
 
 // Pick the row-segment length (one for both plane classes).  Long segments amortise the (taps-1)-row
@@ -1062,7 +1080,7 @@ int launch_all(const tts_plan *p, const uint8_t *src, uint8_t *dst, int n, const
     bool merged = false;
     if (ns == 2 && !env_int("TTS_NO_MERGE", 0)) {
         const StripChoice a0 = strip_choice(p->cls[0]), a1 = strip_choice(p->cls[1]);
-        merged = a0.LW == a1.LW && a0.R == a1.R && a0.N == a1.N && a0.g4 == a1.g4 && a0.lds == a1.lds;
+        merged = a0.LW == a1.LW && a0.R == a1.R && a0.N == a1.N && a0.g4 == a1.g4 && a0.lds == a1.lds && a0.depth == a1.depth;
     }
     for (int k = 0; k < ns; ++k) {
         StripArgs a{};
