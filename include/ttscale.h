@@ -28,6 +28,10 @@ typedef enum tts_status {
 
 enum { TTS_ALG_BICUBIC = 0, TTS_ALG_AREA = 1, TTS_ALG_BILINEAR = 2 };
 enum { TTS_MEM_DEVICE = 0, TTS_MEM_HOST = 1 };
+/* Range step applied to the finished 8-bit frame, borders included: what the swscale pass that
+ * ffmpeg auto-inserts between a yuv420p chain and an encoder wanting yuvj420p does -- the mjpeg
+ * thumbnail of src/services/video.js:329-334 (`-q:v 2 out.jpg`).  SURVEY.md S7 / 8f-1. */
+enum { TTS_RANGE_KEEP = 0, TTS_RANGE_TO_FULL = 1, TTS_RANGE_TO_LIMITED = 2 };
 
 /*
  * Resolved geometry of one filter chain, in luma pixels of a yuv420p frame:
@@ -43,6 +47,7 @@ typedef struct tts_geom {
     int32_t do_pad, pad_x, pad_y;             /* pad stage present; where the picture sits */
     int32_t out_w, out_h;                     /* final frame size */
     int32_t fill_y, fill_u, fill_v;           /* pad colour */
+    int32_t out_range;                        /* TTS_RANGE_*: `format=yuvj420p` / `format=yuv420p` ending the chain */
 } tts_geom;
 
 /* One yuv420p frame: Y, U, V plane pointers and byte strides. */

@@ -23,7 +23,7 @@ class Chain(ctypes.Structure):
     _fields_ = [(n, ctypes.c_int) for n in (
         "in_w", "in_h", "pre_x", "pre_y", "pre_w", "pre_h", "do_scale", "alg", "sc_w", "sc_h",
         "crop_x", "crop_y", "crop_w", "crop_h", "do_pad", "pad_x", "pad_y", "out_w", "out_h",
-        "fill_y", "fill_u", "fill_v")]
+        "fill_y", "fill_u", "fill_v", "out_range")]
 
 
 _lib = None
@@ -83,7 +83,7 @@ def chain_from(geom):
     """geom: anything with the tts_geom field names (dict or ctypes struct)."""
     c = Chain()
     for n, _ in Chain._fields_:
-        setattr(c, n, geom[n] if isinstance(geom, dict) else getattr(geom, n))
+        setattr(c, n, geom.get(n, 0) if isinstance(geom, dict) else getattr(geom, n))
     return c
 
 

@@ -347,5 +347,32 @@ int tto_run_chain(const tto_chain *c,
         }
         free(scaled);
     }
+    /* yuv420p -> yuvj420p (or back) is a SECOND swscale pass, same size, inserted by libavfilter's
+     * format negotiation.  Ranges differ, so sws_init_context() keeps the generic path
+     * (`unscaled && ... && srcRange == dstRange` fails): hScale8To15_c with the 1-tap 16384 filter
+     * (v = p << 7), lum/chrConvertRange on the 15-bit row (swscale.c lumRangeToJpeg_c,
+     * chrRangeToJpeg_c, lumRangeFromJpeg_c, chrRangeFromJpeg_c -- constants of FFmpeg 4.x-6.0,
+     * recalled, UNVERIFIED), then yuv2plane1_8_c: (v + 64) >> 7 clipped.  Borders included. */
+    if (c->out_range) {
+        for (int p = 0; p < 3; p++) {
+            const int sub = p ? 1 : 0;
+            const int ow = (c->out_w + sub) >> sub, oh = (c->out_h + sub) >> sub;
+            for (int y = 0; y < oh; y++) {
+                uint8_t *row = dp[p] + (size_t)y * dst_[p];
+                for (int x = 0; x < ow; x++) {
+                    int v = row[x] << 7;
+                    if (c->out_range == 1) {
+                        if (p) { if (v > 30775) v = 30775; v = (v * 4663 - 9289992) >> 12; }
+                        else   { if (v > 30189) v = 30189; v = (v * 19077 - 39057361) >> 14; }
+                    } else {
+                        if (p) v = (v * 1799 + 4081085) >> 11;
+                        else   v = (v * 14071 + 33561947) >> 14;
+                    }
+                    v = (v + 64) >> 7;
+                    row[x] = (uint8_t)(v < 0 ? 0 : v > 255 ? 255 : v);
+                }
+            }
+        }
+    }
     return 0;
 }

@@ -44,6 +44,7 @@ typedef struct tto_chain {
     int crop_x, crop_y, crop_w, crop_h; /* crop after scale */
     int do_pad, pad_x, pad_y, out_w, out_h; /* pad canvas */
     int fill_y, fill_u, fill_v;
+    int out_range;                    /* 0 keep, 1 limited->full, 2 full->limited: a second, unscaled swscale pass */
 } tto_chain;
 
 /* vf_scale output-size rule; foar: 0 disable, 1 decrease, 2 increase */

@@ -20,7 +20,7 @@ import synth  # noqa: E402
 from oracle import oracle  # noqa: E402
 
 # (name, geometry dict) -- geometry spelled out so that this file does not depend on the product's parser
-def geom(in_w, in_h, sc_w, sc_h, alg=0, pre=None, crop=None, pad=None, fill=(16, 128, 128)):
+def geom(in_w, in_h, sc_w, sc_h, alg=0, pre=None, crop=None, pad=None, fill=(16, 128, 128), out_range=0):
     pre = pre or (0, 0, in_w, in_h)
     crop = crop or (0, 0, sc_w, sc_h)
     g = dict(in_w=in_w, in_h=in_h, pre_x=pre[0], pre_y=pre[1], pre_w=pre[2], pre_h=pre[3],
@@ -28,6 +28,8 @@ def geom(in_w, in_h, sc_w, sc_h, alg=0, pre=None, crop=None, pad=None, fill=(16,
              crop_x=crop[0], crop_y=crop[1], crop_w=crop[2], crop_h=crop[3],
              do_pad=0, pad_x=0, pad_y=0, out_w=crop[2], out_h=crop[3],
              fill_y=fill[0], fill_u=fill[1], fill_v=fill[2])
+    if out_range:
+        g["out_range"] = out_range                     # (left out when 0 so the older fixtures keep their key lists)
     if pad:
         g.update(do_pad=1, pad_x=pad[0], pad_y=pad[1], out_w=pad[2], out_h=pad[3])
     return g
@@ -43,6 +45,7 @@ CASES = {
     "bilinear_half": geom(128, 72, 64, 36, alg=2),
     "precrop_scale": geom(100, 60, 128, 96, pre=(10, 6, 64, 32)),
     "identity": geom(64, 48, 64, 48),
+    "thumb_pad_jpeg_72x128": geom(72, 128, 101, 180, pad=(108, 0, 320, 180), out_range=1),   # ... then the mjpeg full-range pass
 }
 PATTERNS = ("random", "impulse", "zone")
 

@@ -37,6 +37,9 @@ CASES = [
     ("pad=640:480:-1:-1:color=white", 320, 240),      # pad only
     ("scale=iw/2:-2,pad=iw+20:ih+10:10:4:color=red", 200, 150),
     ("format=yuv420p", 64, 48),                        # identity
+    (THUMB_REF + ",format=yuvj420p", 720, 1280),       # video.js:329-334: the mjpeg encoder's full-range pass, borders included
+    ("scale=320:180,format=yuvj420p", 1280, 720),
+    ("format=yuvj420p", 64, 48),                       # range step alone
 ]
 
 

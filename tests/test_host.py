@@ -52,7 +52,11 @@ PARSE_CASES = [
     ("crop=in_w-21:in_h", 101, 60, dict(pre_w=80, pre_h=60, pre_x=10, out_w=80)),       # 10.5 -> lrint 10 -> even
     ("pad=640:480:-1:-1:color=white", 320, 240, dict(do_pad=1, pad_x=160, pad_y=120, fill_y=235, fill_u=128, fill_v=128)),
     ("format=yuv420p", 64, 48, dict(do_scale=0, do_pad=0, out_w=64, out_h=48)),
-    ("scale=64:48", 64, 48, dict(do_scale=0)),
+    ("scale=64:48", 64, 48, dict(do_scale=0, out_range=0)),
+    # video.js:329-334 writes a .jpg: the mjpeg encoder wants yuvj420p, i.e. one more (range) pass
+    ("scale=320x180:force_original_aspect_ratio=decrease,pad=320x180:-1:-1:color=black,format=yuv420p,format=yuvj420p", 720, 1280,
+     dict(sc_w=101, sc_h=180, do_pad=1, pad_x=108, out_range=1)),
+    ("format=pix_fmts=yuvj420p", 64, 48, dict(do_scale=0, out_range=1)),
 ]
 
 

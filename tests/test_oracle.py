@@ -102,3 +102,25 @@ def test_pad_places_picture_and_eats_odd_column(oracle):
     y, u, v = synth.split(out, 320, 180)
     assert (y[:, :108] == 16).all() and (y[:, 108:208] == 255).all() and (y[:, 208:] == 16).all()
     assert (u[:, :54] == 128).all() and (u[:, 54:104] == 255).all() and (u[:, 104:] == 128).all()
+
+
+def test_range_step_known_answers(oracle):
+    """limited -> full as the auto-inserted swscale pass does it: 16 -> 0, 235 -> 255 (luma); 128 stays, 16 -> 0,
+    240 -> 255 (chroma); values outside the nominal range clip; the map is monotone."""
+    import numpy as np
+    g = dict(in_w=256, in_h=2, pre_x=0, pre_y=0, pre_w=256, pre_h=2, do_scale=0, alg=0, sc_w=256, sc_h=2,
+             crop_x=0, crop_y=0, crop_w=256, crop_h=2, do_pad=0, pad_x=0, pad_y=0, out_w=256, out_h=2,
+             fill_y=16, fill_u=128, fill_v=128, out_range=1)
+    ramp = np.arange(256, dtype=np.uint8)
+    frame = np.concatenate([np.tile(ramp, 2), ramp[::2], ramp[1::2]])           # Y 256x2, U = even values, V = odd values
+    out = oracle.run_chain(g, frame[None])[0]
+    y, u, v = out[:256], out[512:640], out[640:768]
+    assert (y[16], y[235], y[0], y[255], y[126]) == (0, 255, 0, 255, 128)
+    c = np.empty(256, np.uint8); c[::2] = u; c[1::2] = v
+    assert (c[128], c[16], c[240], c[0], c[255]) == (128, 0, 255, 0, 255)
+    assert (np.diff(y.astype(int)) >= 0).all() and (np.diff(c.astype(int)) >= 0).all()
+    # and back: full -> limited lands inside the nominal range, 0 -> 16, 255 -> 235 / 240
+    g["out_range"] = 2
+    out = oracle.run_chain(g, frame[None])[0]
+    y, u, v = out[:256], out[512:640], out[640:768]
+    assert (y[0], y[255]) == (16, 235) and (u[0], v[-1]) == (16, 240)

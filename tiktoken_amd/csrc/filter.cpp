@@ -221,6 +221,7 @@ int check_geom(const tts_geom &g)
     if (g.sc_w < 1 || g.sc_h < 1 || g.sc_w > 16384 || g.sc_h > 16384) return TTS_ERR_INVALID_INPUT;
     if (!g.do_scale && (g.sc_w != g.pre_w || g.sc_h != g.pre_h)) return TTS_ERR_INVALID_INPUT;
     if (g.alg < TTS_ALG_BICUBIC || g.alg > TTS_ALG_BILINEAR) return TTS_ERR_INVALID_INPUT;
+    if (g.out_range < TTS_RANGE_KEEP || g.out_range > TTS_RANGE_TO_LIMITED) return TTS_ERR_INVALID_INPUT;
     if (g.crop_w < 1 || g.crop_h < 1 || g.crop_x < 0 || g.crop_y < 0 ||
         g.crop_x + g.crop_w > g.sc_w || g.crop_y + g.crop_h > g.sc_h) return TTS_ERR_INVALID_INPUT;
     const bool has_crop = g.crop_x || g.crop_y || g.crop_w != g.sc_w || g.crop_h != g.sc_h;
@@ -234,6 +235,19 @@ int check_geom(const tts_geom &g)
         return TTS_ERR_INVALID_INPUT;
     }
     return TTS_OK;
+}
+
+void build_range_lut(int out_range, bool chroma, unsigned char lut[256])
+{
+    for (int p = 0; p < 256; ++p) {
+        int v = p << 7;
+        if (out_range == TTS_RANGE_TO_FULL)
+            v = chroma ? (std::min(v, 30775) * 4663 - 9289992) >> 12 : (std::min(v, 30189) * 19077 - 39057361) >> 14;
+        else if (out_range == TTS_RANGE_TO_LIMITED)
+            v = chroma ? (v * 1799 + 4081085) >> 11 : (v * 14071 + 33561947) >> 14;
+        v = (v + 64) >> 7;
+        lut[p] = static_cast<unsigned char>(v < 0 ? 0 : v > 255 ? 255 : v);
+    }
 }
 
 }  // namespace tts

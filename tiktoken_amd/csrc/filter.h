@@ -26,6 +26,11 @@ int  crop_origin(int in, int out, double value, bool has_value);
 // Validate a resolved geometry; returns TTS_OK or an error.
 int  check_geom(const tts_geom &g);
 
+// Range step on a finished 8-bit plane as swscale's unscaled-size generic path computes it
+// (1-tap H pass: v = p << 7; lum/chrRangeToJpeg_c or ...FromJpeg_c on the 15-bit value; 1-tap V
+// pass: (v + 64) >> 7, clipped).  A function of one byte, so a 256-entry table per plane class.
+void build_range_lut(int out_range, bool chroma, unsigned char lut[256]);
+
 // "-vf" chain parser; err receives a one-line reason on failure.
 int  parse_vf(const char *vf, int iw, int ih, tts_geom &g, std::string &err);
 

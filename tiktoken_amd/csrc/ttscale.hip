@@ -695,6 +695,30 @@ __global__ __launch_bounds__(kBlock) void fill_kernel(const FillArgs a)
         if (!(in_rows && i >= a.px && i < a.px + a.pw)) row[i] = f;
 }
 
+// Range step (tts_geom.out_range): every byte of the finished canvas through a 256-entry table,
+// in place.  Thumbnail-sized work; four bytes per lane.
+struct RangeArgs {
+    uint8_t *dst;
+    int32_t w, h, stride;              // canvas of this plane class
+    int32_t planes, plane0;
+    uint32_t origin;                   // bytes from the canvas origin to the picture origin
+    FrameAddr addr;
+    uint8_t lut[256];
+};
+
+__global__ __launch_bounds__(kBlock) void range_kernel(const RangeArgs a)
+{
+    const int x  = (int(blockIdx.x) * 64 + int(threadIdx.x & 63)) * 4;
+    const int y  = int(blockIdx.y) * 4 + int(threadIdx.x >> 6);
+    const int fp = int(blockIdx.z);
+    if (x >= a.w || y >= a.h) return;
+    const int plane = a.plane0 + fp % a.planes, frame = fp / a.planes;
+    const uint32_t doff = (a.addr.use_table ? a.addr.dst_tab[plane][frame]
+                                            : uint32_t(frame) * a.addr.dst_pitch + a.addr.dst_plane[plane]) - a.origin;
+    uint8_t *row = a.dst + doff + size_t(y) * size_t(a.stride);
+    for (int i = x; i < min(x + 4, a.w); ++i) row[i] = a.lut[row[i]];
+}
+
 }  // namespace
 
 // ------------------------------------------------------------------------------------
@@ -1125,6 +1149,19 @@ int launch_all(const tts_plan *p, const uint8_t *src, uint8_t *dst, int n, const
         a.addr = addr;
         dim3 grid((c.ow + 63) / 64, (c.oh + 3) / 4, n * a.planes);
         hipLaunchKernelGGL(generic_kernel, grid, dim3(kBlock), 0, st, a);
+    }
+    if (p->g.out_range != TTS_RANGE_KEEP) {
+        for (int ci = 0; ci < 2; ++ci) {
+            const ClassPlan &c = p->cls[ci];
+            RangeArgs r{};
+            r.dst = dst; r.w = c.canvas_w; r.h = c.canvas_h; r.stride = dst_stride[ci];
+            r.planes = ci ? 2 : 1; r.plane0 = ci ? 1 : 0;
+            r.origin = uint32_t(c.pad_y) * uint32_t(dst_stride[ci]) + uint32_t(c.pad_x);
+            r.addr = addr;
+            tts::build_range_lut(p->g.out_range, ci != 0, r.lut);
+            dim3 grid((c.canvas_w + 255) / 256, (c.canvas_h + 3) / 4, n * r.planes);
+            hipLaunchKernelGGL(range_kernel, grid, dim3(kBlock), 0, st, r);
+        }
     }
     return hipGetLastError() == hipSuccess ? TTS_OK : TTS_ERR_PROCESSING_FAILED;
 }

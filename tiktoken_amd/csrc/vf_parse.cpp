@@ -262,8 +262,13 @@ int parse_vf(const char *vf, int iw, int ih, tts_geom &g, std::string &err)
             const std::string args = eq == std::string::npos ? "" : f.substr(eq + 1);
 
             if (name == "format" || name == "setsar") {
-                if (name == "format" && trim(args) != "yuv420p" && trim(args) != "pix_fmts=yuv420p") {
-                    err = "only format=yuv420p is supported"; return TTS_ERR_UNSUPPORTED;
+                if (name == "format") {
+                    std::string f = trim(args);
+                    if (f.rfind("pix_fmts=", 0) == 0) f = f.substr(9);
+                    // yuvj420p = the same planes in full range: the range step of a second, unscaled swscale pass
+                    if (f == "yuvj420p") g.out_range = TTS_RANGE_TO_FULL;
+                    else if (f == "yuv420p") g.out_range = TTS_RANGE_KEEP;
+                    else { err = "only format=yuv420p / yuvj420p is supported"; return TTS_ERR_UNSUPPORTED; }
                 }
                 continue;
             }
