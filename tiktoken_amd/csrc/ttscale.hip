@@ -781,8 +781,24 @@ int env_int(const char *name, int dflt)
 
 }  // namespace
 
+// Tuning / experiment knobs (environment), read ONCE when a plan is created so that tts_run*
+// never calls getenv.  Defaults are the product behaviour; tools/sweep.py sets them per plan.
+struct Knobs {
+    int strip_n = 8, strip_d = 0, paced = -1, lds_block = 0, no_merge = 0;
+    int exp_nosrc = 0, exp_nodst = 0, exp_srcpitch0 = 0, exp_dstpitch0 = 0, exp_stride0 = 0;
+    void read()
+    {
+        strip_n = env_int("TTS_STRIP_N", 8); strip_d = env_int("TTS_STRIP_D", 0);
+        paced = env_int("TTS_PACED", -1); lds_block = env_int("TTS_LDS_BLOCK", 0); no_merge = env_int("TTS_NO_MERGE", 0);
+        exp_nosrc = env_int("TTS_EXP_NOSRC", 0); exp_nodst = env_int("TTS_EXP_NODST", 0);
+        exp_srcpitch0 = env_int("TTS_EXP_SRCPITCH0", 0); exp_dstpitch0 = env_int("TTS_EXP_DSTPITCH0", 0);
+        exp_stride0 = env_int("TTS_EXP_STRIDE0", 0);
+    }
+};
+
 struct tts_plan {
     tts_geom g;
+    Knobs knobs;
     ClassPlan cls[2];
     uint32_t *d_tab = nullptr;        // strip tables of both classes
     int device = 0;
@@ -961,21 +977,21 @@ typedef void (*strip_fn)(const uint8_t *, uint8_t *, const uint32_t *, const Str
 // lds: LDS-DMAs per row of the LDS-staged kernel, 0 = register kernel; depth: its source rows in flight
 struct StripChoice { int LW, R, N; bool g4; int lds; int depth; };
 
-StripChoice strip_choice(const ClassPlan &c)
+StripChoice strip_choice(const ClassPlan &c, const Knobs &kn)
 {
     StripChoice ch{c.LW, c.R, 8, false, 0, 1};
-    if (c.LW == 4 && c.R == 4) ch.N = env_int("TTS_STRIP_N", 8) == 16 ? 16 : 8;
+    if (c.LW == 4 && c.R == 4) ch.N = kn.strip_n == 16 ? 16 : 8;
     const HTables &t = c.ht[ch.N == 16];
     ch.g4 = t.g4;
     ch.lds = t.g4 ? t.lds_g4 : t.lds_col;
     if (t.g4 && ch.lds != 1) { ch.lds = t.lds_col; if (ch.lds) ch.g4 = false; }   // grouped windows ride in one DMA only
-    if (ch.lds && ch.g4 && ch.R == 4) ch.depth = env_int("TTS_STRIP_D", 1) == 2 ? 2 : 1;
+    if (ch.lds && ch.g4 && ch.R == 4) ch.depth = kn.strip_d == 2 ? 2 : 1;
     return ch;
 }
 
-strip_fn pick_strip(const StripChoice &ch)
+strip_fn pick_strip(const StripChoice &ch, const Knobs &kn)
 {
-    const int D = env_int("TTS_STRIP_D", 0);          // rows in flight of the register kernels (tuning knob)
+    const int D = kn.strip_d;                          // rows in flight of the register kernels (tuning knob)
     if (ch.lds && ch.g4) {
         if (ch.R == 4) return ch.depth == 2 ? strip_lds_kernel<4, 4, true, 1, 2> : strip_lds_kernel<4, 4, true, 1, 1>;
         return ch.R == 6 ? strip_lds_kernel<4, 6, true, 1, 1> : strip_lds_kernel<4, 8, true, 1, 1>;
@@ -1010,7 +1026,7 @@ void fill_strip_class(const tts_plan *p, int ci, int n, int N, bool g4, int src_
     sc.strips = t.strips;
     sc.planes = ci ? 2 : 1; sc.plane0 = ci ? 1 : 0;
     sc.n_items = n * sc.planes * sc.strips;
-    sc.ow = c.ow; sc.oh = c.oh; sc.src_stride = env_int("TTS_EXP_STRIDE0", 0) ? 0 : src_stride; sc.dst_stride = dst_stride;
+    sc.ow = c.ow; sc.oh = c.oh; sc.src_stride = p->knobs.exp_stride0 ? 0 : src_stride; sc.dst_stride = dst_stride;
     sc.nblocks = uint32_t((sc.n_items + block - 1) / block) * uint32_t(st.nseg);
     sc.paced = paced;
 }
@@ -1048,8 +1064,8 @@ BlockShape block_shape(const tts_plan *p, int ci, const StripChoice &ch, int dst
     const int src_cols = c.h.pos[c.x0 + c.ow - 1] + c.h.size - c.h.pos[c.x0];
     const bool write_bound = 2.0 * c.ow * c.oh >= 3.0 * src_rows * src_cols;     // writes >= 60 % of the traffic
     int paced = misaligned && write_bound;
-    paced = env_int("TTS_PACED", paced);
-    int t = env_int("TTS_LDS_BLOCK", paced ? kMaxLdsBlock : kBlock);
+    if (p->knobs.paced >= 0) paced = p->knobs.paced;
+    int t = p->knobs.lds_block > 0 ? p->knobs.lds_block : paced ? kMaxLdsBlock : kBlock;
     t = std::min(std::max(t / 64 * 64, 64), kMaxLdsBlock);
     return {t, size_t(t / 64) * ch.depth * (size_t(ch.lds) * 1024 + 16), paced};
 }
@@ -1102,8 +1118,8 @@ int launch_all(const tts_plan *p, const uint8_t *src, uint8_t *dst, int n, const
     int strip_cls[2], ns = 0;
     for (int ci = 0; ci < 2; ++ci) if (p->cls[ci].kind == 1) strip_cls[ns++] = ci;
     bool merged = false;
-    if (ns == 2 && !env_int("TTS_NO_MERGE", 0)) {
-        const StripChoice a0 = strip_choice(p->cls[0]), a1 = strip_choice(p->cls[1]);
+    if (ns == 2 && !p->knobs.no_merge) {
+        const StripChoice a0 = strip_choice(p->cls[0], p->knobs), a1 = strip_choice(p->cls[1], p->knobs);
         merged = a0.LW == a1.LW && a0.R == a1.R && a0.N == a1.N && a0.g4 == a1.g4 && a0.lds == a1.lds && a0.depth == a1.depth;
     }
     for (int k = 0; k < ns; ++k) {
@@ -1111,13 +1127,13 @@ int launch_all(const tts_plan *p, const uint8_t *src, uint8_t *dst, int n, const
         a.src_span = src_span; a.dst_span = dst_span; a.addr = addr;
         // timing experiments (outputs are wrong): a zero-record descriptor makes the range check drop that
         // buffer's traffic while the instruction stream stays
-        if (env_int("TTS_EXP_NOSRC", 0)) a.src_span = 0;
-        if (env_int("TTS_EXP_SRCPITCH0", 0)) a.addr.src_pitch = 0;    // every frame reads frame 0: source stays in L2
-        if (env_int("TTS_EXP_DSTPITCH0", 0)) a.addr.dst_pitch = 0;    // every frame writes frame 0: output stays in L2
-        if (env_int("TTS_EXP_NODST", 0)) a.dst_span = 0;
+        if (p->knobs.exp_nosrc) a.src_span = 0;
+        if (p->knobs.exp_srcpitch0) a.addr.src_pitch = 0;    // every frame reads frame 0: source stays in L2
+        if (p->knobs.exp_dstpitch0) a.addr.dst_pitch = 0;    // every frame writes frame 0: output stays in L2
+        if (p->knobs.exp_nodst) a.dst_span = 0;
         const int ci = strip_cls[k];
-        const StripChoice ch = strip_choice(p->cls[ci]);
-        strip_fn fn = pick_strip(ch);
+        const StripChoice ch = strip_choice(p->cls[ci], p->knobs);
+        strip_fn fn = pick_strip(ch, p->knobs);
         if (!fn) return TTS_ERR_UNSUPPORTED;
         size_t si[2];
         const BlockShape bs = block_shape(p, ci, ch, dst_stride[ci]);
@@ -1197,6 +1213,7 @@ int tts_plan_create(const tts_geom *g, tts_plan **out)
     tts_plan *p = new (std::nothrow) tts_plan();
     if (!p) return TTS_ERR_INITIALIZATION_FAILED;
     p->g = *g; p->device = dev;
+    p->knobs.read();
     int cus = 0;
     if (hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) == hipSuccess && cus > 0) p->n_cus = cus;
     std::vector<uint32_t> tab;
