@@ -66,3 +66,83 @@ ffmpeg(%r).inputSize(480, 854)
     assert r.returncode == 0 and "END" in r.stdout, r.stdout + r.stderr
     got = np.frombuffer((tmp_path / "out.yuv").read_bytes(), np.uint8).reshape(2, -1)
     assert np.array_equal(got, oracle.run_chain(tts.parse_vf("scale=w=720:h=1280", 480, 854), src))
+
+
+@needs_node
+def test_video_processor_contract_without_gpu(tts):
+    """web/src/tests/video/compression.test.js:52-90 and portrait.test.js:70-97,133-147: error names,
+    9:16 -> `scale=720:1280`, anything else -> the `min()` / `decrease` chain."""
+    js = """
+const {videoProcessor: v, VIDEO_CONSTANTS: C} = require(%r);
+const out = {};
+out.portrait = v.scaleFilter({width: 1080, height: 1920});
+out.square = v.scaleFilter({width: 1080, height: 1080});
+out.tall = v.scaleFilter({width: 720, height: 2560});
+out.valid = v.validatePortraitMode({width: 720, height: 1280}).isValid;
+try { v.validatePortraitMode({}); } catch (e) { out.meta = e.message; }
+Promise.all([
+  v.compress(null).catch((e) => e.message),
+  v.compress(undefined).catch((e) => e.message),
+  v.compress({type: 'video/webm', width: 8, height: 8, data: Buffer.alloc(96)}).catch((e) => e.message),
+  v.compress({type: 'video/mp4', width: 8, height: 8, data: Buffer.alloc(95)}).catch((e) => e.message),
+]).then((errs) => { out.errs = errs; console.log(JSON.stringify(out)); });
+""" % os.path.join(ROOT, "js", "videoProcessor.js")
+    out = json.loads(subprocess.run([NODE, "-e", js], capture_output=True, text=True, check=True).stdout)
+    assert out["portrait"] == "scale=720:1280"
+    assert "force_original_aspect_ratio=decrease" in out["square"] and "min(720" in out["square"]
+    assert "min(1280" in out["tall"]
+    assert out["valid"] is True and out["meta"] == "Invalid video metadata"
+    assert [e.split(":")[0] for e in out["errs"]] == ["INVALID_INPUT", "INVALID_INPUT", "INVALID_FORMAT", "INVALID_INPUT"]
+    # the chains it emits resolve to what the web spec asks for
+    assert tts.parse_vf(out["square"], 1080, 1080).as_dict()["out_w"] == 720
+    g = tts.parse_vf(out["tall"], 720, 2560).as_dict()
+    assert (g["out_w"], g["out_h"]) == (360, 1280)
+
+
+@pytest.mark.gpu
+@needs_node
+def test_video_processor_compress_pixels(tts, oracle, tmp_path):
+    src = synth.frames("random", 360, 640, 2)
+    (tmp_path / "in.yuv").write_bytes(src.tobytes())
+    js = """
+const fs = require('fs');
+const {videoProcessor: v} = require(%r);
+const seen = [];
+v.compress({type: 'video/mp4', width: 360, height: 640, data: fs.readFileSync(%r)}, {onProgress: (p) => seen.push(p)})
+  .then((r) => { fs.writeFileSync(%r, r.data); console.log(JSON.stringify({w: r.width, h: r.height, vf: r.vf, seen})); });
+""" % (os.path.join(ROOT, "js", "videoProcessor.js"), str(tmp_path / "in.yuv"), str(tmp_path / "out.yuv"))
+    r = json.loads(subprocess.run([NODE, "-e", js], capture_output=True, text=True, check=True).stdout)
+    assert (r["w"], r["h"], r["vf"], r["seen"]) == (720, 1280, "scale=720:1280", [0, 100])
+    got = np.frombuffer((tmp_path / "out.yuv").read_bytes(), np.uint8).reshape(2, -1)
+    assert np.array_equal(got, oracle.run_chain(tts.parse_vf("scale=720:1280", 360, 640), src))
+
+
+@pytest.mark.gpu
+@needs_node
+def test_process_clips_batch_driver(tts, oracle, tmp_path):
+    """js/processClips.js on a two-clip manifest shaped like VIDEOS_TO_FIX (scripts/processVideos.js:25-48):
+    a small clip is resized to 720x1280 and trimmed, a large one is only trimmed; the report has the
+    reference's {codec, resolution, duration} fields (:141-145)."""
+    small = synth.frames("random", 360, 640, 6)
+    large = synth.frames("zone", 720, 1280, 4)
+    (tmp_path / "small.yuv").write_bytes(small.tobytes())
+    (tmp_path / "large.yuv").write_bytes(large.tobytes())
+    manifest = {
+        "small.yuv": {"width": 360, "height": 640, "fps": 2, "issues": ["resolution", "duration"], "targetDuration": 2,
+                      "trimStart": 1, "newName": "forest_demo.yuv"},
+        "large.yuv": {"width": 720, "height": 1280, "fps": 2, "issues": ["resolution", "duration"], "targetDuration": 1,
+                      "newName": "birds_demo.yuv"},
+        "missing.yuv": {"width": 8, "height": 8, "issues": []},
+    }
+    (tmp_path / "manifest.json").write_text(json.dumps(manifest))
+    r = subprocess.run([NODE, os.path.join(ROOT, "js", "processClips.js"), str(tmp_path / "manifest.json")],
+                       capture_output=True, text=True)
+    assert r.returncode == 0, r.stderr
+    rep = json.loads(r.stdout)
+    assert rep["small.yuv"] == {"codec": "rawvideo", "resolution": "720x1280", "duration": "2.000000"}
+    assert rep["large.yuv"] == {"codec": "rawvideo", "resolution": "720x1280", "duration": "1.000000"}
+    assert "error" in rep["missing.yuv"]
+    got = np.frombuffer((tmp_path / "processed" / "forest_demo.yuv").read_bytes(), np.uint8).reshape(4, -1)
+    assert np.array_equal(got, oracle.run_chain(tts.parse_vf("scale=w=720:h=1280", 360, 640), small[2:6]))
+    got = np.frombuffer((tmp_path / "processed" / "birds_demo.yuv").read_bytes(), np.uint8).reshape(2, -1)
+    assert np.array_equal(got, large[:2])
