@@ -68,7 +68,7 @@ def main():
         dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
 
     plan = tts.Plan.from_vf(VF, IN_W, IN_H)
-    assert plan.kernel_kind(0) == 1 and plan.kernel_kind(1) == 1, "hot path must use the strip kernel"
+    assert plan.kernel_kind(0) == 2 and plan.kernel_kind(1) == 2, "hot path must use the LDS-staged strip kernel"
     n = args.frames
     gen = torch.Generator(device="cuda").manual_seed(0x5EED + rank)
     src = torch.randint(0, 256, (n, plan.in_bytes), dtype=torch.uint8, device="cuda", generator=gen)

@@ -120,7 +120,8 @@ int tts_plan_filter(const tts_plan *p, int plane_class, int axis,
  */
 int tts_build_filter(int src, int dst, int one, int alg, int *taps, int16_t *coef, int32_t *pos);
 
-/* Which kernel family the plan dispatches to for a plane class: 0 = generic, 1 = strip. */
+/* Which kernel the plan dispatches to for a plane class: 0 = generic, 1 = strip walk with register
+ * gathers, 2 / 3 = LDS-staged strip walk with one / two LDS-DMAs per source row. */
 int tts_plan_kernel_kind(const tts_plan *p, int plane_class);
 
 size_t tts_frame_bytes(int w, int h);          /* packed I420 size of a w x h frame */

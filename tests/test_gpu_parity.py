@@ -82,7 +82,7 @@ def test_generic_and_strip_kernels_agree(tts, oracle, monkeypatch):
     import torch
     src = synth.frames("random", 320, 180, 2)
     plan = tts.Plan.from_vf("scale=568:320", 320, 180)
-    assert plan.kernel_kind(0) == 1 and plan.kernel_kind(1) == 1
+    assert plan.kernel_kind(0) >= 1 and plan.kernel_kind(1) >= 1
     a = plan.run_batch(torch.from_numpy(src).cuda()).cpu().numpy()
     monkeypatch.setenv("TTS_FORCE_GENERIC", "1")
     plan2 = tts.Plan.from_vf("scale=568:320", 320, 180)
@@ -232,3 +232,44 @@ def test_clip_shard_runner(tts, oracle):
         g = tts.parse_vf(vf, c.width, c.height)
         want = int(oracle.run_chain(g, synth.frames("random", c.width, c.height, c.frames)).astype(np.int64).sum())
         assert sums[c.name] == want
+
+
+# The LDS-staged kernel's own corner cases: (chain, iw, ih, frames, expected kernel kind of the luma class).
+# kind: 1 = register strip walk, 2 / 3 = LDS-staged with one / two DMAs per source row (include/ttscale.h).
+LDS_CASES = [
+    ("scale=136:96", 100, 60, 70, 2),                      # 17 strips per row: a wave wraps over 4-5 plane rows (pieces)
+    ("scale=24:40", 18, 30, 300, 1),                       # 3 strips per luma row: 22 pieces per wave -> register walk
+    ("scale=72:40", 54, 30, 100, 2),                       # 9 strips per luma row: 8 pieces per wave, the most the LDS walk takes
+    ("scale=16:16", 12, 12, 500, None),                    # 2 luma strips, 1 chroma strip per row: too many pieces -> register walk
+    ("scale=320:568:flags=area", 1080, 1920, 3, 3),        # 5-tap per-column windows, 40 strips per row, 1.1 KB runs: two DMAs
+    ("scale=256:144:flags=area", 960, 540, 9, 3),          # 3.75x area: source run of a wave needs two DMAs
+    ("scale=200:112:flags=area", 1400, 784, 5, 1),         # 7x area: run does not fit two DMAs -> register walk
+    ("scale=3413:1920,crop=1080:1920", 3840, 2160, 1, 2),  # 6-tap bicubic downscale, 8-byte windows
+    ("scale=1080:1920:force_original_aspect_ratio=increase,crop=1024:1920", 1920, 1080, 2, 2),   # aligned rows: unpaced
+    ("scale=1080:1920:force_original_aspect_ratio=increase,crop=1080:1920", 1920, 1080, 9, 2),   # paced, 1024-thread workgroups
+    ("scale=1080:1920:force_original_aspect_ratio=increase,crop=1080:1920,pad=1200:2000:60:40", 1280, 720, 2, 2),  # paced into a padded canvas
+]
+
+
+@pytest.mark.parametrize("vf,iw,ih,n,kind", LDS_CASES)
+def test_lds_kernel_variants(tts, oracle, vf, iw, ih, n, kind):
+    import torch
+    plan = tts.Plan.from_vf(vf, iw, ih)
+    if kind is not None:
+        assert plan.kernel_kind(0) == kind, "luma class runs kernel kind %d, expected %d" % (plan.kernel_kind(0), kind)
+    src = synth.frames("random", iw, ih, n)
+    got = plan.run_batch(torch.from_numpy(src).cuda()).cpu().numpy()
+    want = oracle.run_chain(plan.geom, src)
+    assert np.array_equal(got, want)
+
+
+@pytest.mark.parametrize("knob,val", [("TTS_PACED", "1"), ("TTS_PACED", "0"), ("TTS_LDS_BLOCK", "64"), ("TTS_LDS_BLOCK", "704"),
+                                      ("TTS_STRIP_D", "2"), ("TTS_NO_LDS", "1"), ("TTS_NO_G4", "1"), ("TTS_NO_MERGE", "1")])
+def test_tuning_knobs_do_not_change_pixels(tts, oracle, monkeypatch, knob, val):
+    import torch
+    monkeypatch.setenv(knob, val)
+    for vf, iw, ih in (("scale=355:267", 200, 150), ("scale=120:90:flags=area", 200, 150), ("scale=136:96", 100, 60)):
+        plan = tts.Plan.from_vf(vf, iw, ih)
+        src = synth.frames("random", iw, ih, 21)
+        got = plan.run_batch(torch.from_numpy(src).cuda()).cpu().numpy()
+        assert np.array_equal(got, oracle.run_chain(plan.geom, src)), (knob, val, vf)

@@ -464,6 +464,10 @@ __global__ __launch_bounds__(kMaxLdsBlock, (G4 && R == 4) ? 8 : 4) void strip_ld
     const uint32_t first = off[0], last = off[NW - 1] + kWin;          // this lane's bytes: [first, last)
     const bool restart = lane > 0 && strip == 0 && live;               // a new plane row begins at this lane
     uint64_t pm = __builtin_amdgcn_ballot_w64(restart) | 1ull;
+    const int rstart = int(uni(tab[c.seginfo + 2 * seg]));
+    const int nrows  = int(uni(tab[c.seginfo + 2 * seg + 1]));
+    const int src_stride = int(uni(uint32_t(c.src_stride)));
+    const uint32_t max_rowoff = uint32_t(rstart + nrows - 1) * uint32_t(src_stride);
     uint32_t csrc[NDMA];
     uint32_t lbase = 0, prefix = 0;
 #pragma unroll
@@ -472,9 +476,14 @@ __global__ __launch_bounds__(kMaxLdsBlock, (G4 && R == 4) ? 8 : 4) void strip_ld
         const int l0 = __builtin_ctzll(pm);
         pm &= pm - 1;
         const int l1 = pm ? __builtin_ctzll(pm) : 64;
-        const uint32_t start = uint32_t(__builtin_amdgcn_readlane(int(first), l0)) & ~15u;
+        uint32_t start = uint32_t(__builtin_amdgcn_readlane(int(first), l0)) & ~15u;
         const uint32_t end   = uint32_t(__builtin_amdgcn_readlane(int(last), l1 - 1));
         const uint32_t n     = (end - start + 15u) >> 4;
+        // The run is rounded out to whole chunks, so its last chunk may reach past the piece's last
+        // byte.  Past the END OF THE BUFFER that must not happen: the range check zero-fills whole
+        // dwords, including one that straddles the end and still holds needed bytes.  Such a piece
+        // (the last plane rows of the launch) is right-aligned instead: it ends exactly at `end`.
+        if (start + 16u * n + max_rowoff > a.src_span && end >= 16u * n) start = end - 16u * n;
         if (lane >= l0 && lane < l1) lbase = 16u * prefix - start;
 #pragma unroll
         for (int d = 0; d < NDMA; ++d) {
@@ -509,14 +518,12 @@ __global__ __launch_bounds__(kMaxLdsBlock, (G4 && R == 4) ? 8 : 4) void strip_ld
 #pragma unroll
         for (int k = 0; k < R / 2; ++k) ring[i][k] = 0;
 
-    const int rstart = int(uni(tab[c.seginfo + 2 * seg]));
-    const int nrows  = int(uni(tab[c.seginfo + 2 * seg + 1]));
     const uint32_t *emit = tab + c.emit + seg * c.maxrows;
     const uint32_t *vco  = tab + c.vcoef;
     int y = seg * c.seg_rows;                                  // (the host picks this kernel only if ow >= N: no ragged strips)
     // class fields used inside the loop, read once (the asm statements below clobber "memory", which
     // would otherwise make the compiler reload them from the kernel arguments every row)
-    const int src_stride = int(uni(uint32_t(c.src_stride))), dst_stride = int(uni(uint32_t(c.dst_stride)));
+    const int dst_stride = int(uni(uint32_t(c.dst_stride)));
     const int last_y = c.oh - 1;
     const bool bar = c.paced != 0;
 
@@ -1132,7 +1139,8 @@ int launch_all(const tts_plan *p, const uint8_t *src, uint8_t *dst, int n, const
         if (p->knobs.exp_dstpitch0) a.addr.dst_pitch = 0;    // every frame writes frame 0: output stays in L2
         if (p->knobs.exp_nodst) a.dst_span = 0;
         const int ci = strip_cls[k];
-        const StripChoice ch = strip_choice(p->cls[ci], p->knobs);
+        StripChoice ch = strip_choice(p->cls[ci], p->knobs);
+        if (src_span < 4096u) { ch.lds = 0; ch.depth = 1; }     // (a right-aligned run must not start before the buffer)
         strip_fn fn = pick_strip(ch, p->knobs);
         if (!fn) return TTS_ERR_UNSUPPORTED;
         size_t si[2];
@@ -1268,7 +1276,9 @@ int tts_build_filter(int src, int dst, int one, int alg, int *taps, int16_t *coe
 int tts_plan_kernel_kind(const tts_plan *p, int plane_class)
 {
     if (!p || plane_class < 0 || plane_class > 1) return TTS_ERR_INVALID_INPUT;
-    return p->cls[plane_class].kind;
+    const ClassPlan &c = p->cls[plane_class];
+    if (c.kind == 0) return 0;
+    return 1 + strip_choice(c, p->knobs).lds;
 }
 
 size_t tts_frame_bytes(int w, int h)

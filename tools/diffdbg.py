@@ -21,3 +21,9 @@ for f in range(n):
                 f, name, bad.sum(), cols[0], cols[-1], cols.size, cols[:24].tolist(), rows[0], rows[-1], rows.size))
         else:
             print("frame %d plane %s ok" % (f, name))
+if len(sys.argv) > 5:
+    f = n - 1
+    g, w = synth.split(got[f], ow, oh)[2], synth.split(want[f], ow, oh)[2]
+    print("got V tail:\n", g[-6:, -10:]); print("want V tail:\n", w[-6:, -10:])
+    s = synth.split(src[f], iw, ih)[2]
+    print("src V tail:\n", s[-4:, -10:])
