@@ -103,11 +103,18 @@ def test_row_segmentation_is_invisible(tts, oracle, monkeypatch, seg):
         assert np.array_equal(got, oracle.run_chain(plan.geom, src))
 
 
-def test_frame_pointer_api_matches_batch_api(tts, oracle):
-    """tts_run with per-frame plane pointers and padded strides == tts_run_batch."""
+@pytest.mark.parametrize("vf,iw,ih,n,pad", [
+    ("scale=284:160", 160, 90, 5, True),
+    ("scale=284:160", 160, 90, 40, False),       # more than one launch group (32 frames each), tight strides
+    ("scale=136:96", 100, 60, 40, False),        # rows of 100 / 50 bytes: the runs of the LDS walk must stay inside each plane
+    ("scale=72:40", 54, 30, 33, False),          # planes of a single short segment -> register walk in pointer mode
+    ("scale=640:360:flags=area", 1283, 721, 3, False),
+])
+def test_frame_pointer_api_matches_batch_api(tts, oracle, vf, iw, ih, n, pad):
+    """tts_run with per-frame plane pointers (every plane its own allocation, padded or tight strides)
+    == the oracle."""
     import torch
-    iw, ih, n = 160, 90, 5
-    plan = tts.Plan.from_vf("scale=284:160", iw, ih)
+    plan = tts.Plan.from_vf(vf, iw, ih)
     ow, oh = plan.out_size
     src = synth.frames("random", iw, ih, n)
     want = oracle.run_chain(plan.geom, src)
@@ -116,7 +123,7 @@ def test_frame_pointer_api_matches_batch_api(tts, oracle):
         y, u, v = synth.split(src[i], iw, ih)
         planes, strides = [], []
         for k, pl in enumerate((y, u, v)):
-            stride = pl.shape[1] + (24 if k == 0 else 8)
+            stride = pl.shape[1] + ((24 if k == 0 else 8) if pad else 0)
             t = torch.zeros((pl.shape[0], stride), dtype=torch.uint8, device="cuda")
             t[:, : pl.shape[1]] = torch.from_numpy(np.ascontiguousarray(pl)).cuda()
             keep.append(t); planes.append(t.data_ptr()); strides.append(stride)
@@ -124,7 +131,7 @@ def test_frame_pointer_api_matches_batch_api(tts, oracle):
         outs, ostr = [], []
         for k in range(3):
             w_, h_ = (ow, oh) if k == 0 else ((ow + 1) // 2, (oh + 1) // 2)
-            stride = w_ + 16
+            stride = w_ + (16 if pad else 0)
             t = torch.full((h_, stride), 7, dtype=torch.uint8, device="cuda")
             keep.append(t); outs.append(t); ostr.append(stride)
         dp.append(outs); ds.append(ostr)

@@ -71,6 +71,8 @@ struct StripClass {
     int32_t  ow, oh, src_stride, dst_stride;
     uint32_t nblocks;              // workgroups of this class in the launch
     int32_t  paced;                // LDS-staged kernel: strip-major workgroup order + barrier before every row's store
+    uint32_t src_begin_rel;        // bytes from a plane's first byte to its (pre-cropped) origin
+    uint32_t src_end_rel;          // bytes from a plane's (pre-cropped) origin to one past its last byte
 };
 
 struct StripArgs {
@@ -467,6 +469,7 @@ __global__ __launch_bounds__(kMaxLdsBlock, (G4 && R == 4) ? 8 : 4) void strip_ld
     const int rstart = int(uni(tab[c.seginfo + 2 * seg]));
     const int nrows  = int(uni(tab[c.seginfo + 2 * seg + 1]));
     const int src_stride = int(uni(uint32_t(c.src_stride)));
+    const uint32_t min_rowoff = uint32_t(rstart) * uint32_t(src_stride);
     const uint32_t max_rowoff = uint32_t(rstart + nrows - 1) * uint32_t(src_stride);
     uint32_t csrc[NDMA];
     uint32_t lbase = 0, prefix = 0;
@@ -476,14 +479,24 @@ __global__ __launch_bounds__(kMaxLdsBlock, (G4 && R == 4) ? 8 : 4) void strip_ld
         const int l0 = __builtin_ctzll(pm);
         pm &= pm - 1;
         const int l1 = pm ? __builtin_ctzll(pm) : 64;
+        // Where may this piece's run lie?  Its chunk grid is the same for every source row of the
+        // segment, rows differ by the scalar row offset only.  The run is rounded out to whole
+        // chunks; rounding into a neighbouring row of the same plane is harmless, rounding out of
+        // the PLANE is not: with per-frame plane pointers those bytes may not be mapped, and at the
+        // end of a launch's span the range check zero-fills whole dwords, one that straddles the end
+        // and still holds needed bytes included.  So: start on a 16-byte boundary unless that falls
+        // before the plane (pointer mode; in packed batches the bytes before a plane are the previous
+        // plane), and if the last chunk would pass the plane's end on the segment's last row, slide
+        // the run down so that it ends exactly on the piece's last byte.  (A segment holding BOTH the
+        // first and the last row of a narrow plane can satisfy only one end; the host never sends
+        // such a segment here in pointer mode, and in a packed batch the lower end gives way.)
+        const uint32_t porg = uint32_t(__builtin_amdgcn_readlane(int(soff), l0));
+        const uint32_t lo_abs = a.addr.use_table ? porg - c.src_begin_rel : 0u, hi_abs = porg + c.src_end_rel;
+        const uint32_t end = uint32_t(__builtin_amdgcn_readlane(int(last), l1 - 1));
         uint32_t start = uint32_t(__builtin_amdgcn_readlane(int(first), l0)) & ~15u;
-        const uint32_t end   = uint32_t(__builtin_amdgcn_readlane(int(last), l1 - 1));
-        const uint32_t n     = (end - start + 15u) >> 4;
-        // The run is rounded out to whole chunks, so its last chunk may reach past the piece's last
-        // byte.  Past the END OF THE BUFFER that must not happen: the range check zero-fills whole
-        // dwords, including one that straddles the end and still holds needed bytes.  Such a piece
-        // (the last plane rows of the launch) is right-aligned instead: it ends exactly at `end`.
-        if (start + 16u * n + max_rowoff > a.src_span && end >= 16u * n) start = end - 16u * n;
+        if (start + min_rowoff < lo_abs) start = lo_abs - min_rowoff;
+        const uint32_t n = (end - start + 15u) >> 4;
+        if (start + 16u * n + max_rowoff > hi_abs && end >= 16u * n && end - 16u * n + min_rowoff >= lo_abs) start = end - 16u * n;
         if (lane >= l0 && lane < l1) lbase = 16u * prefix - start;
 #pragma unroll
         for (int d = 0; d < NDMA; ++d) {
@@ -1023,7 +1036,7 @@ strip_fn pick_strip(const StripChoice &ch, const Knobs &kn)
 }
 
 void fill_strip_class(const tts_plan *p, int ci, int n, int N, bool g4, int src_stride, int dst_stride,
-                      const SegTables &st, int block, int paced, StripClass &sc)
+                      const SegTables &st, int block, int paced, int planes, int plane0, StripClass &sc)
 {
     const ClassPlan &c = p->cls[ci];
     const HTables &t = c.ht[N == 16];
@@ -1031,11 +1044,17 @@ void fill_strip_class(const tts_plan *p, int ci, int n, int N, bool g4, int src_
     sc.seginfo = st.seginfo; sc.emit = st.emit; sc.vcoef = st.vcoef;
     sc.maxrows = st.maxrows; sc.nseg = st.nseg; sc.seg_rows = st.seg_rows;
     sc.strips = t.strips;
-    sc.planes = ci ? 2 : 1; sc.plane0 = ci ? 1 : 0;
+    sc.planes = planes; sc.plane0 = plane0;
     sc.n_items = n * sc.planes * sc.strips;
     sc.ow = c.ow; sc.oh = c.oh; sc.src_stride = p->knobs.exp_stride0 ? 0 : src_stride; sc.dst_stride = dst_stride;
     sc.nblocks = uint32_t((sc.n_items + block - 1) / block) * uint32_t(st.nseg);
     sc.paced = paced;
+    {   // the source plane of this class, seen from the pre-cropped origin the frame offsets point at
+        const int sub = ci ? 1 : 0;
+        const int plane_w = ceil_shift(p->g.in_w, sub), plane_h = ceil_shift(p->g.in_h, sub);
+        sc.src_begin_rel = uint32_t(p->g.pre_y >> sub) * uint32_t(src_stride) + uint32_t(p->g.pre_x >> sub);
+        sc.src_end_rel = uint32_t(plane_h - (p->g.pre_y >> sub) - 1) * uint32_t(src_stride) + uint32_t(plane_w - (p->g.pre_x >> sub));
+    }
 }
 
 // Resident workgroups per CU of a strip kernel (VGPR- and LDS-limited); asked once per kernel.
@@ -1082,7 +1101,7 @@ BlockShape block_shape(const tts_plan *p, int ci, const StripChoice &ch, int dst
 // keep the tail short when the last ones drain.  Measured on MI355X the time is flat from 64 to 96
 // rows once there are >= ~3 workgroups per resident slot, so: the longest segment <= 96 rows that
 // still leaves that many workgroups, else the shortest on offer.
-void choose_segs(const tts_plan *p, const int *cis, int ncls, int n, int N, strip_fn fn, const BlockShape &bs, size_t out_idx[2])
+void choose_segs(const tts_plan *p, const int *cis, int ncls, int n, int N, strip_fn fn, const BlockShape &bs, int min_segs, size_t out_idx[2])
 {
     out_idx[0] = out_idx[1] = 0;
     const size_t nopt = p->cls[cis[0]].segs.size();
@@ -1099,20 +1118,32 @@ void choose_segs(const tts_plan *p, const int *cis, int ncls, int n, int N, stri
         }
         if (i == 0 || blocks >= (bs.paced ? 2.0 : 3.0) * slots) best = i;   // (paced workgroups are 4x as large)
     }
+    for (bool ok = false; !ok && best > 0; ) {         // pointer mode + LDS-staged kernel: at least min_segs segments per plane
+        ok = true;
+        for (int k = 0; k < ncls; ++k) ok &= p->cls[cis[k]].segs[best].nseg >= min_segs;
+        if (!ok) --best;
+    }
     out_idx[0] = out_idx[1] = best;
 }
 
 // One launch set: frames [0, n) addressed by `addr` relative to (src, dst).
+// `only_plane` >= 0 restricts the launch set to that one plane (per-frame pointers whose planes lie
+// too far apart for one base + 32-bit offsets are processed plane by plane).
 int launch_all(const tts_plan *p, const uint8_t *src, uint8_t *dst, int n, const int src_stride[2],
-               const int dst_stride[2], uint32_t src_span, uint32_t dst_span, const FrameAddr &addr, hipStream_t st)
+               const int dst_stride[2], uint32_t src_span, uint32_t dst_span, const FrameAddr &addr, hipStream_t st,
+               int only_plane = -1)
 {
+    auto active  = [&](int ci) { return only_plane < 0 || ci == (only_plane ? 1 : 0); };
+    auto nplanes = [&](int ci) { return only_plane < 0 ? (ci ? 2 : 1) : 1; };
+    auto plane0  = [&](int ci) { return only_plane < 0 ? (ci ? 1 : 0) : only_plane; };
     if (p->g.do_pad) {
         for (int ci = 0; ci < 2; ++ci) {
+            if (!active(ci)) continue;
             const ClassPlan &c = p->cls[ci];
             FillArgs f{};
             f.dst = dst; f.w = c.canvas_w; f.h = c.canvas_h; f.stride = dst_stride[ci];
             f.px = c.pad_x; f.py = c.pad_y; f.pw = c.ow; f.ph = c.oh;
-            f.planes = ci ? 2 : 1; f.plane0 = ci ? 1 : 0;
+            f.planes = nplanes(ci); f.plane0 = plane0(ci);
             f.fill[0] = p->g.fill_y; f.fill[1] = p->g.fill_u; f.fill[2] = p->g.fill_v;
             f.origin = uint32_t(c.pad_y) * uint32_t(dst_stride[ci]) + uint32_t(c.pad_x);
             f.addr = addr;
@@ -1123,7 +1154,7 @@ int launch_all(const tts_plan *p, const uint8_t *src, uint8_t *dst, int n, const
 
     // strip classes: one launch when both classes run the same instantiation, else one each
     int strip_cls[2], ns = 0;
-    for (int ci = 0; ci < 2; ++ci) if (p->cls[ci].kind == 1) strip_cls[ns++] = ci;
+    for (int ci = 0; ci < 2; ++ci) if (p->cls[ci].kind == 1 && active(ci)) strip_cls[ns++] = ci;
     bool merged = false;
     if (ns == 2 && !p->knobs.no_merge) {
         const StripChoice a0 = strip_choice(p->cls[0], p->knobs), a1 = strip_choice(p->cls[1], p->knobs);
@@ -1140,19 +1171,25 @@ int launch_all(const tts_plan *p, const uint8_t *src, uint8_t *dst, int n, const
         if (p->knobs.exp_nodst) a.dst_span = 0;
         const int ci = strip_cls[k];
         StripChoice ch = strip_choice(p->cls[ci], p->knobs);
-        if (src_span < 4096u) { ch.lds = 0; ch.depth = 1; }     // (a right-aligned run must not start before the buffer)
+        // Per-frame plane pointers: a segment of the LDS-staged kernel must not hold both the first and
+        // the last source row of a plane (see the kernel), so planes shorter than two of the shortest
+        // segments take the register kernel; taller ones are cut into at least two segments below.
+        bool short_plane = false;
+        for (int j = 0; j < ns; ++j) short_plane |= p->cls[strip_cls[j]].oh <= p->cls[strip_cls[j]].segs[0].seg_rows;
+        if (src_span < 4096u || (addr.use_table && short_plane)) { ch.lds = 0; ch.depth = 1; }
         strip_fn fn = pick_strip(ch, p->knobs);
         if (!fn) return TTS_ERR_UNSUPPORTED;
         size_t si[2];
         const BlockShape bs = block_shape(p, ci, ch, dst_stride[ci]);
+        const int min_segs = addr.use_table && ch.lds ? 2 : 1;
         if (merged) {
-            choose_segs(p, strip_cls, 2, n, ch.N, fn, bs, si);
+            choose_segs(p, strip_cls, 2, n, ch.N, fn, bs, min_segs, si);
             for (int j = 0; j < 2; ++j)
-                fill_strip_class(p, j, n, ch.N, ch.g4, src_stride[j], dst_stride[j], p->cls[j].segs[si[j]], bs.threads, bs.paced, a.c[j]);
+                fill_strip_class(p, j, n, ch.N, ch.g4, src_stride[j], dst_stride[j], p->cls[j].segs[si[j]], bs.threads, bs.paced, nplanes(j), plane0(j), a.c[j]);
         } else {
             // a single class rides in slot 0; slot 1 is empty
-            choose_segs(p, &ci, 1, n, ch.N, fn, bs, si);
-            fill_strip_class(p, ci, n, ch.N, ch.g4, src_stride[ci], dst_stride[ci], p->cls[ci].segs[si[0]], bs.threads, bs.paced, a.c[0]);
+            choose_segs(p, &ci, 1, n, ch.N, fn, bs, min_segs, si);
+            fill_strip_class(p, ci, n, ch.N, ch.g4, src_stride[ci], dst_stride[ci], p->cls[ci].segs[si[0]], bs.threads, bs.paced, nplanes(ci), plane0(ci), a.c[0]);
             a.c[1] = a.c[0]; a.c[1].nblocks = 0;
         }
         const uint32_t blocks = a.c[0].nblocks + (merged ? a.c[1].nblocks : 0);
@@ -1162,24 +1199,25 @@ int launch_all(const tts_plan *p, const uint8_t *src, uint8_t *dst, int n, const
 
     for (int ci = 0; ci < 2; ++ci) {
         const ClassPlan &c = p->cls[ci];
-        if (c.kind != 0) continue;
+        if (c.kind != 0 || !active(ci)) continue;
         GenericArgs a{};
         a.src = src; a.dst = dst;
         a.hpos = c.d_hpos; a.htaps = c.d_htaps; a.vpos = c.d_vpos; a.vtaps = c.d_vtaps;
         a.ht = c.h.size; a.vt = c.v.size;
         a.x0 = c.x0; a.y0 = c.y0; a.ow = c.ow; a.oh = c.oh;
         a.src_stride = src_stride[ci]; a.dst_stride = dst_stride[ci];
-        a.planes = ci ? 2 : 1; a.plane0 = ci ? 1 : 0;
+        a.planes = nplanes(ci); a.plane0 = plane0(ci);
         a.addr = addr;
         dim3 grid((c.ow + 63) / 64, (c.oh + 3) / 4, n * a.planes);
         hipLaunchKernelGGL(generic_kernel, grid, dim3(kBlock), 0, st, a);
     }
     if (p->g.out_range != TTS_RANGE_KEEP) {
         for (int ci = 0; ci < 2; ++ci) {
+            if (!active(ci)) continue;
             const ClassPlan &c = p->cls[ci];
             RangeArgs r{};
             r.dst = dst; r.w = c.canvas_w; r.h = c.canvas_h; r.stride = dst_stride[ci];
-            r.planes = ci ? 2 : 1; r.plane0 = ci ? 1 : 0;
+            r.planes = nplanes(ci); r.plane0 = plane0(ci);
             r.origin = uint32_t(c.pad_y) * uint32_t(dst_stride[ci]) + uint32_t(c.pad_x);
             r.addr = addr;
             tts::build_range_lut(p->g.out_range, ci != 0, r.lut);
@@ -1342,51 +1380,59 @@ int tts_run(const tts_plan *p, const tts_frame *src, const tts_frame *dst, int n
         if (src[i].stride[1] != src[i].stride[2] || dst[i].stride[1] != dst[i].stride[2]) return TTS_ERR_UNSUPPORTED;
     }
     hipStream_t st = static_cast<hipStream_t>(hip_stream);
-    int f0 = 0;
-    while (f0 < n_frames) {
-        // group consecutive frames with equal strides whose planes lie within 4 GiB of a common base
-        uintptr_t smin = UINTPTR_MAX, dmin = UINTPTR_MAX, smax = 0, dmax = 0;
-        int n = 0;
-        while (f0 + n < n_frames && n < kMaxTableFrames) {
-            const tts_frame &s = src[f0 + n], &d = dst[f0 + n];
-            if (n && (s.stride[0] != src[f0].stride[0] || s.stride[1] != src[f0].stride[1] ||
-                      d.stride[0] != dst[f0].stride[0] || d.stride[1] != dst[f0].stride[1])) break;
-            uintptr_t a = smin, b = smax, c2 = dmin, e = dmax;     // [min start, max end) over the group's planes
-            for (int k = 0; k < 3; ++k) {
-                const int ci = k ? 1 : 0;
-                const size_t sext = size_t(s.stride[k]) * (ceil_shift(g.in_h, ci) - 1) + ceil_shift(g.in_w, ci);
-                const size_t dext = size_t(d.stride[k]) * (ceil_shift(g.out_h, ci) - 1) + ceil_shift(g.out_w, ci);
-                a = std::min(a, uintptr_t(s.plane[k])); b = std::max(b, uintptr_t(s.plane[k]) + sext);
-                c2 = std::min(c2, uintptr_t(d.plane[k])); e = std::max(e, uintptr_t(d.plane[k]) + dext);
+    // Frames are grouped so that every plane of a group lies within kMaxSpan of a common base (32-bit
+    // lane offsets).  `only` < 0: the three planes of a frame share the base (one launch set for the
+    // group); `only` = k: plane k alone -- the fallback for frames whose planes lie further apart
+    // (each plane its own far-away allocation).
+    auto run_groups = [&](int first, int count, int only) -> int {
+        const int k0 = only < 0 ? 0 : only, k1 = only < 0 ? 3 : only + 1;
+        int f0 = first;
+        while (f0 < first + count) {
+            uintptr_t smin = UINTPTR_MAX, dmin = UINTPTR_MAX, smax = 0, dmax = 0;   // [min start, max end) over the group's planes
+            int n = 0;
+            while (f0 + n < first + count && n < kMaxTableFrames) {
+                const tts_frame &s = src[f0 + n], &d = dst[f0 + n];
+                if (n && (s.stride[0] != src[f0].stride[0] || s.stride[1] != src[f0].stride[1] ||
+                          d.stride[0] != dst[f0].stride[0] || d.stride[1] != dst[f0].stride[1])) break;
+                uintptr_t a = smin, b = smax, c2 = dmin, e = dmax;
+                for (int k = k0; k < k1; ++k) {
+                    const int ci = k ? 1 : 0;
+                    const size_t sext = size_t(s.stride[k]) * (ceil_shift(g.in_h, ci) - 1) + ceil_shift(g.in_w, ci);
+                    const size_t dext = size_t(d.stride[k]) * (ceil_shift(g.out_h, ci) - 1) + ceil_shift(g.out_w, ci);
+                    a = std::min(a, uintptr_t(s.plane[k])); b = std::max(b, uintptr_t(s.plane[k]) + sext);
+                    c2 = std::min(c2, uintptr_t(d.plane[k])); e = std::max(e, uintptr_t(d.plane[k]) + dext);
+                }
+                if (b - a > kMaxSpan || e - c2 > kMaxSpan) break;
+                smin = a; smax = b; dmin = c2; dmax = e;
+                ++n;
             }
-            if (b - a > kMaxSpan || e - c2 > kMaxSpan) {
-                if (n) break;
-                return TTS_ERR_UNSUPPORTED;             // one frame whose planes lie further apart than 32-bit offsets reach
-            }
-            smin = a; smax = b; dmin = c2; dmax = e;
-            ++n;
+            if (n == 0) return TTS_ERR_UNSUPPORTED;     // this frame does not fit one base (caller falls back or gives up)
+            FrameAddr addr{};
+            addr.use_table = 1;
+            const int sstride[2] = {src[f0].stride[0], src[f0].stride[1]};
+            const int dstride[2] = {dst[f0].stride[0], dst[f0].stride[1]};
+            for (int i = 0; i < n; ++i)
+                for (int k = k0; k < k1; ++k) {
+                    const int ci = k ? 1 : 0;
+                    const ClassPlan &c = p->cls[ci];
+                    const size_t so = size_t(uintptr_t(src[f0 + i].plane[k]) - smin), dof = size_t(uintptr_t(dst[f0 + i].plane[k]) - dmin);
+                    addr.src_tab[k][i] = uint32_t(so) + uint32_t(g.pre_y >> ci) * sstride[ci] + uint32_t(g.pre_x >> ci);
+                    addr.dst_tab[k][i] = uint32_t(dof) + uint32_t(c.pad_y) * dstride[ci] + uint32_t(c.pad_x);
+                }
+            const int rc = launch_all(p, reinterpret_cast<const uint8_t *>(smin), reinterpret_cast<uint8_t *>(dmin), n,
+                                      sstride, dstride, uint32_t(smax - smin), uint32_t(dmax - dmin), addr, st, only);
+            if (rc) return rc;
+            f0 += n;
         }
-        FrameAddr addr{};
-        addr.use_table = 1;
-        const int sstride[2] = {src[f0].stride[0], src[f0].stride[1]};
-        const int dstride[2] = {dst[f0].stride[0], dst[f0].stride[1]};
-        size_t sspan = 0, dspan = 0;    // bytes reachable from the common bases: furthest plane end of the group
-        for (int i = 0; i < n; ++i)
-            for (int k = 0; k < 3; ++k) {
-                const int ci = k ? 1 : 0;
-                const ClassPlan &c = p->cls[ci];
-                const size_t so = size_t(uintptr_t(src[f0 + i].plane[k]) - smin), dof = size_t(uintptr_t(dst[f0 + i].plane[k]) - dmin);
-                addr.src_tab[k][i] = uint32_t(so) + uint32_t(g.pre_y >> ci) * sstride[ci] + uint32_t(g.pre_x >> ci);
-                addr.dst_tab[k][i] = uint32_t(dof) + uint32_t(c.pad_y) * dstride[ci] + uint32_t(c.pad_x);
-                sspan = std::max(sspan, so + size_t(sstride[ci]) * (ceil_shift(g.in_h, ci) - 1) + ceil_shift(g.in_w, ci));
-                dspan = std::max(dspan, dof + size_t(dstride[ci]) * (ceil_shift(g.out_h, ci) - 1) + ceil_shift(g.out_w, ci));
-            }
-        const int rc = launch_all(p, reinterpret_cast<const uint8_t *>(smin), reinterpret_cast<uint8_t *>(dmin), n,
-                                  sstride, dstride, uint32_t(sspan), uint32_t(dspan), addr, st);
-        if (rc) return rc;
-        f0 += n;
+        return TTS_OK;
+    };
+    int rc = run_groups(0, n_frames, -1);
+    if (rc == TTS_ERR_UNSUPPORTED) {
+        // some frame's planes are spread over more than kMaxSpan: go plane by plane (a repeat of the
+        // frames already done above is harmless -- same inputs, same outputs)
+        for (int k = 0; k < 3 && (rc == TTS_ERR_UNSUPPORTED || rc == TTS_OK); ++k) rc = run_groups(0, n_frames, k);
     }
-    return TTS_OK;
+    return rc;
 }
 
 int tts_run_host(const tts_plan *p, const void *src, void *dst, int n_frames)
