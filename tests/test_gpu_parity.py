@@ -280,3 +280,40 @@ def test_tuning_knobs_do_not_change_pixels(tts, oracle, monkeypatch, knob, val):
         src = synth.frames("random", iw, ih, 21)
         got = plan.run_batch(torch.from_numpy(src).cuda()).cpu().numpy()
         assert np.array_equal(got, oracle.run_chain(plan.geom, src)), (knob, val, vf)
+
+
+def test_pointer_api_shuffled_placements(tts, oracle):
+    """tts_run again, many times, with the planes (each its own allocation) landing at different
+    addresses and in different orders: results must not depend on where a plane lies, what lies
+    behind it, or which plane ends the launch's span."""
+    import random
+    import torch
+    iw, ih, n = 1283, 721, 3
+    plan = tts.Plan.from_vf("scale=640:360:flags=area", iw, ih)
+    ow, oh = plan.out_size
+    src = synth.frames("random", iw, ih, n)
+    want = oracle.run_chain(plan.geom, src)
+    rng = random.Random(7)
+    for rep in range(25):
+        keep = [torch.full((rng.randrange(1, 3000) * 512,), 0xAB, dtype=torch.uint8, device="cuda") for _ in range(rng.randrange(0, 6))]
+        slots = {}
+        order = list(range(n))
+        rng.shuffle(order)
+        for i in order:
+            planes, strides, outs, ostr = [], [], [], []
+            for pl in synth.split(src[i], iw, ih):
+                t = torch.from_numpy(np.ascontiguousarray(pl)).cuda()
+                keep.append(t); planes.append(t.data_ptr()); strides.append(pl.shape[1])
+                if rng.random() < 0.3:
+                    keep.append(torch.full((rng.randrange(1, 64) * 512,), 0xCD, dtype=torch.uint8, device="cuda"))
+            for k in range(3):
+                w_, h_ = (ow, oh) if k == 0 else ((ow + 1) // 2, (oh + 1) // 2)
+                t = torch.full((h_, w_), 7, dtype=torch.uint8, device="cuda")
+                keep.append(t); outs.append(t); ostr.append(w_)
+            slots[i] = (planes, strides, outs, ostr)
+        sp, ss, dp, ds = ([slots[i][j] for i in range(n)] for j in range(4))
+        plan.run_frames(sp, [[t.data_ptr() for t in o] for o in dp], ss, ds)
+        torch.cuda.synchronize()
+        for i in range(n):
+            for k, w in enumerate(synth.split(want[i], ow, oh)):
+                assert np.array_equal(dp[i][k].cpu().numpy(), w), "rep %d frame %d plane %d" % (rep, i, k)

@@ -399,7 +399,7 @@ template <int LW, int R, bool G4, int NDMA, int D>
 __global__ __launch_bounds__(kMaxLdsBlock, (G4 && R == 4) ? 8 : 4) void strip_lds_kernel(const uint8_t *__restrict__ src, uint8_t *__restrict__ dst,
                                                                                const uint32_t *__restrict__ tab, const StripArgs a)
 {
-    static_assert(R % 2 == 0 && (LW == 4 || LW == 8) && (!G4 || LW == 4) && (NDMA == 1 || NDMA == 2), "see strip_kernel");
+    static_assert(R % 2 == 0 && (LW == 4 || LW == 6 || LW == 8) && (!G4 || LW == 4) && (NDMA == 1 || NDMA == 2), "see strip_kernel");
     static_assert(D >= 1 && R % D == 0, "D source rows in flight, one LDS slot each, rotating with the ring");
 #if defined(__HIP_DEVICE_COMPILE__)   // the LDS-DMA builtin exists in the device pass only
     constexpr int N = 8;
@@ -474,7 +474,7 @@ __global__ __launch_bounds__(kMaxLdsBlock, (G4 && R == 4) ? 8 : 4) void strip_ld
     uint32_t csrc[NDMA];
     uint32_t lbase = 0, prefix = 0;
 #pragma unroll
-    for (int d = 0; d < NDMA; ++d) csrc[d] = uni(first) & ~15u;       // spare lanes re-fetch the first chunk
+    for (int d = 0; d < NDMA; ++d) csrc[d] = ~0u;                     // spare lanes: set below to the first piece's first chunk
     for (int p = 0; p < kMaxPieces && pm; ++p) {
         const int l0 = __builtin_ctzll(pm);
         pm &= pm - 1;
@@ -498,6 +498,10 @@ __global__ __launch_bounds__(kMaxLdsBlock, (G4 && R == 4) ? 8 : 4) void strip_ld
         const uint32_t n = (end - start + 15u) >> 4;
         if (start + 16u * n + max_rowoff > hi_abs && end >= 16u * n && end - 16u * n + min_rowoff >= lo_abs) start = end - 16u * n;
         if (lane >= l0 && lane < l1) lbase = 16u * prefix - start;
+        if (p == 0) {
+#pragma unroll
+            for (int d = 0; d < NDMA; ++d) csrc[d] = start;
+        }
 #pragma unroll
         for (int d = 0; d < NDMA; ++d) {
             const uint32_t ch = uint32_t(lane) + 64u * d;
@@ -573,7 +577,7 @@ __global__ __launch_bounds__(kMaxLdsBlock, (G4 && R == 4) ? 8 : 4) void strip_ld
             uint32_t wk[NW][3];                                 // the aligned dwords holding each window
             if constexpr (G4) {
                 TTS_LDS_READ_WIN3_X2(wk, lpos, (s % D) * kSlotBytes);
-            } else if constexpr (LW == 8) {
+            } else if constexpr (LW > 4) {
                 static_assert(G4 || D == 1, "per-column readers address slot 0 only");
                 Win3 wv[NW];
                 lds_read_win3(wv, lpos);
@@ -605,10 +609,8 @@ __global__ __launch_bounds__(kMaxLdsBlock, (G4 && R == 4) ? 8 : 4) void strip_ld
                     acc = dot2(__builtin_amdgcn_perm(wk[i / 4][1], wk[i / 4][0], sel[i][1]), hc[i][1], acc);
                 } else {
 #pragma unroll
-                    for (int q = 0; q < LW / 4; ++q) {          // taps 4q .. 4q+3 start at byte o of dwords q, q+1
-                        acc = dot2(__builtin_amdgcn_perm(wk[i][q + 1], wk[i][q], psel[i][0]), hc[i][2 * q], acc);
-                        acc = dot2(__builtin_amdgcn_perm(wk[i][q + 1], wk[i][q], psel[i][1]), hc[i][2 * q + 1], acc);
-                    }
+                    for (int tp = 0; tp < LW / 2; ++tp)         // taps 2tp, 2tp+1 sit at bytes o + 2 (tp % 2) of dwords tp / 2, tp / 2 + 1
+                        acc = dot2(__builtin_amdgcn_perm(wk[i][tp / 2 + 1], wk[i][tp / 2], psel[i][tp % 2]), hc[i][tp], acc);
                 }
                 const uint32_t t = hfinish(acc);
                 ring[i][s / 2] = (s & 1) ? __builtin_amdgcn_perm(t, ring[i][s / 2], 0x05040100)
@@ -764,6 +766,7 @@ struct HTables {
     uint32_t hoff4 = 0, hsel4 = 0, hcoef4 = 0;
     int lds_g4 = 0, lds_col = 0;                   // LDS-staged kernel: 1 KiB DMAs per row it needs with grouped /
                                                    // per-column windows (0 = not usable)
+    uint32_t hoff6 = 0, hcoef6 = 0;                // 5-6 taps: 6-byte windows for the LDS-staged kernel (3 tap pairs a column)
 };
 
 struct ClassPlan {
@@ -775,6 +778,7 @@ struct ClassPlan {
     int pad_x = 0, pad_y = 0;
     int kind = 0;                      // 0 generic, 1 strip
     int LW = 0, R = 0;
+    int LWlds = 0;                     // window width of the LDS-staged kernel's per-column mode (6 when 5-6 taps)
     HTables ht[2];                     // horizontal tables for N = 8 and N = 16 columns per lane
     std::vector<SegTables> segs;
     // generic tables
@@ -806,6 +810,7 @@ int env_int(const char *name, int dflt)
 struct Knobs {
     int strip_n = 8, strip_d = 0, paced = -1, lds_block = 0, no_merge = 0;
     int exp_nosrc = 0, exp_nodst = 0, exp_srcpitch0 = 0, exp_dstpitch0 = 0, exp_stride0 = 0;
+    int planewise = 0;                // tts_run: always take the plane-by-plane path (test knob)
     void read()
     {
         strip_n = env_int("TTS_STRIP_N", 8); strip_d = env_int("TTS_STRIP_D", 0);
@@ -813,6 +818,7 @@ struct Knobs {
         exp_nosrc = env_int("TTS_EXP_NOSRC", 0); exp_nodst = env_int("TTS_EXP_NODST", 0);
         exp_srcpitch0 = env_int("TTS_EXP_SRCPITCH0", 0); exp_dstpitch0 = env_int("TTS_EXP_DSTPITCH0", 0);
         exp_stride0 = env_int("TTS_EXP_STRIDE0", 0);
+        planewise = env_int("TTS_PLANEWISE", 0);
     }
 };
 
@@ -969,12 +975,30 @@ int build_class(const tts_geom &g, int sub, ClassPlan &c, std::vector<uint32_t> 
         }
         t.lds_g4 = lds_dmas(c, t, N, glo.data(), NL, 8);
     }
+    c.LWlds = LW == 8 && HT <= 6 && c.src_w >= 6 ? 6 : LW;
     for (int v = 0; v < 2; ++v) {
         HTables &t = c.ht[v];
         const int N = v ? 16 : 8;
-        std::vector<int> lo(size_t(t.strips) * N);
-        for (size_t i = 0; i < lo.size(); ++i) lo[i] = int(tab[t.hoff + i]);
-        t.lds_col = lds_dmas(c, t, N, lo.data(), N, LW);
+        const int ncols = t.strips * N;
+        std::vector<int> lo(static_cast<size_t>(ncols));
+        if (c.LWlds == 6) {
+            auto column = [&](int i) { return c.x0 + std::min(std::min((i / N) * N, std::max(c.ow - N, 0)) + i % N, c.ow - 1); };
+            t.hoff6 = uint32_t(tab.size());
+            tab.resize(tab.size() + ncols);
+            t.hcoef6 = uint32_t(tab.size());
+            tab.resize(tab.size() + size_t(ncols) * 3, 0);
+            for (int i = 0; i < ncols; ++i) {
+                const int vx = column(i), pos = c.h.pos[vx];
+                lo[i] = std::min(pos, c.src_w - 6);
+                int16_t slot[6] = {0, 0, 0, 0, 0, 0};
+                for (int j = 0; j < HT; ++j) slot[pos - lo[i] + j] = c.h.taps[size_t(vx) * HT + j];
+                tab[t.hoff6 + i] = uint32_t(lo[i]);
+                for (int k = 0; k < 3; ++k) tab[t.hcoef6 + size_t(i) * 3 + k] = pack16(slot[2 * k], slot[2 * k + 1]);
+            }
+        } else {
+            for (int i = 0; i < ncols; ++i) lo[i] = int(tab[t.hoff + i]);
+        }
+        t.lds_col = lds_dmas(c, t, N, lo.data(), N, c.LWlds);
     }
     std::vector<int> opts(kSegOptions, kSegOptions + kNumSegOptions);
     const int forced = env_int("TTS_SEG_ROWS", 0);
@@ -1005,6 +1029,7 @@ StripChoice strip_choice(const ClassPlan &c, const Knobs &kn)
     ch.g4 = t.g4;
     ch.lds = t.g4 ? t.lds_g4 : t.lds_col;
     if (t.g4 && ch.lds != 1) { ch.lds = t.lds_col; if (ch.lds) ch.g4 = false; }   // grouped windows ride in one DMA only
+    if (ch.lds && !ch.g4) ch.LW = c.LWlds;
     if (ch.lds && ch.g4 && ch.R == 4) ch.depth = kn.strip_d == 2 ? 2 : 1;
     return ch;
 }
@@ -1019,6 +1044,7 @@ strip_fn pick_strip(const StripChoice &ch, const Knobs &kn)
     if (ch.lds) {
 #define TTS_LDS_PICK(LW_, R_) (ch.lds == 1 ? strip_lds_kernel<LW_, R_, false, 1, 1> : strip_lds_kernel<LW_, R_, false, 2, 1>)
         if (ch.LW == 4) return ch.R == 4 ? TTS_LDS_PICK(4, 4) : ch.R == 6 ? TTS_LDS_PICK(4, 6) : TTS_LDS_PICK(4, 8);
+        if (ch.LW == 6) return ch.R == 4 ? TTS_LDS_PICK(6, 4) : ch.R == 6 ? TTS_LDS_PICK(6, 6) : TTS_LDS_PICK(6, 8);
         return ch.R == 4 ? TTS_LDS_PICK(8, 4) : ch.R == 6 ? TTS_LDS_PICK(8, 6) : TTS_LDS_PICK(8, 8);
 #undef TTS_LDS_PICK
     }
@@ -1035,12 +1061,13 @@ strip_fn pick_strip(const StripChoice &ch, const Knobs &kn)
     return nullptr;
 }
 
-void fill_strip_class(const tts_plan *p, int ci, int n, int N, bool g4, int src_stride, int dst_stride,
+void fill_strip_class(const tts_plan *p, int ci, int n, int N, bool g4, int lw, int src_stride, int dst_stride,
                       const SegTables &st, int block, int paced, int planes, int plane0, StripClass &sc)
 {
     const ClassPlan &c = p->cls[ci];
     const HTables &t = c.ht[N == 16];
     sc.hoff = g4 ? t.hoff4 : t.hoff; sc.hcoef = g4 ? t.hcoef4 : t.hcoef; sc.hsel = t.hsel4;
+    if (!g4 && lw == 6) { sc.hoff = t.hoff6; sc.hcoef = t.hcoef6; }
     sc.seginfo = st.seginfo; sc.emit = st.emit; sc.vcoef = st.vcoef;
     sc.maxrows = st.maxrows; sc.nseg = st.nseg; sc.seg_rows = st.seg_rows;
     sc.strips = t.strips;
@@ -1176,7 +1203,7 @@ int launch_all(const tts_plan *p, const uint8_t *src, uint8_t *dst, int n, const
         // segments take the register kernel; taller ones are cut into at least two segments below.
         bool short_plane = false;
         for (int j = 0; j < ns; ++j) short_plane |= p->cls[strip_cls[j]].oh <= p->cls[strip_cls[j]].segs[0].seg_rows;
-        if (src_span < 4096u || (addr.use_table && short_plane)) { ch.lds = 0; ch.depth = 1; }
+        if (src_span < 4096u || (addr.use_table && short_plane)) { ch.lds = 0; ch.depth = 1; ch.LW = p->cls[ci].LW; }
         strip_fn fn = pick_strip(ch, p->knobs);
         if (!fn) return TTS_ERR_UNSUPPORTED;
         size_t si[2];
@@ -1185,11 +1212,11 @@ int launch_all(const tts_plan *p, const uint8_t *src, uint8_t *dst, int n, const
         if (merged) {
             choose_segs(p, strip_cls, 2, n, ch.N, fn, bs, min_segs, si);
             for (int j = 0; j < 2; ++j)
-                fill_strip_class(p, j, n, ch.N, ch.g4, src_stride[j], dst_stride[j], p->cls[j].segs[si[j]], bs.threads, bs.paced, nplanes(j), plane0(j), a.c[j]);
+                fill_strip_class(p, j, n, ch.N, ch.g4, ch.LW, src_stride[j], dst_stride[j], p->cls[j].segs[si[j]], bs.threads, bs.paced, nplanes(j), plane0(j), a.c[j]);
         } else {
             // a single class rides in slot 0; slot 1 is empty
             choose_segs(p, &ci, 1, n, ch.N, fn, bs, min_segs, si);
-            fill_strip_class(p, ci, n, ch.N, ch.g4, src_stride[ci], dst_stride[ci], p->cls[ci].segs[si[0]], bs.threads, bs.paced, nplanes(ci), plane0(ci), a.c[0]);
+            fill_strip_class(p, ci, n, ch.N, ch.g4, ch.LW, src_stride[ci], dst_stride[ci], p->cls[ci].segs[si[0]], bs.threads, bs.paced, nplanes(ci), plane0(ci), a.c[0]);
             a.c[1] = a.c[0]; a.c[1].nblocks = 0;
         }
         const uint32_t blocks = a.c[0].nblocks + (merged ? a.c[1].nblocks : 0);
@@ -1426,7 +1453,7 @@ int tts_run(const tts_plan *p, const tts_frame *src, const tts_frame *dst, int n
         }
         return TTS_OK;
     };
-    int rc = run_groups(0, n_frames, -1);
+    int rc = p->knobs.planewise ? TTS_ERR_UNSUPPORTED : run_groups(0, n_frames, -1);
     if (rc == TTS_ERR_UNSUPPORTED) {
         // some frame's planes are spread over more than kMaxSpan: go plane by plane (a repeat of the
         // frames already done above is harmless -- same inputs, same outputs)
