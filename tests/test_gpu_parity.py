@@ -23,6 +23,8 @@ CASES = [
     (PORTRAIT, 1920, 1080),                            # BASELINE configs[1]
     (PORTRAIT, 1280, 720),
     (PORTRAIT, 3840, 2160),
+    (PORTRAIT, 7680, 4320),                            # 8K: 10 taps per axis -> generic kernel
+    ("scale=3840:2160", 1920, 1080),                   # 1080p -> 4K: the largest output here (12.4 MB a frame)
     ("scale=320:568:flags=area", 1080, 1920),          # BASELINE configs[2]
     ("scale=160:284:flags=area", 1080, 1920),
     ("scale=640:360:flags=bilinear", 1280, 720),
@@ -109,11 +111,20 @@ def test_row_segmentation_is_invisible(tts, oracle, monkeypatch, seg):
     ("scale=136:96", 100, 60, 40, False),        # rows of 100 / 50 bytes: the runs of the LDS walk must stay inside each plane
     ("scale=72:40", 54, 30, 33, False),          # planes of a single short segment -> register walk in pointer mode
     ("scale=640:360:flags=area", 1283, 721, 3, False),
+    # plane-by-plane launches (what tts_run falls back to when a frame's planes lie > 4 GiB apart), down
+    # to ONE plane per launch: the plane then starts at offset 0 and ends the span
+    ("scale=640:360:flags=area", 1283, 721, 1, "planewise"),
+    ("scale=136:96", 100, 60, 1, "planewise"),
+    ("scale=355:267", 200, 150, 2, "planewise"),
+    ("scale=1080:1920:force_original_aspect_ratio=increase,crop=1080:1920", 1280, 720, 1, "planewise"),
 ])
-def test_frame_pointer_api_matches_batch_api(tts, oracle, vf, iw, ih, n, pad):
+def test_frame_pointer_api_matches_batch_api(tts, oracle, monkeypatch, vf, iw, ih, n, pad):
     """tts_run with per-frame plane pointers (every plane its own allocation, padded or tight strides)
     == the oracle."""
     import torch
+    if pad == "planewise":
+        monkeypatch.setenv("TTS_PLANEWISE", "1")
+        pad = False
     plan = tts.Plan.from_vf(vf, iw, ih)
     ow, oh = plan.out_size
     src = synth.frames("random", iw, ih, n)
@@ -141,7 +152,13 @@ def test_frame_pointer_api_matches_batch_api(tts, oracle, vf, iw, ih, n, pad):
         wy, wu, wv = synth.split(want[i], ow, oh)
         for k, wpl in enumerate((wy, wu, wv)):
             got = dp[i][k].cpu().numpy()
-            assert np.array_equal(got[:, : wpl.shape[1]], wpl)
+            bad = got[:, : wpl.shape[1]] != wpl
+            if bad.any():
+                ys, xs = np.nonzero(bad)
+                ends = sorted((sp[f][q] + ss[f][q] * ((ih if q == 0 else (ih + 1) // 2) - 1) + (iw if q == 0 else (iw + 1) // 2), f, q)
+                              for f in range(n) for q in range(3))
+                raise AssertionError("frame %d plane %d: %d bad, rows %d..%d cols %d..%d; src planes %s; highest end: frame %d plane %d" % (
+                    i, k, bad.sum(), ys.min(), ys.max(), xs.min(), xs.max(), [[hex(p) for p in f] for f in sp], ends[-1][1], ends[-1][2]))
             assert (got[:, wpl.shape[1]:] == 7).all(), "wrote into the stride padding"
 
 

@@ -463,14 +463,16 @@ __global__ __launch_bounds__(kMaxLdsBlock, (G4 && R == 4) ? 8 : 4) void strip_ld
     // bytes [start, end) rounded out to 16-byte chunks, and takes the next n chunks of the slot;
     // chunk c of the slot is fetched by lane c % 64 of DMA c / 64.
     constexpr uint32_t kWin = G4 ? 8u : uint32_t(LW);
-    const uint32_t first = off[0], last = off[NW - 1] + kWin;          // this lane's bytes: [first, last)
+    // (all run addresses below are those of the segment's FIRST source row, `rstart`: the DMAs add
+    // (row - rstart) * stride as their scalar offset, so nothing here can be "negative")
     const bool restart = lane > 0 && strip == 0 && live;               // a new plane row begins at this lane
     uint64_t pm = __builtin_amdgcn_ballot_w64(restart) | 1ull;
     const int rstart = int(uni(tab[c.seginfo + 2 * seg]));
     const int nrows  = int(uni(tab[c.seginfo + 2 * seg + 1]));
     const int src_stride = int(uni(uint32_t(c.src_stride)));
-    const uint32_t min_rowoff = uint32_t(rstart) * uint32_t(src_stride);
-    const uint32_t max_rowoff = uint32_t(rstart + nrows - 1) * uint32_t(src_stride);
+    const uint32_t row0_off = uint32_t(rstart) * uint32_t(src_stride);
+    const uint32_t last_rowoff = uint32_t(nrows - 1) * uint32_t(src_stride);      // last row of the segment, relative to its first
+    const uint32_t first = off[0] + row0_off, last = off[NW - 1] + kWin + row0_off;   // this lane's bytes in row `rstart`: [first, last)
     uint32_t csrc[NDMA];
     uint32_t lbase = 0, prefix = 0;
 #pragma unroll
@@ -498,9 +500,9 @@ __global__ __launch_bounds__(kMaxLdsBlock, (G4 && R == 4) ? 8 : 4) void strip_ld
         const uint32_t lo_abs = a.addr.use_table ? porg - c.src_begin_rel : 0u, hi_abs = porg + c.src_end_rel;
         const uint32_t end = uint32_t(__builtin_amdgcn_readlane(int(last), l1 - 1));
         uint32_t start = uint32_t(__builtin_amdgcn_readlane(int(first), l0)) & ~15u;
-        if (start + min_rowoff < lo_abs) start = lo_abs - min_rowoff;
+        if (start < lo_abs) start = lo_abs;
         const uint32_t n = (end - start + 15u) >> 4;
-        if (start + 16u * n + max_rowoff > hi_abs && end >= 16u * n && end - 16u * n + min_rowoff >= lo_abs) start = end - 16u * n;
+        if (start + 16u * n + last_rowoff > hi_abs && end >= lo_abs + 16u * n) start = end - 16u * n;
         if (lane >= l0 && lane < l1) lbase = 16u * prefix - start;
         if (p == 0) {
 #pragma unroll
@@ -523,7 +525,7 @@ __global__ __launch_bounds__(kMaxLdsBlock, (G4 && R == 4) ? 8 : 4) void strip_ld
     uint32_t psel[G4 ? 1 : N][2];                    // per-column windows: the phase folded into v_perm selectors
 #pragma unroll
     for (int j = 0; j < NW; ++j) {
-        const uint32_t pos = off[j] + lbase + lds_wave;
+        const uint32_t pos = off[j] + row0_off + lbase + lds_wave;
         lpos[j] = pos & ~3u;
         if constexpr (G4) phase[j] = pos;
         else {
@@ -557,7 +559,7 @@ __global__ __launch_bounds__(kMaxLdsBlock, (G4 && R == 4) ? 8 : 4) void strip_ld
 #pragma unroll
         for (int d = 0; d < NDMA; ++d)
             __builtin_amdgcn_raw_ptr_buffer_load_lds(srs, (lds_void_t *)&lds[wave][r][d * 1024], 16, csrc[d],
-                                                     (rstart + min(r, nrows - 1)) * src_stride, 0, 0);
+                                                     min(r, nrows - 1) * src_stride, 0, 0);
     int cnt_next = int(uni(emit[0]));
     uint32_t vk_next[R / 2];                       // vertical taps of the next output row, requested a row ahead
 #pragma unroll
@@ -604,7 +606,7 @@ __global__ __launch_bounds__(kMaxLdsBlock, (G4 && R == 4) ? 8 : 4) void strip_ld
 #pragma unroll
             for (int d = 0; d < NDMA; ++d)
                 __builtin_amdgcn_raw_ptr_buffer_load_lds(srs, (lds_void_t *)&lds[wave][s % D][d * 1024], 16, csrc[d],
-                                                         (rstart + min(k + D, nrows - 1)) * src_stride, 0, 0);
+                                                         min(k + D, nrows - 1) * src_stride, 0, 0);
 #pragma unroll
             for (int i = 0; i < N; ++i) {
                 int acc = 0;

@@ -21,9 +21,14 @@ for rep in range(reps):
     slots = {}
     for i in order:
         planes, strides, outs, ostr = [], [], [], []
-        for k, pl in enumerate(synth.split(src[i], iw, ih)):
-            t = torch.from_numpy(np.ascontiguousarray(pl)).cuda()
-            keep.append(t); planes.append(t.data_ptr()); strides.append(pl.shape[1])
+        pls = synth.split(src[i], iw, ih)
+        planes, strides = [0, 0, 0], [0, 0, 0]
+        korder = [0, 1, 2]; rng.shuffle(korder)                 # any plane may end up highest in memory
+        for k in korder:
+            pl = pls[k]
+            t = torch.zeros(pl.shape, dtype=torch.uint8, device="cuda")
+            t[:] = torch.from_numpy(np.ascontiguousarray(pl)).cuda()
+            keep.append(t); planes[k] = t.data_ptr(); strides[k] = pl.shape[1]
             if rng.random() < 0.3: keep.append(torch.full((rng.randrange(1, 64) * 512,), 0xCD, dtype=torch.uint8, device="cuda"))
         for k in range(3):
             w_, h_ = (ow, oh) if k == 0 else ((ow + 1) // 2, (oh + 1) // 2)
