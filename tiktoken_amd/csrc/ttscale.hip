@@ -476,10 +476,8 @@ __global__ __launch_bounds__(kMaxLdsBlock, (G4 && R == 4) ? 8 : 4) void strip_ld
     uint32_t csrc[NDMA];
     uint32_t lbase = 0, prefix = 0;
 #pragma unroll
-    // Spare lanes (chunks past the last piece) re-fetch the first piece's first chunk.  EVERY lane of
-    // an LDS-DMA must be in range: an out-of-range lane is zero-filled, and (seen once, with a spare
-    // lane whose 16 bytes straddled the end of the launch's span) the valid chunk next to it came
-    // back zeroed as well.
+    // Spare lanes (chunks past the last piece) re-fetch the first piece's first chunk, so that every
+    // lane of an LDS-DMA reads bytes of a plane it was sent to.
     for (int d = 0; d < NDMA; ++d) csrc[d] = ~0u;
     for (int p = 0; p < kMaxPieces && pm; ++p) {
         const int l0 = __builtin_ctzll(pm);
