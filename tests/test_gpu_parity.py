@@ -334,3 +334,19 @@ def test_pointer_api_shuffled_placements(tts, oracle):
         for i in range(n):
             for k, w in enumerate(synth.split(want[i], ow, oh)):
                 assert np.array_equal(dp[i][k].cpu().numpy(), w), "rep %d frame %d plane %d" % (rep, i, k)
+
+
+def test_batch_longer_than_one_launch_span(tts, oracle):
+    """1,500 frames of 1080x1920 (4.7 GB of source) exceed the 32-bit offset span of one launch:
+    tts_run_batch cuts the batch into launches; every frame must still come out right."""
+    import torch
+    iw, ih, n, distinct = 1080, 1920, 1500, 6
+    plan = tts.Plan.from_vf("scale=320:568:flags=area", iw, ih)
+    assert n * plan.in_bytes > 0xFF000000
+    base = synth.frames("random", iw, ih, distinct)
+    want = torch.from_numpy(oracle.run_chain(plan.geom, base)).cuda()
+    src = torch.from_numpy(base).cuda().repeat((n + distinct - 1) // distinct, 1)[:n].contiguous()
+    out = plan.run_batch(src)
+    torch.cuda.synchronize()
+    idx = torch.arange(n, device="cuda") % distinct
+    assert bool((out == want[idx]).all())
