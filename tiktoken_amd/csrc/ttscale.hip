@@ -317,24 +317,22 @@ __global__ __launch_bounds__(kBlock) void strip_kernel(const uint8_t *__restrict
     }
 }
 
-// ---- LDS-staged variant of the strip kernel (taps <= 4, grouped windows) ----------------------
-// Same walk as strip_kernel, but a wave first copies the run of source bytes that holds all of its
-// lanes' windows HBM/L2 -> LDS with ONE lane-contiguous 16-byte-per-lane LDS-DMA
-// (`buffer_load_dwordx4 ... lds`): every 128-byte line is requested exactly once, by one coalesced
-// instruction, instead of being met by dozens of overlapping per-lane window reads (each new line
-// then stalls the vector L1's pipe, stores included, on hit-under-miss).  The lanes pick their
-// 8-byte windows out of the wave's private LDS slot with ds_read_b64.  A wave's 64 strips may
-// straddle the end of a plane row (items are flattened over frames), so the run is one or two
-// pieces; more than two (rows shorter than a wave's run) fall back to strip_kernel.
+// ---- LDS-staged variant of the strip kernel ------------------------------------------------------
+// Same walk as strip_kernel, but per source row a wave first copies the runs of source bytes that
+// hold all of its lanes' windows HBM/L2 -> LDS with one or two lane-contiguous 16-byte-per-lane
+// LDS-DMAs (`buffer_load_dwordx4 ... lds`): every 128-byte line is requested exactly once, by one
+// coalesced instruction, instead of being met by dozens of overlapping per-lane window reads (each
+// new line then stalls the vector L1's pipe, stores included, on hit-under-miss; 8 gathers a row
+// also keep the texture addresser busy for ~16 cycles each).  The lanes pick their windows out of
+// the wave's private LDS slot.  A wave's 64 strips wrap over plane rows (items are flattened over
+// frames), so there is one run ("piece") per plane row touched.
 // Nothing in flight lives in VGPRs, and an LDS read hipcc can see is ordered behind EVERY LDS-DMA
 // still in flight (vmcnt(0)), so the window reads are inline asm and the waits are ours: before row
 // k is read we wait, exactly, until only the operations issued after row k's DMA are outstanding
 // -- the DMAs of the D-1 later rows plus the stores issued since (counted at run time; gfx950
 // retires vector-memory operations in issue order).
-// Output alignment is what this kernel's speed depends on most (tools/micro/pattern*.hip): a wave
-// stores 512 contiguous bytes per row; when rows are 1080 bytes the chunk ends fall inside 64-byte
-// sectors shared with the neighbouring wave on 7 rows of 8 and the job runs at ~42 % of the HBM
-// roofline, with 1024-byte rows (every chunk line-aligned) the same kernel reaches ~50 %.
+// What its speed depends on most is the output row pitch (tools/micro/pattern*.hip):
+// 1080-byte rows run at 42 % of the HBM roofline (46 % paced), 1024-byte rows at 50-52 %.
 template <int V>
 __device__ __forceinline__ void wait_vm() { asm volatile("s_waitcnt vmcnt(%0)" ::"n"(V) : "memory"); }
 
