@@ -1102,7 +1102,8 @@ int blocks_per_cu(strip_fn fn, int block, size_t lds_bytes)
 
 // Workgroup shape of a strip launch.  The register kernels run 256 threads.  The LDS-staged kernel
 // takes any multiple of 64 up to 1024 (one LDS slot per wave) and has a PACED mode for jobs that
-// are bound by their writes while the output rows are not sector-aligned (1080-byte rows: a wave's
+// are bound by their writes, large enough to fill the chip with such workgroups (~100 1080p frames),
+// while the output rows are not sector-aligned (1080-byte rows: a wave's
 // 512-byte chunk then ends inside a 64-byte sector it shares with the next wave on 7 rows of 8):
 // 1024-thread workgroups of neighbouring strips, dealt strip-major so that neighbours also share
 // an XCD, whose waves meet at a barrier before every output row's store.  The halves of a shared
@@ -1110,7 +1111,7 @@ int blocks_per_cu(strip_fn fn, int block, size_t lds_bytes)
 // 1080p->portrait 0.370 -> 0.330 ms, 720p->portrait 0.380 -> 0.327 ms; jobs that read more than they
 // write (4K->portrait) or write aligned rows lose 3-10 % to the barrier and stay unpaced.
 struct BlockShape { int threads; size_t lds_bytes; int paced; };
-BlockShape block_shape(const tts_plan *p, int ci, const StripChoice &ch, int dst_stride)
+BlockShape block_shape(const tts_plan *p, int ci, const StripChoice &ch, int dst_stride, int max_items, int64_t total_items)
 {
     if (!ch.lds) return {kBlock, 0, 0};
     const ClassPlan &c = p->cls[ci];
@@ -1118,9 +1119,12 @@ BlockShape block_shape(const tts_plan *p, int ci, const StripChoice &ch, int dst
     const int src_rows = c.v.pos[c.y0 + c.oh - 1] + c.v.size - c.v.pos[c.y0];
     const int src_cols = c.h.pos[c.x0 + c.ow - 1] + c.h.size - c.h.pos[c.x0];
     const bool write_bound = 2.0 * c.ow * c.oh >= 3.0 * src_rows * src_cols;     // writes >= 60 % of the traffic
-    int paced = misaligned && write_bound;
+    // (below ~100 strips per CU there are too few 1024-thread workgroups to keep the chip busy: 16
+    // 1080p frames take 44 us paced, 29 us not; the gain starts at ~100 frames)
+    int paced = misaligned && write_bound && total_items >= int64_t(96) * p->n_cus;
     if (p->knobs.paced >= 0) paced = p->knobs.paced;
-    int t = p->knobs.lds_block > 0 ? p->knobs.lds_block : paced ? kMaxLdsBlock : kBlock;
+    // (a paced workgroup is no larger than the biggest class needs: idle waves still walk every row)
+    int t = p->knobs.lds_block > 0 ? p->knobs.lds_block : paced ? std::max(kBlock, std::min(kMaxLdsBlock, (max_items + 63) / 64 * 64)) : kBlock;
     t = std::min(std::max(t / 64 * 64, 64), kMaxLdsBlock);
     return {t, size_t(t / 64) * ch.depth * (size_t(ch.lds) * 1024 + 16), paced};
 }
@@ -1209,7 +1213,15 @@ int launch_all(const tts_plan *p, const uint8_t *src, uint8_t *dst, int n, const
         strip_fn fn = pick_strip(ch, p->knobs);
         if (!fn) return TTS_ERR_UNSUPPORTED;
         size_t si[2];
-        const BlockShape bs = block_shape(p, ci, ch, dst_stride[ci]);
+        int max_items = 0;
+        int64_t total_items = 0;
+        for (int j = 0; j < ns; ++j) {
+            const int cj = strip_cls[j];
+            if (!(merged || cj == ci)) continue;
+            const int items = n * nplanes(cj) * p->cls[cj].ht[ch.N == 16].strips;
+            max_items = std::max(max_items, items); total_items += items;
+        }
+        const BlockShape bs = block_shape(p, ci, ch, dst_stride[ci], max_items, total_items);
         const int min_segs = addr.use_table && ch.lds ? 2 : 1;
         if (merged) {
             choose_segs(p, strip_cls, 2, n, ch.N, fn, bs, min_segs, si);
