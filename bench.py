@@ -2,7 +2,9 @@
 """bench.py -- frames/s of the 1080p -> 1080x1920 portrait scale+crop hot path on MI355X.
 
 One step = one pass of libttscale over one HBM-resident batch of synthetic yuv420p frames
-(BASELINE.json configs[1] geometry, batched: 300 frames = the 10 s 1080p30 clip of configs[0]).
+(BASELINE.json configs[1] geometry, batched: 1,200 frames = 40 s of 1080p30, 3.7 GB of source and
+3.7 GB of output per GPU, one kernel launch; `--frames 300` is the 10 s clip of configs[0]: the
+launch's ramp and tail weigh more there, 906 k frames/s against 985 k).
 Multi-GPU: one process per GPU, every rank owns its own clip (clip-sharded, no data-path
 collective; torch.distributed is used for the barrier and the max-over-ranks only).
 
@@ -47,10 +49,10 @@ def cpu_baseline(geom, budget_s=12.0):
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=200)
+    ap.add_argument("--steps", type=int, default=100)
     ap.add_argument("--warmup", type=int, default=10)
-    ap.add_argument("--frames", type=int, default=300, help="frames per GPU per step")
-    ap.add_argument("--settle", type=int, default=50,
+    ap.add_argument("--frames", type=int, default=1200, help="frames per GPU per step")
+    ap.add_argument("--settle", type=int, default=20,
                     help="untimed launches BEFORE the warm-up steps: back-to-back launch times drift 0.33 -> 0.42 -> 0.35 ms over "
                          "the first ~30 launches of a burst while the clock governor settles (DESIGN.md 4.4); the metric is sustained rate")
     ap.add_argument("--no-cpu-baseline", action="store_true")
@@ -106,15 +108,17 @@ def main():
         fps = world * n * args.steps / wall
         # A step is ONE launch of the strip kernel (luma and chroma planes ride in one grid), so its
         # average launch duration is the event time per step and a launch moves a whole step's bytes.
-        launches = 1
+        span = 0xFF000000                          # bytes one launch addresses (include/ttscale.h): longer batches are cut
+        per_launch = 1 + min((span - plan.in_bytes) // plan.in_bytes, (span - plan.out_bytes) // plan.out_bytes)
+        launches = -(-n // per_launch)
         launch_ms = dev_ms / args.steps / launches
         algo_bytes_launch = ALGO_BYTES_PER_FRAME * n / launches
         achieved = algo_bytes_launch / (launch_ms * 1e-3) / 1e9
-        traffic = None
+        traffic = None                             # PMC-measured HBM bytes per frame (profiles/traffic.json) x frames per launch
         tpath = os.path.join(ROOT, "profiles", "traffic.json")
         if os.path.exists(tpath):
             try:
-                traffic = json.load(open(tpath)).get("hbm_bytes_per_launch")
+                traffic = int(json.load(open(tpath))["hbm_bytes_per_frame"] * n / launches)
             except Exception:
                 traffic = None
         out = {
