@@ -117,6 +117,10 @@ def test_row_segmentation_is_invisible(tts, oracle, monkeypatch, seg):
     ("scale=136:96", 100, 60, 1, "planewise"),
     ("scale=355:267", 200, 150, 2, "planewise"),
     ("scale=1080:1920:force_original_aspect_ratio=increase,crop=1080:1920", 1280, 720, 1, "planewise"),
+    # the column walk in pointer mode
+    (THUMB_REF, 1920, 1080, 3, False),
+    (THUMB_REF, 1283, 721, 1, "planewise"),
+    ("scale=20:12", 200, 120, 40, False),                   # 12-row planes: single segment -> generic kernel in pointer mode
 ])
 def test_frame_pointer_api_matches_batch_api(tts, oracle, monkeypatch, vf, iw, ih, n, pad):
     """tts_run with per-frame plane pointers (every plane its own allocation, padded or tight strides)
@@ -350,3 +354,31 @@ def test_batch_longer_than_one_launch_span(tts, oracle):
     torch.cuda.synchronize()
     idx = torch.arange(n, device="cuda") % distinct
     assert bool((out == want[idx]).all())
+
+
+# The column walk (9..64 taps per axis): (chain, iw, ih, frames, expected kernel kind of the luma class); 4 / 5 = one /
+# two LDS-DMAs per source row, 0 = generic kernel (more than 64 taps).
+COLUMN_CASES = [
+    (THUMB_REF, 1920, 1080, 9, 4),                         # src/services/video.js:329-332 on 1080p: 6x, 25 taps
+    (THUMB_REF, 3840, 2160, 2, 4),                         # ... on 4K: 12x, 49 taps (32 tap pairs, ring of 64 rows)
+    (THUMB_REF, 720, 1280, 70, 4),                         # ... on a portrait clip: 101 columns, waves wrap over planes
+    (THUMB_REF + ",format=yuvj420p", 1080, 1080, 3, 4),    # ... square source, then the mjpeg range pass
+    ("scale=160:90", 1920, 1080, 5, 4),
+    ("scale=40:ih", 640, 48, 33, 5),                       # 16x horizontally only: runs of 1.1 KB, vertical taps = 1
+    ("scale=iw:30", 64, 480, 33, 4),                       # 16x vertically only
+    ("scale=320:180:flags=area", 3840, 2160, 2, 4),        # 12x area: 13 taps
+    ("scale=20:12", 200, 120, 200, 4),                     # 20-column planes: 3-4 pieces per wave
+    ("crop=1280:720:320:180,scale=160:90", 1920, 1080, 3, 4),   # pre-crop: windows start inside the rows
+    ("scale=64:36", 1920, 1080, 2, 0),                     # 30x: 121 taps -> generic kernel
+]
+
+
+@pytest.mark.parametrize("vf,iw,ih,n,kind", COLUMN_CASES)
+def test_column_kernel_variants(tts, oracle, vf, iw, ih, n, kind):
+    import torch
+    plan = tts.Plan.from_vf(vf, iw, ih)
+    assert plan.kernel_kind(0) == kind, "luma class runs kernel kind %d, expected %d" % (plan.kernel_kind(0), kind)
+    for pat in ("random", "impulse"):
+        src = synth.frames(pat, iw, ih, n)
+        got = plan.run_batch(torch.from_numpy(src).cuda()).cpu().numpy()
+        assert np.array_equal(got, oracle.run_chain(plan.geom, src)), pat

@@ -390,6 +390,64 @@ struct Win3 { u32x2_t lo; uint32_t hi; };
 
 constexpr int kMaxPieces = 8;      // source runs a wave's 64 strips may need (they wrap over plane rows)
 
+// The source runs of one wave of an LDS-staged kernel.  The wave's source bytes are one run per
+// plane row its 64 lanes touch ("pieces": a new one starts at every lane whose windows restart in
+// another plane, `new_row`).  Piece p covers lanes [l0, l1), bytes [start, end) rounded out to
+// 16-byte chunks, and takes the next n chunks of the wave's LDS slot; chunk c of the slot is fetched
+// by lane c % 64 of DMA c / 64.  In: this lane's bytes [first, last) in the segment's FIRST source
+// row (the DMAs add (row - first row) * stride as their scalar offset, so nothing here can be
+// "negative"), its plane's origin `soff`.  Out: csrc[d] = what this lane fetches in DMA d;
+// lbase = slot position minus source address for this lane's piece.
+template <int NDMA>
+__device__ __forceinline__ void plan_runs(const StripArgs &a, const StripClass &c, uint32_t first, uint32_t last, uint32_t soff,
+                                          bool new_row, int lane, uint32_t last_rowoff, uint32_t (&csrc)[NDMA], uint32_t &lbase)
+{
+    uint64_t pm = __builtin_amdgcn_ballot_w64(new_row) | 1ull;
+    uint32_t prefix = 0;
+    lbase = 0;
+    // Spare lanes (chunks past the last piece) re-fetch the first piece's first chunk, so that every
+    // lane of an LDS-DMA reads bytes of a plane it was sent to.
+#pragma unroll
+    for (int d = 0; d < NDMA; ++d) csrc[d] = ~0u;
+    for (int p = 0; p < kMaxPieces && pm; ++p) {
+        const int l0 = __builtin_ctzll(pm);
+        pm &= pm - 1;
+        const int l1 = pm ? __builtin_ctzll(pm) : 64;
+        // Where may this piece's run lie?  Its chunk grid is the same for every source row of the
+        // segment, rows differ by the scalar row offset only.  The run is rounded out to whole
+        // chunks; rounding into a neighbouring row of the same plane is harmless, rounding out of
+        // the PLANE is not: with per-frame plane pointers those bytes may not be mapped, and at the
+        // end of a launch's span the range check zero-fills whole dwords, one that straddles the end
+        // and still holds needed bytes included.  So: start on a 16-byte boundary unless that falls
+        // before the plane (pointer mode; in packed batches the bytes before a plane are the previous
+        // plane), and if the last chunk would pass the plane's end on the segment's last row, slide
+        // the run down so that it ends exactly on the piece's last byte.  (A segment holding BOTH the
+        // first and the last row of a narrow plane can satisfy only one end; the host never sends
+        // such a segment here in pointer mode, and in a packed batch the lower end gives way.)
+        const uint32_t porg = uint32_t(__builtin_amdgcn_readlane(int(soff), l0));
+        const uint32_t lo_abs = a.addr.use_table ? porg - c.src_begin_rel : 0u, hi_abs = porg + c.src_end_rel;
+        const uint32_t end = uint32_t(__builtin_amdgcn_readlane(int(last), l1 - 1));
+        uint32_t start = uint32_t(__builtin_amdgcn_readlane(int(first), l0)) & ~15u;
+        if (start < lo_abs) start = lo_abs;
+        const uint32_t n = (end - start + 15u) >> 4;
+        if (start + 16u * n + last_rowoff > hi_abs && end >= lo_abs + 16u * n) start = end - 16u * n;
+        if (lane >= l0 && lane < l1) lbase = 16u * prefix - start;
+        if (p == 0) {
+#pragma unroll
+            for (int d = 0; d < NDMA; ++d) csrc[d] = start;
+        }
+#pragma unroll
+        for (int d = 0; d < NDMA; ++d) {
+            const uint32_t ch = uint32_t(lane) + 64u * d;
+            if (ch >= prefix && ch < prefix + n) csrc[d] = start + 16u * (ch - prefix);
+        }
+        prefix += n;
+    }
+    // the host picks these kernels only for geometries whose runs fit; anything else here would be
+    // silent corruption, so trap
+    if (pm || prefix > 64u * NDMA) __builtin_trap();
+}
+
 // LW, R as in strip_kernel; G4: grouped windows (two 8-byte windows per lane, taps <= 4), else one
 // LW-byte window per column; NDMA: 1 KiB LDS-DMAs per source row (the wave's runs hold <= 64 * NDMA
 // sixteen-byte chunks).  Eight columns per lane.
@@ -456,64 +514,15 @@ __global__ __launch_bounds__(kMaxLdsBlock, (G4 && R == 4) ? 8 : 4) void strip_ld
         }
     }
 
-    // The wave's source bytes are one run per plane row its 64 strips touch ("pieces": a new one
-    // starts at every lane whose windows restart in another plane).  Piece p covers lanes [l0, l1),
-    // bytes [start, end) rounded out to 16-byte chunks, and takes the next n chunks of the slot;
-    // chunk c of the slot is fetched by lane c % 64 of DMA c / 64.
     constexpr uint32_t kWin = G4 ? 8u : uint32_t(LW);
-    // (all run addresses below are those of the segment's FIRST source row, `rstart`: the DMAs add
-    // (row - rstart) * stride as their scalar offset, so nothing here can be "negative")
-    const bool restart = lane > 0 && strip == 0 && live;               // a new plane row begins at this lane
-    uint64_t pm = __builtin_amdgcn_ballot_w64(restart) | 1ull;
     const int rstart = int(uni(tab[c.seginfo + 2 * seg]));
     const int nrows  = int(uni(tab[c.seginfo + 2 * seg + 1]));
     const int src_stride = int(uni(uint32_t(c.src_stride)));
     const uint32_t row0_off = uint32_t(rstart) * uint32_t(src_stride);
-    const uint32_t last_rowoff = uint32_t(nrows - 1) * uint32_t(src_stride);      // last row of the segment, relative to its first
-    const uint32_t first = off[0] + row0_off, last = off[NW - 1] + kWin + row0_off;   // this lane's bytes in row `rstart`: [first, last)
     uint32_t csrc[NDMA];
-    uint32_t lbase = 0, prefix = 0;
-#pragma unroll
-    // Spare lanes (chunks past the last piece) re-fetch the first piece's first chunk, so that every
-    // lane of an LDS-DMA reads bytes of a plane it was sent to.
-    for (int d = 0; d < NDMA; ++d) csrc[d] = ~0u;
-    for (int p = 0; p < kMaxPieces && pm; ++p) {
-        const int l0 = __builtin_ctzll(pm);
-        pm &= pm - 1;
-        const int l1 = pm ? __builtin_ctzll(pm) : 64;
-        // Where may this piece's run lie?  Its chunk grid is the same for every source row of the
-        // segment, rows differ by the scalar row offset only.  The run is rounded out to whole
-        // chunks; rounding into a neighbouring row of the same plane is harmless, rounding out of
-        // the PLANE is not: with per-frame plane pointers those bytes may not be mapped, and at the
-        // end of a launch's span the range check zero-fills whole dwords, one that straddles the end
-        // and still holds needed bytes included.  So: start on a 16-byte boundary unless that falls
-        // before the plane (pointer mode; in packed batches the bytes before a plane are the previous
-        // plane), and if the last chunk would pass the plane's end on the segment's last row, slide
-        // the run down so that it ends exactly on the piece's last byte.  (A segment holding BOTH the
-        // first and the last row of a narrow plane can satisfy only one end; the host never sends
-        // such a segment here in pointer mode, and in a packed batch the lower end gives way.)
-        const uint32_t porg = uint32_t(__builtin_amdgcn_readlane(int(soff), l0));
-        const uint32_t lo_abs = a.addr.use_table ? porg - c.src_begin_rel : 0u, hi_abs = porg + c.src_end_rel;
-        const uint32_t end = uint32_t(__builtin_amdgcn_readlane(int(last), l1 - 1));
-        uint32_t start = uint32_t(__builtin_amdgcn_readlane(int(first), l0)) & ~15u;
-        if (start < lo_abs) start = lo_abs;
-        const uint32_t n = (end - start + 15u) >> 4;
-        if (start + 16u * n + last_rowoff > hi_abs && end >= lo_abs + 16u * n) start = end - 16u * n;
-        if (lane >= l0 && lane < l1) lbase = 16u * prefix - start;
-        if (p == 0) {
-#pragma unroll
-            for (int d = 0; d < NDMA; ++d) csrc[d] = start;
-        }
-#pragma unroll
-        for (int d = 0; d < NDMA; ++d) {
-            const uint32_t ch = uint32_t(lane) + 64u * d;
-            if (ch >= prefix && ch < prefix + n) csrc[d] = start + 16u * (ch - prefix);
-        }
-        prefix += n;
-    }
-    // the host picks this kernel only for geometries whose runs fit; anything else here would be
-    // silent corruption, so trap
-    if (pm || prefix > 64u * NDMA) __builtin_trap();
+    uint32_t lbase;
+    plan_runs<NDMA>(a, c, off[0] + row0_off, off[NW - 1] + kWin + row0_off, soff, lane > 0 && strip == 0 && live, lane,
+                    uint32_t(nrows - 1) * uint32_t(src_stride), csrc, lbase);
 
     const uint32_t lds_wave = uint32_t(reinterpret_cast<uintptr_t>((lds_void_t *)&lds[wave][0][0]));   // LDS byte address
     uint32_t lpos[NW];                               // aligned LDS address of each window's first dword
@@ -643,6 +652,155 @@ __global__ __launch_bounds__(kMaxLdsBlock, (G4 && R == 4) ? 8 : 4) void strip_ld
                 ++y;
             }
             hist[s % D] = cnt;
+        }
+    }
+#endif
+}
+
+// ---- column walk: many-tap downscales (9..64 taps per axis) ------------------------------------
+// The reference's own thumbnail chain (src/services/video.js:329-332) shrinks 1080p by 6x and 4K by
+// 12x with bicubic: 25 to 49 taps per axis.  Same walk as strip_lds_kernel with ONE output column
+// per lane: a wave's 64 columns read one run of (64 x ratio + taps) source bytes per source row
+// through the LDS slot, every lane dots its 2*NTP-byte window with its own taps (NTP v_perm +
+// NTP v_dot2), and the 15-bit results of the last R source rows sit in a register ring of R/2
+// int16 pairs; an output row is R/2 v_dot2 against the wave-uniform vertical taps and one byte
+// store per lane (a wave stores 64 contiguous bytes).  Every source byte is read once per row
+// segment; the generic kernel re-reads each one taps^2 / ratio^2 times.
+template <int NDW>
+__device__ __forceinline__ void lds_read_dwords(uint32_t (&w)[NDW], uint32_t p);
+template <>
+[[maybe_unused]] __device__ __forceinline__ void lds_read_dwords<9>(uint32_t (&w)[9], uint32_t p)
+{
+    u32x2_t a, b, c, d; uint32_t e;
+    asm volatile("ds_read2_b32 %0, %5 offset1:1\n\tds_read2_b32 %1, %5 offset0:2 offset1:3\n\t"
+                 "ds_read2_b32 %2, %5 offset0:4 offset1:5\n\tds_read2_b32 %3, %5 offset0:6 offset1:7\n\t"
+                 "ds_read_b32 %4, %5 offset:32\n\ts_waitcnt lgkmcnt(0)"
+                 : "=&v"(a), "=&v"(b), "=&v"(c), "=&v"(d), "=&v"(e) : "v"(p) : "memory");
+    w[0] = a.x; w[1] = a.y; w[2] = b.x; w[3] = b.y; w[4] = c.x; w[5] = c.y; w[6] = d.x; w[7] = d.y; w[8] = e;
+}
+template <>
+[[maybe_unused]] __device__ __forceinline__ void lds_read_dwords<17>(uint32_t (&w)[17], uint32_t p)
+{
+    u32x2_t a, b, c, d, e, f, g, h; uint32_t i;
+    asm volatile("ds_read2_b32 %0, %9 offset1:1\n\tds_read2_b32 %1, %9 offset0:2 offset1:3\n\t"
+                 "ds_read2_b32 %2, %9 offset0:4 offset1:5\n\tds_read2_b32 %3, %9 offset0:6 offset1:7\n\t"
+                 "ds_read2_b32 %4, %9 offset0:8 offset1:9\n\tds_read2_b32 %5, %9 offset0:10 offset1:11\n\t"
+                 "ds_read2_b32 %6, %9 offset0:12 offset1:13\n\tds_read2_b32 %7, %9 offset0:14 offset1:15\n\t"
+                 "ds_read_b32 %8, %9 offset:64\n\ts_waitcnt lgkmcnt(0)"
+                 : "=&v"(a), "=&v"(b), "=&v"(c), "=&v"(d), "=&v"(e), "=&v"(f), "=&v"(g), "=&v"(h), "=&v"(i) : "v"(p) : "memory");
+    w[0] = a.x; w[1] = a.y; w[2] = b.x; w[3] = b.y; w[4] = c.x; w[5] = c.y; w[6] = d.x; w[7] = d.y;
+    w[8] = e.x; w[9] = e.y; w[10] = f.x; w[11] = f.y; w[12] = g.x; w[13] = g.y; w[14] = h.x; w[15] = h.y; w[16] = i;
+}
+
+// NTP: tap pairs per column (window = 2 * NTP bytes); R: ring depth >= vertical taps; NDMA as above.
+template <int NTP, int R, int NDMA>
+__global__ __launch_bounds__(kBlock) void column_lds_kernel(const uint8_t *__restrict__ src, uint8_t *__restrict__ dst,
+                                                            const uint32_t *__restrict__ tab, const StripArgs a)
+{
+    static_assert(NTP % 2 == 0 && R % 2 == 0 && (NDMA == 1 || NDMA == 2), "window is whole dwords; ring holds row pairs");
+#if defined(__HIP_DEVICE_COMPILE__)   // the LDS-DMA builtin exists in the device pass only
+    constexpr int NDW = NTP / 2 + 1;                 // aligned dwords that hold a 2 * NTP-byte window at any byte phase
+    constexpr int kSlotBytes = NDMA * 1024 + 16;
+    __shared__ __attribute__((aligned(16))) uint8_t lds[kBlock / 64][kSlotBytes];
+
+    uint32_t lb = xcd_remap(blockIdx.x, gridDim.x);
+    const int ci = lb >= a.c[0].nblocks ? 1 : 0;
+    if (ci) lb -= a.c[0].nblocks;
+    const StripClass &c = a.c[ci];
+
+    const int seg = int(lb % uint32_t(c.nseg));
+    const int sb  = int(lb / uint32_t(c.nseg));
+    int       g   = sb * kBlock + int(threadIdx.x);
+    const bool live = g < c.n_items;
+    if (!live) g = c.n_items - 1;                  // dead lanes (a suffix of the last workgroup) shadow the last live one
+    const int col   = g % c.strips;                // one output column per lane: strips == ow
+    const int fp    = g / c.strips;
+    const int wave = __builtin_amdgcn_readfirstlane(int(threadIdx.x) >> 6);
+    const int lane = int(threadIdx.x) & 63;
+
+    const int plane = c.plane0 + fp % c.planes;
+    const int frame = fp / c.planes;
+    uint32_t soff, doff;
+    if (a.addr.use_table) {
+        soff = a.addr.src_tab[plane][frame];
+        doff = a.addr.dst_tab[plane][frame];
+    } else {
+        soff = uint32_t(frame) * a.addr.src_pitch + a.addr.src_plane[plane];
+        doff = uint32_t(frame) * a.addr.dst_pitch + a.addr.dst_plane[plane];
+    }
+    doff += uint32_t(col);
+    if (!live) doff = kDiscard;                    // see strip_lds_kernel
+
+    uint32_t hc[NTP];
+#pragma unroll
+    for (int k = 0; k < NTP; ++k) hc[k] = tab[c.hcoef + col * NTP + k];
+    const uint32_t off = tab[c.hoff + col] + soff;
+
+    const int rstart = int(uni(tab[c.seginfo + 2 * seg]));
+    const int nrows  = int(uni(tab[c.seginfo + 2 * seg + 1]));
+    const int src_stride = int(uni(uint32_t(c.src_stride)));
+    const uint32_t row0_off = uint32_t(rstart) * uint32_t(src_stride);
+    uint32_t csrc[NDMA];
+    uint32_t lbase;
+    plan_runs<NDMA>(a, c, off + row0_off, off + 2u * NTP + row0_off, soff, lane > 0 && col == 0 && live, lane,
+                    uint32_t(nrows - 1) * uint32_t(src_stride), csrc, lbase);
+
+    const uint32_t pos = off + row0_off + lbase + uint32_t(reinterpret_cast<uintptr_t>((lds_void_t *)&lds[wave][0]));
+    const uint32_t lpos = pos & ~3u, o = pos & 3u;
+    // taps 2tp, 2tp+1 (as 16-bit lanes) sit at bytes o + 2 (tp % 2), +1 of dwords tp / 2, tp / 2 + 1
+    const uint32_t psel[2] = {0x0c000c00u | o | ((o + 1u) << 16), 0x0c000c00u | (o + 2u) | ((o + 3u) << 16)};
+
+    uint32_t ring[R / 2];
+#pragma unroll
+    for (int k = 0; k < R / 2; ++k) ring[k] = 0;
+
+    const uint32_t *emit = tab + c.emit + seg * c.maxrows;
+    const uint32_t *vco  = tab + c.vcoef;
+    int y = seg * c.seg_rows;
+    const int dst_stride = int(uni(uint32_t(c.dst_stride)));
+
+    const __amdgpu_buffer_rsrc_t srs = __builtin_amdgcn_make_buffer_rsrc(const_cast<uint8_t *>(src), 0, a.src_span, 0x00020000);
+    const uint64_t dbase = reinterpret_cast<uint64_t>(dst);
+    const u32x4_t drs = {uni(uint32_t(dbase)), uni(uint32_t(dbase >> 32) & 0xffffu), uni(a.dst_span), 0x00020000u};
+
+#pragma unroll
+    for (int d = 0; d < NDMA; ++d)
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(srs, (lds_void_t *)&lds[wave][d * 1024], 16, csrc[d], 0, 0, 0);
+    int cnt_next = int(uni(emit[0]));
+    int prev_cnt = 0;                              // stores issued since the DMA of the row about to be read
+
+    for (int k0 = 0; k0 < nrows; k0 += R) {
+#pragma unroll
+        for (int s = 0; s < R; ++s) {
+            const int k = k0 + s;
+            if (k >= nrows) continue;                           // wave-uniform (no early exit: the loop must unroll fully)
+            const int cnt = cnt_next;
+            cnt_next = int(uni(emit[min(k + 1, nrows - 1)]));
+            wait_vm_plus<0>(prev_cnt);                          // row k's DMA has landed; younger stores may still fly
+            uint32_t w[NDW];
+            lds_read_dwords<NDW>(w, lpos);
+            // the slot is free again (its bytes sit in registers): request row k + 1 into it
+#pragma unroll
+            for (int d = 0; d < NDMA; ++d)
+                __builtin_amdgcn_raw_ptr_buffer_load_lds(srs, (lds_void_t *)&lds[wave][d * 1024], 16, csrc[d],
+                                                         min(k + 1, nrows - 1) * src_stride, 0, 0);
+            int acc = 0;
+#pragma unroll
+            for (int tp = 0; tp < NTP; ++tp)
+                acc = dot2(__builtin_amdgcn_perm(w[tp / 2 + 1], w[tp / 2], psel[tp % 2]), hc[tp], acc);
+            const uint32_t t = hfinish(acc);
+            ring[s / 2] = (s & 1) ? __builtin_amdgcn_perm(t, ring[s / 2], 0x05040100)
+                                  : __builtin_amdgcn_perm(ring[s / 2], t, 0x07060100);
+            for (int e = 0; e < cnt; ++e) {                     // wave-uniform
+                int v = 64 << 12;
+#pragma unroll
+                for (int q = 0; q < R / 2; ++q) v = dot2(ring[q], uni(vco[y * (R / 2) + q]), v);
+                v >>= 19;
+                v = v < 0 ? 0 : v > 255 ? 255 : v;
+                store_b8(uint32_t(v), drs, doff, int(uni(uint32_t(y * dst_stride))));
+                ++y;
+            }
+            prev_cnt = cnt;
         }
     }
 #endif
@@ -778,9 +936,12 @@ struct ClassPlan {
     int x0 = 0, y0 = 0, ow = 0, oh = 0; // region of the virtual scaled plane that is produced
     int canvas_w = 0, canvas_h = 0;    // output plane
     int pad_x = 0, pad_y = 0;
-    int kind = 0;                      // 0 generic, 1 strip
+    int kind = 0;                      // 0 generic, 1 strip, 2 column
     int LW = 0, R = 0;
     int LWlds = 0;                     // window width of the LDS-staged kernel's per-column mode (6 when 5-6 taps)
+    // kind 2: column walk (9..64 taps): one output column per lane
+    int NTP = 0, Rc = 0, col_dmas = 0; // tap pairs per column, ring depth, LDS-DMAs per source row
+    uint32_t hoff1 = 0, hcoef1 = 0;    // window start per column, taps per column [ow][NTP]
     HTables ht[2];                     // horizontal tables for N = 8 and N = 16 columns per lane
     std::vector<SegTables> segs;
     // generic tables
@@ -843,9 +1004,9 @@ bool monotone(const std::vector<int32_t> &p)
 
 inline uint32_t pack16(int16_t lo, int16_t hi) { return uint32_t(uint16_t(lo)) | (uint32_t(uint16_t(hi)) << 16); }
 
-void build_seg_tables(const ClassPlan &c, int seg_rows, std::vector<uint32_t> &tab, SegTables &st)
+void build_seg_tables(const ClassPlan &c, int R, int seg_rows, std::vector<uint32_t> &tab, SegTables &st)
 {
-    const int VT = c.v.size, R = c.R;
+    const int VT = c.v.size;
     st.seg_rows = seg_rows;
     st.nseg = (c.oh + seg_rows - 1) / seg_rows;
     st.maxrows = 0; st.total_src_rows = 0;
@@ -867,7 +1028,7 @@ void build_seg_tables(const ClassPlan &c, int seg_rows, std::vector<uint32_t> &t
         const int s = y / seg_rows, vy = c.y0 + y;
         const int p = c.v.pos[vy];
         tab[st.emit + size_t(s) * st.maxrows + (p + VT - 1 - first[s])] += 1;
-        int16_t slot[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+        int16_t slot[64] = {0};
         for (int j = 0; j < VT; ++j) slot[(p + j - first[s]) % R] = c.v.taps[size_t(vy) * VT + j];
         for (int k = 0; k < R / 2; ++k) tab[st.vcoef + size_t(y) * (R / 2) + k] = pack16(slot[2 * k], slot[2 * k + 1]);
     }
@@ -880,7 +1041,7 @@ void build_seg_tables(const ClassPlan &c, int seg_rows, std::vector<uint32_t> &t
 // `nw` windows of a strip, `win` their width.  0 = not usable.
 int lds_dmas(const ClassPlan &c, const HTables &t, int N, const int *lo, int nw, int win)
 {
-    if (N != 8 || c.ow < N || t.strips < 2 || env_int("TTS_NO_LDS", 0)) return 0;
+    if ((N != 8 && N != 1) || c.ow < N || t.strips < 2 || env_int("TTS_NO_LDS", 0)) return 0;
     auto chunks = [&](int s0, int s1) {   // strips [s0, s1] of one row
         const uint32_t b = uint32_t(lo[size_t(s0) * nw]), e = uint32_t(lo[size_t(s1) * nw + nw - 1] + win);
         return (e - b + 30u) >> 4;
@@ -923,7 +1084,39 @@ int build_class(const tts_geom &g, int sub, ClassPlan &c, std::vector<uint32_t> 
     const int R = VT <= 4 ? 4 : VT <= 6 ? 6 : 8;
     const bool strip_ok = HT <= 8 && VT <= 8 && c.src_w >= LW && monotone(c.v.pos) &&
                           !env_int("TTS_FORCE_GENERIC", 0);
-    if (!strip_ok) { c.kind = 0; return TTS_OK; }
+    if (!strip_ok) {
+        // Many taps: the column walk, if the taps fit its windows and ring and the runs fit its slot.
+        c.kind = 0;
+        const int NTP = HT <= 32 ? 16 : 32, Rc = VT <= 32 ? 32 : 64;
+        if (HT > 64 || VT > 64 || c.src_w < 2 * NTP || !monotone(c.v.pos) || env_int("TTS_FORCE_GENERIC", 0)) return TTS_OK;
+        HTables t;                                     // (only `strips` is used by lds_dmas)
+        t.strips = c.ow;
+        std::vector<int> lo(static_cast<size_t>(c.ow));
+        const uint32_t hoff1 = uint32_t(tab.size());
+        tab.resize(tab.size() + c.ow);
+        const uint32_t hcoef1 = uint32_t(tab.size());
+        tab.resize(tab.size() + size_t(c.ow) * NTP, 0);
+        for (int i = 0; i < c.ow; ++i) {
+            const int vx = c.x0 + i, pos = c.h.pos[vx];
+            lo[i] = std::min(pos, c.src_w - 2 * NTP);           // keep the window inside the row
+            int16_t slot[64] = {0};
+            for (int j = 0; j < HT; ++j) slot[pos - lo[i] + j] = c.h.taps[size_t(vx) * HT + j];
+            tab[hoff1 + i] = uint32_t(lo[i]);
+            for (int k = 0; k < NTP; ++k) tab[hcoef1 + size_t(i) * NTP + k] = pack16(slot[2 * k], slot[2 * k + 1]);
+        }
+        const int dmas = lds_dmas(c, t, 1, lo.data(), 1, 2 * NTP);
+        if (!dmas) return TTS_OK;
+        c.kind = 2; c.NTP = NTP; c.Rc = Rc; c.col_dmas = dmas; c.hoff1 = hoff1; c.hcoef1 = hcoef1;
+        std::vector<int> opts(kSegOptions, kSegOptions + kNumSegOptions);
+        const int forced = env_int("TTS_SEG_ROWS", 0);
+        if (forced > 0) opts.assign(1, forced);
+        for (int sr : opts) {
+            SegTables st;
+            build_seg_tables(c, Rc, sr, tab, st);
+            c.segs.push_back(st);
+        }
+        return TTS_OK;
+    }
     c.kind = 1; c.LW = LW; c.R = R;
 
     // Horizontal tables, one set per strip width N.  Strip s covers columns [xs, xs + N) with
@@ -1007,7 +1200,7 @@ int build_class(const tts_geom &g, int sub, ClassPlan &c, std::vector<uint32_t> 
     if (forced > 0) opts.assign(1, forced);
     for (int sr : opts) {
         SegTables st;
-        build_seg_tables(c, sr, tab, st);
+        build_seg_tables(c, c.R, sr, tab, st);
         c.segs.push_back(st);
     }
     return TTS_OK;
@@ -1159,6 +1352,58 @@ void choose_segs(const tts_plan *p, const int *cis, int ncls, int n, int N, stri
     out_idx[0] = out_idx[1] = best;
 }
 
+strip_fn pick_column(const ClassPlan &c)
+{
+    if (c.NTP == 16 && c.Rc == 32) return c.col_dmas == 1 ? column_lds_kernel<16, 32, 1> : column_lds_kernel<16, 32, 2>;
+    if (c.NTP == 16 && c.Rc == 64) return c.col_dmas == 1 ? column_lds_kernel<16, 64, 1> : column_lds_kernel<16, 64, 2>;
+    if (c.NTP == 32 && c.Rc == 32) return c.col_dmas == 1 ? column_lds_kernel<32, 32, 1> : column_lds_kernel<32, 32, 2>;
+    if (c.NTP == 32 && c.Rc == 64) return c.col_dmas == 1 ? column_lds_kernel<32, 64, 1> : column_lds_kernel<32, 64, 2>;
+    return nullptr;
+}
+
+void fill_column_class(const tts_plan *p, int ci, int n, int src_stride, int dst_stride, const SegTables &st,
+                       int planes, int plane0, StripClass &sc)
+{
+    const ClassPlan &c = p->cls[ci];
+    sc = StripClass{};
+    sc.hoff = c.hoff1; sc.hcoef = c.hcoef1;
+    sc.seginfo = st.seginfo; sc.emit = st.emit; sc.vcoef = st.vcoef;
+    sc.maxrows = st.maxrows; sc.nseg = st.nseg; sc.seg_rows = st.seg_rows;
+    sc.strips = c.ow;                                  // one column per lane
+    sc.planes = planes; sc.plane0 = plane0;
+    sc.n_items = n * planes * c.ow;
+    sc.ow = c.ow; sc.oh = c.oh; sc.src_stride = src_stride; sc.dst_stride = dst_stride;
+    sc.nblocks = uint32_t((sc.n_items + kBlock - 1) / kBlock) * uint32_t(st.nseg);
+    const int sub = ci ? 1 : 0;
+    const int plane_w = ceil_shift(p->g.in_w, sub), plane_h = ceil_shift(p->g.in_h, sub);
+    sc.src_begin_rel = uint32_t(p->g.pre_y >> sub) * uint32_t(src_stride) + uint32_t(p->g.pre_x >> sub);
+    sc.src_end_rel = uint32_t(plane_h - (p->g.pre_y >> sub) - 1) * uint32_t(src_stride) + uint32_t(plane_w - (p->g.pre_x >> sub));
+}
+
+// Row-segment length of a column-walk launch: as choose_segs (the longest segment <= 96 output rows
+// that leaves >= 3 workgroups per resident slot, else the shortest), at least `min_segs` segments.
+size_t choose_column_segs(const tts_plan *p, const int *cis, int ncls, int n, int planes_each[2], strip_fn fn, int min_segs)
+{
+    const size_t nopt = p->cls[cis[0]].segs.size();
+    const double slots = double(p->n_cus) * blocks_per_cu(fn, kBlock, 0);
+    size_t best = 0;
+    for (size_t i = 0; i < nopt; ++i) {
+        if (p->cls[cis[0]].segs[i].seg_rows > 96) break;
+        double blocks = 0;
+        for (int k = 0; k < ncls; ++k) {
+            const ClassPlan &c = p->cls[cis[k]];
+            blocks += double((int64_t(n) * planes_each[k] * c.ow + kBlock - 1) / kBlock) * c.segs[i].nseg;
+        }
+        if (i == 0 || blocks >= 3.0 * slots) best = i;
+    }
+    for (bool ok = false; !ok && best > 0; ) {
+        ok = true;
+        for (int k = 0; k < ncls; ++k) ok &= p->cls[cis[k]].segs[best].nseg >= min_segs;
+        if (!ok) --best;
+    }
+    return best;
+}
+
 // One launch set: frames [0, n) addressed by `addr` relative to (src, dst).
 // `only_plane` >= 0 restricts the launch set to that one plane (per-frame pointers whose planes lie
 // too far apart for one base + 32-bit offsets are processed plane by plane).
@@ -1238,9 +1483,45 @@ int launch_all(const tts_plan *p, const uint8_t *src, uint8_t *dst, int n, const
         if (merged) break;
     }
 
+    // column classes (9..64 taps): one launch when both classes run the same instantiation
+    bool to_generic[2] = {false, false};               // column classes this launch hands to the generic kernel instead
+    {
+        int col_cls[2], nc = 0;
+        for (int ci = 0; ci < 2; ++ci) {
+            const ClassPlan &c = p->cls[ci];
+            if (c.kind != 2 || !active(ci)) continue;
+            // (per-frame plane pointers: see the strip classes above; tiny sources likewise)
+            if (src_span < 4096u || (addr.use_table && c.oh <= c.segs[0].seg_rows)) to_generic[ci] = true;
+            else col_cls[nc++] = ci;
+        }
+        const bool cmerged = nc == 2 && !p->knobs.no_merge && pick_column(p->cls[0]) == pick_column(p->cls[1]);
+        for (int k = 0; k < nc; ++k) {
+            const int ci = col_cls[k];
+            strip_fn fn = pick_column(p->cls[ci]);
+            if (!fn) return TTS_ERR_UNSUPPORTED;
+            StripArgs a{};
+            a.src_span = src_span; a.dst_span = dst_span; a.addr = addr;
+            const int min_segs = addr.use_table ? 2 : 1;
+            if (cmerged) {
+                int planes_each[2] = {nplanes(0), nplanes(1)};
+                const size_t si = choose_column_segs(p, col_cls, 2, n, planes_each, fn, min_segs);
+                for (int j = 0; j < 2; ++j)
+                    fill_column_class(p, j, n, src_stride[j], dst_stride[j], p->cls[j].segs[si], nplanes(j), plane0(j), a.c[j]);
+            } else {
+                int planes_each[2] = {nplanes(ci), 0};
+                const size_t si = choose_column_segs(p, &ci, 1, n, planes_each, fn, min_segs);
+                fill_column_class(p, ci, n, src_stride[ci], dst_stride[ci], p->cls[ci].segs[si], nplanes(ci), plane0(ci), a.c[0]);
+                a.c[1] = a.c[0]; a.c[1].nblocks = 0;
+            }
+            const uint32_t blocks = a.c[0].nblocks + (cmerged ? a.c[1].nblocks : 0);
+            hipLaunchKernelGGL(fn, dim3(blocks), dim3(kBlock), 0, st, src, dst, p->d_tab, a);
+            if (cmerged) break;
+        }
+    }
+
     for (int ci = 0; ci < 2; ++ci) {
         const ClassPlan &c = p->cls[ci];
-        if (c.kind != 0 || !active(ci)) continue;
+        if (!(c.kind == 0 || to_generic[ci]) || !active(ci)) continue;
         GenericArgs a{};
         a.src = src; a.dst = dst;
         a.hpos = c.d_hpos; a.htaps = c.d_htaps; a.vpos = c.d_vpos; a.vtaps = c.d_vtaps;
@@ -1357,6 +1638,7 @@ int tts_plan_kernel_kind(const tts_plan *p, int plane_class)
     if (!p || plane_class < 0 || plane_class > 1) return TTS_ERR_INVALID_INPUT;
     const ClassPlan &c = p->cls[plane_class];
     if (c.kind == 0) return 0;
+    if (c.kind == 2) return 3 + c.col_dmas;
     return 1 + strip_choice(c, p->knobs).lds;
 }
 

@@ -16,6 +16,11 @@ CASES = {
     "4k": ("scale=1080:1920:force_original_aspect_ratio=increase,crop=1080:1920", 3840, 2160, 7050240),
     "720p": ("scale=1080:1920:force_original_aspect_ratio=increase,crop=1080:1920", 1280, 720, 3548880),
     "aligned": ("scale=1080:1920:force_original_aspect_ratio=increase,crop=1024:1920", 1920, 1080, 3882240),
+    # the reference's own thumbnail chain (src/services/video.js:329-332) on a 1080p / portrait 1080p / 4K source
+    "thumbref": ("scale=320x180:force_original_aspect_ratio=decrease,pad=320x180:-1:-1:color=black,format=yuv420p", 1920, 1080, 3110400 + 86400),
+    "thumbref_portrait": ("scale=320x180:force_original_aspect_ratio=decrease,pad=320x180:-1:-1:color=black,format=yuv420p", 1080, 1920, 3110400 + 86400),
+    "thumbref_4k": ("scale=320x180:force_original_aspect_ratio=decrease,pad=320x180:-1:-1:color=black,format=yuv420p", 3840, 2160, 12441600 + 86400),
+    "stretch": ("scale=w=720:h=1280", 480, 854, 614880 + 1382400),
     "thumb": ("scale=320:568:flags=area", 1080, 1920, 3383040),
 }
 
