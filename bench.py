@@ -54,7 +54,7 @@ def main():
     ap.add_argument("--frames", type=int, default=1200, help="frames per GPU per step")
     ap.add_argument("--settle", type=int, default=20,
                     help="untimed launches BEFORE the warm-up steps: back-to-back launch times drift 0.33 -> 0.42 -> 0.35 ms over "
-                         "the first ~30 launches of a burst while the clock governor settles (DESIGN.md 4.4); the metric is sustained rate")
+                         "the first ~30 launches of a burst while the clock governor settles (DESIGN.md 4.5); the metric is sustained rate")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     args = ap.parse_args()
 

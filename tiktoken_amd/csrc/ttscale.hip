@@ -331,7 +331,7 @@ __global__ __launch_bounds__(kBlock) void strip_kernel(const uint8_t *__restrict
 // k is read we wait, exactly, until only the operations issued after row k's DMA are outstanding
 // -- the DMAs of the D-1 later rows plus the stores issued since (counted at run time; gfx950
 // retires vector-memory operations in issue order).
-// What its speed depends on most is the output row pitch (tools/micro/pattern*.hip, DESIGN.md 4.4):
+// What its speed depends on most is the output row pitch (tools/micro/pattern*.hip, DESIGN.md 4.5):
 // 1080-byte rows run at 42 % of the HBM roofline (46 % paced), 1024-byte rows at 50-52 %.
 template <int V>
 __device__ __forceinline__ void wait_vm() { asm volatile("s_waitcnt vmcnt(%0)" ::"n"(V) : "memory"); }
