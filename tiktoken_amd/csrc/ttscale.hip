@@ -1107,7 +1107,13 @@ int build_class(const tts_geom &g, int sub, ClassPlan &c, std::vector<uint32_t> 
         const int dmas = lds_dmas(c, t, 1, lo.data(), 1, 2 * NTP);
         if (!dmas) return TTS_OK;
         c.kind = 2; c.NTP = NTP; c.Rc = Rc; c.col_dmas = dmas; c.hoff1 = hoff1; c.hcoef1 = hcoef1;
-        std::vector<int> opts(kSegOptions, kSegOptions + kNumSegOptions);
+        // Segment lengths on offer: the luma plane cut into 1..32 EQUAL parts (outputs here are small --
+        // a ragged last segment would be most of the tail), the same list for both classes, ascending.
+        std::vector<int> opts;
+        for (int parts : {32, 24, 16, 12, 10, 8, 6, 5, 4, 3, 2, 1}) {
+            const int sr = std::max(8, (g.crop_h + parts - 1) / parts);
+            if (opts.empty() || sr > opts.back()) opts.push_back(sr);
+        }
         const int forced = env_int("TTS_SEG_ROWS", 0);
         if (forced > 0) opts.assign(1, forced);
         for (int sr : opts) {
@@ -1380,21 +1386,21 @@ void fill_column_class(const tts_plan *p, int ci, int n, int src_stride, int dst
     sc.src_end_rel = uint32_t(plane_h - (p->g.pre_y >> sub) - 1) * uint32_t(src_stride) + uint32_t(plane_w - (p->g.pre_x >> sub));
 }
 
-// Row-segment length of a column-walk launch: as choose_segs (the longest segment <= 96 output rows
-// that leaves >= 3 workgroups per resident slot, else the shortest), at least `min_segs` segments.
+// Row-segment length of a column-walk launch: the longest segment on offer that leaves >= 1.5
+// workgroups per resident slot (every segment start re-reads taps - 1 source rows: 24 of 120 at
+// 16-row segments of the 1080p thumbnail), else the shortest; at least `min_segs` segments.
 size_t choose_column_segs(const tts_plan *p, const int *cis, int ncls, int n, int planes_each[2], strip_fn fn, int min_segs)
 {
     const size_t nopt = p->cls[cis[0]].segs.size();
     const double slots = double(p->n_cus) * blocks_per_cu(fn, kBlock, 0);
     size_t best = 0;
     for (size_t i = 0; i < nopt; ++i) {
-        if (p->cls[cis[0]].segs[i].seg_rows > 96) break;
         double blocks = 0;
         for (int k = 0; k < ncls; ++k) {
             const ClassPlan &c = p->cls[cis[k]];
             blocks += double((int64_t(n) * planes_each[k] * c.ow + kBlock - 1) / kBlock) * c.segs[i].nseg;
         }
-        if (i == 0 || blocks >= 3.0 * slots) best = i;
+        if (i == 0 || blocks >= 1.5 * slots) best = i;
     }
     for (bool ok = false; !ok && best > 0; ) {
         ok = true;

@@ -11,9 +11,10 @@ acc = defaultdict(lambda: defaultdict(list))
 for f in glob.glob(os.path.join(out, "p*", "**", "*counter_collection.csv"), recursive=True):
     for r in csv.DictReader(open(f)):
         k = r["Kernel_Name"]
-        if "strip_" not in k and "generic_kernel" not in k:
+        names = [n for n in ("strip_", "column_lds", "generic_kernel") if n in k]
+        if not names:
             continue
-        k = k[k.index("strip_") if "strip_" in k else 0:][:32]
+        k = k[k.index(names[0]):][:36]
         acc[k][r["Counter_Name"]].append(float(r["Counter_Value"]))
 lines = []
 for k, cs in acc.items():
