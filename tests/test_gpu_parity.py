@@ -369,6 +369,8 @@ COLUMN_CASES = [
     ("scale=320:180:flags=area", 3840, 2160, 2, 4),        # 12x area: 13 taps
     ("scale=20:12", 200, 120, 200, 4),                     # 20-column planes: 3-4 pieces per wave
     ("crop=1280:720:320:180,scale=160:90", 1920, 1080, 3, 4),   # pre-crop: windows start inside the rows
+    ("scale=720:1280", 2160, 3840, 1, 4),                  # web compress of a 4K portrait clip: 3x, 13 taps (8 tap pairs, ring of 16)
+    ("scale=480:270", 1920, 1080, 4, 4),                   # 4x: 17 taps -> 16 tap pairs
     ("scale=64:36", 1920, 1080, 2, 0),                     # 30x: 121 taps -> generic kernel
 ]
 

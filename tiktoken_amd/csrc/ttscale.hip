@@ -669,6 +669,15 @@ __global__ __launch_bounds__(kMaxLdsBlock, (G4 && R == 4) ? 8 : 4) void strip_ld
 template <int NDW>
 __device__ __forceinline__ void lds_read_dwords(uint32_t (&w)[NDW], uint32_t p);
 template <>
+[[maybe_unused]] __device__ __forceinline__ void lds_read_dwords<5>(uint32_t (&w)[5], uint32_t p)
+{
+    u32x2_t a, b; uint32_t e;
+    asm volatile("ds_read2_b32 %0, %3 offset1:1\n\tds_read2_b32 %1, %3 offset0:2 offset1:3\n\t"
+                 "ds_read_b32 %2, %3 offset:16\n\ts_waitcnt lgkmcnt(0)"
+                 : "=&v"(a), "=&v"(b), "=&v"(e) : "v"(p) : "memory");
+    w[0] = a.x; w[1] = a.y; w[2] = b.x; w[3] = b.y; w[4] = e;
+}
+template <>
 [[maybe_unused]] __device__ __forceinline__ void lds_read_dwords<9>(uint32_t (&w)[9], uint32_t p)
 {
     u32x2_t a, b, c, d; uint32_t e;
@@ -1087,7 +1096,9 @@ int build_class(const tts_geom &g, int sub, ClassPlan &c, std::vector<uint32_t> 
     if (!strip_ok) {
         // Many taps: the column walk, if the taps fit its windows and ring and the runs fit its slot.
         c.kind = 0;
-        const int NTP = HT <= 32 ? 16 : 32, Rc = VT <= 32 ? 32 : 64;
+        // three instantiations, by the larger tap count of the two axes: up to 16, 32, 64 taps
+        const int mt = std::max(HT, VT);
+        const int NTP = mt <= 16 ? 8 : mt <= 32 ? 16 : 32, Rc = 2 * NTP;
         if (HT > 64 || VT > 64 || c.src_w < 2 * NTP || !monotone(c.v.pos) || env_int("TTS_FORCE_GENERIC", 0)) return TTS_OK;
         HTables t;                                     // (only `strips` is used by lds_dmas)
         t.strips = c.ow;
@@ -1360,9 +1371,8 @@ void choose_segs(const tts_plan *p, const int *cis, int ncls, int n, int N, stri
 
 strip_fn pick_column(const ClassPlan &c)
 {
+    if (c.NTP == 8 && c.Rc == 16) return c.col_dmas == 1 ? column_lds_kernel<8, 16, 1> : column_lds_kernel<8, 16, 2>;
     if (c.NTP == 16 && c.Rc == 32) return c.col_dmas == 1 ? column_lds_kernel<16, 32, 1> : column_lds_kernel<16, 32, 2>;
-    if (c.NTP == 16 && c.Rc == 64) return c.col_dmas == 1 ? column_lds_kernel<16, 64, 1> : column_lds_kernel<16, 64, 2>;
-    if (c.NTP == 32 && c.Rc == 32) return c.col_dmas == 1 ? column_lds_kernel<32, 32, 1> : column_lds_kernel<32, 32, 2>;
     if (c.NTP == 32 && c.Rc == 64) return c.col_dmas == 1 ? column_lds_kernel<32, 64, 1> : column_lds_kernel<32, 64, 2>;
     return nullptr;
 }

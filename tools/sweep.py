@@ -20,6 +20,9 @@ CASES = {
     "thumbref": ("scale=320x180:force_original_aspect_ratio=decrease,pad=320x180:-1:-1:color=black,format=yuv420p", 1920, 1080, 3110400 + 86400),
     "thumbref_portrait": ("scale=320x180:force_original_aspect_ratio=decrease,pad=320x180:-1:-1:color=black,format=yuv420p", 1080, 1920, 3110400 + 86400),
     "thumbref_4k": ("scale=320x180:force_original_aspect_ratio=decrease,pad=320x180:-1:-1:color=black,format=yuv420p", 3840, 2160, 12441600 + 86400),
+    # web compress (portrait.test.js:70-97): a 1080x1920 phone clip into the 720x1280 box; 2160x3840 likewise
+    "web": ("scale=720:1280", 1080, 1920, 3110400 + 1382400),
+    "web_4k": ("scale=720:1280", 2160, 3840, 12441600 + 1382400),
     "stretch": ("scale=w=720:h=1280", 480, 854, 614880 + 1382400),
     "thumb": ("scale=320:568:flags=area", 1080, 1920, 3383040),
 }
