@@ -67,7 +67,7 @@ typedef struct tts_plan tts_plan;
  *   src/services/video.js:329-332    "scale=320x180:force_original_aspect_ratio=decrease,
  *                                     pad=320x180:-1:-1:color=black,format=yuv420p"
  *   web/src/tests/video/portrait.test.js:78,95-96,146  "scale=W:H", "min(720,...", decrease
- * Accepted filters: scale, crop, pad, format=yuv420p.
+ * Accepted filters: scale (bicubic | area | bilinear), crop, pad, format=yuv420p | yuvj420p, setsar.
  */
 int tts_parse_vf(const char *vf, int iw, int ih, tts_geom *out);
 
@@ -85,7 +85,8 @@ int tts_plan_geom(const tts_plan *p, tts_geom *out);
  * Run n_frames frames through the plan, asynchronously on hip_stream (a hipStream_t,
  * NULL = default stream).  Replaces the per-frame scale/crop/pad loop of the ffmpeg
  * child (scripts/processVideos.js:71-108).  Frames must be TTS_MEM_DEVICE; the caller
- * owns every buffer and nothing is allocated here.
+ * owns every buffer and nothing is allocated here.  Planes may lie anywhere (every plane its
+ * own allocation, any stride >= width; U and V strides equal); nothing outside a plane is read.
  */
 int tts_run(const tts_plan *p, const tts_frame *src, const tts_frame *dst, int n_frames, void *hip_stream);
 

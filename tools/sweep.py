@@ -23,6 +23,8 @@ CASES = {
     # web compress (portrait.test.js:70-97): a 1080x1920 phone clip into the 720x1280 box; 2160x3840 likewise
     "web": ("scale=720:1280", 1080, 1920, 3110400 + 1382400),
     "web_4k": ("scale=720:1280", 2160, 3840, 12441600 + 1382400),
+    "half": ("scale=1920:1080", 3840, 2160, 12441600 + 3110400),        # 4K -> 1080p, 2x: 9 taps
+    "third": ("scale=1280:720", 3840, 2160, 12441600 + 1382400),        # 4K -> 720p, 3x: 13 taps
     "stretch": ("scale=w=720:h=1280", 480, 854, 614880 + 1382400),
     "thumb": ("scale=320:568:flags=area", 1080, 1920, 3383040),
 }
