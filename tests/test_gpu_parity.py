@@ -121,6 +121,10 @@ def test_row_segmentation_is_invisible(tts, oracle, monkeypatch, seg):
     (THUMB_REF, 1920, 1080, 3, False),
     (THUMB_REF, 1283, 721, 1, "planewise"),
     ("scale=20:12", 200, 120, 40, False),                   # 12-row planes: single segment -> generic kernel in pointer mode
+    # source planes too small for a staged run to be slid inside them: 24 / 12-byte rows, 6 / 3-row planes
+    ("scale=136:96", 24, 60, 33, False),
+    ("scale=320:200", 200, 6, 33, False),
+    ("scale=20:4", 200, 6, 33, False),
 ])
 def test_frame_pointer_api_matches_batch_api(tts, oracle, monkeypatch, vf, iw, ih, n, pad):
     """tts_run with per-frame plane pointers (every plane its own allocation, padded or tight strides)

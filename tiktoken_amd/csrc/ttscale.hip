@@ -1468,8 +1468,13 @@ int launch_all(const tts_plan *p, const uint8_t *src, uint8_t *dst, int n, const
         // Per-frame plane pointers: a segment of the LDS-staged kernel must not hold both the first and
         // the last source row of a plane (see the kernel), so planes shorter than two of the shortest
         // segments take the register kernel; taller ones are cut into at least two segments below.
+        // (source planes under 48 bytes a row or 32 rows likewise: a run slid down from the plane's end
+        // must still begin inside the plane)
         bool short_plane = false;
-        for (int j = 0; j < ns; ++j) short_plane |= p->cls[strip_cls[j]].oh <= p->cls[strip_cls[j]].segs[0].seg_rows;
+        for (int j = 0; j < ns; ++j) {
+            const ClassPlan &cj = p->cls[strip_cls[j]];
+            short_plane |= cj.oh <= cj.segs[0].seg_rows || cj.src_w < 48 || cj.src_h < 32;
+        }
         if (src_span < 4096u || (addr.use_table && short_plane)) { ch.lds = 0; ch.depth = 1; ch.LW = p->cls[ci].LW; }
         strip_fn fn = pick_strip(ch, p->knobs);
         if (!fn) return TTS_ERR_UNSUPPORTED;
@@ -1507,7 +1512,7 @@ int launch_all(const tts_plan *p, const uint8_t *src, uint8_t *dst, int n, const
             const ClassPlan &c = p->cls[ci];
             if (c.kind != 2 || !active(ci)) continue;
             // (per-frame plane pointers: see the strip classes above; tiny sources likewise)
-            if (src_span < 4096u || (addr.use_table && c.oh <= c.segs[0].seg_rows)) to_generic[ci] = true;
+            if (src_span < 4096u || (addr.use_table && (c.oh <= c.segs[0].seg_rows || c.src_w < 48 || c.src_h < 32))) to_generic[ci] = true;
             else col_cls[nc++] = ci;
         }
         const bool cmerged = nc == 2 && !p->knobs.no_merge && pick_column(p->cls[0]) == pick_column(p->cls[1]);
