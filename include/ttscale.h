@@ -99,6 +99,30 @@ int tts_run_batch(const tts_plan *p, const void *src, size_t src_frame_pitch,
                   void *dst, size_t dst_frame_pitch, int n_frames, void *hip_stream);
 
 /*
+ * Time-domain steps as frame indices (host only, no device call).  A frame i of a constant-rate clip
+ * has timestamp i * fps_den / fps_num and belongs to `-ss start -t duration` when that lies in
+ * [start, start + duration); duration < 0 = to the end.
+ *   tts_trim_range  replaces `.seekInput(start).duration(d)` / `-ss`, `-t`
+ *                   (scripts/processVideos.js:84-92, scripts/loopVideos.js:42-52).
+ *   tts_loop_order  replaces createLoopedVideo (scripts/loopVideos.js:54-100): initial [0, start) +
+ *                   repeats x [start, start + duration) + end [start + duration, n), joined by the concat
+ *                   demuxer.  order == NULL: returns the number of output frames; else fills order[0..cap)
+ *                   and returns the count.  (The script's `crossfade: 0.5` is never read -- :55 -- so
+ *                   there is no blend step to replace.)
+ */
+int tts_trim_range(int n_frames, int fps_num, int fps_den, double start, double duration, int *first, int *count);
+int tts_loop_order(int n_frames, int fps_num, int fps_den, double extract_start, double extract_duration,
+                   int repeats, int32_t *order, int cap);
+
+/*
+ * tts_run_batch through a frame order (host array): output frame j = the plan applied to source frame
+ * order[j].  A trimmed or looped clip is scaled straight from the original frames; no segment is
+ * copied out first (the reference writes three temporary files, scripts/loopVideos.js:56-74).
+ */
+int tts_run_batch_order(const tts_plan *p, const void *src, size_t src_frame_pitch, int n_src_frames,
+                        void *dst, size_t dst_frame_pitch, const int32_t *order, int n_out, void *hip_stream);
+
+/*
  * Convenience for callers that hold host memory (the CLI, the Node addon): allocates
  * staging buffers, copies in, runs, copies out, synchronises.  Packed I420 as above.
  */

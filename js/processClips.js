@@ -3,7 +3,7 @@
 // of clips with the issues to fix, one clip after another, the same per-clip report.  The reference
 // decodes and encodes through ffmpeg; here clips are raw yuv420p files and only the steps that touch
 // pixels or frame counts happen: resize (`.size('720x1280')` when the clip is smaller, :96,:126) and
-// trim (`targetDuration`, `trimStart`, :74-83).  Codec issues are reported and left to the host codec.
+// trim (`targetDuration`, `trimStart`, :84-92).  Codec issues are reported and left to the host codec.
 //
 //   node js/processClips.js manifest.json [outDir]
 //   manifest: { "clip.yuv": { width, height, fps, issues: ["resolution","duration"], targetDuration, trimStart, newName } }
@@ -25,20 +25,12 @@ function probe(file, meta) {
 
 function transcodeClip(inputPath, outputPath, meta, options) {
   return new Promise((resolve, reject) => {
-    const fps = meta.fps || 30;
-    const frame = ffmpeg.frameBytes(meta.width, meta.height);
-    let src = inputPath;
-    if (options.duration !== undefined || options.trimStart) {          // frame-accurate trim on the raw file
-      const all = fs.readFileSync(inputPath);
-      const first = Math.round((options.trimStart || 0) * fps);
-      const count = options.duration !== undefined ? Math.round(options.duration * fps) : all.length / frame - first;
-      src = outputPath + '.trim.tmp';
-      fs.writeFileSync(src, all.slice(first * frame, (first + count) * frame));
-    }
-    let command = ffmpeg(src).inputSize(meta.width, meta.height);
-    if (options.scale) command = command.size(`${TARGET.width}x${TARGET.height}`);
-    const done = (err) => { if (src !== inputPath) fs.unlinkSync(src); err ? reject(err) : resolve(); };
-    command.on('end', () => done()).on('error', done).save(outputPath);
+    // the reference's own call chain (scripts/processVideos.js:71-108): trim options first, then size
+    let command = ffmpeg(inputPath).inputSize(meta.width, meta.height).inputFPS(meta.fps || 30);
+    if (options.duration !== undefined) command = command.duration(options.duration);   // :85-87
+    if (options.trimStart) command = command.seekInput(options.trimStart);             // :90-92
+    if (options.scale) command = command.size(`${TARGET.width}x${TARGET.height}`);  // :96
+    command.on('end', () => resolve()).on('error', reject).save(outputPath);
   });
 }
 
@@ -49,7 +41,7 @@ async function processClip(dir, outDir, filename, config) {
   const needsResize = (config.issues || []).includes('resolution') && (stream.width < TARGET.width || stream.height < TARGET.height);
   const needsTrim = (config.issues || []).includes('duration') && config.targetDuration;
   await transcodeClip(inputPath, outputPath, config, {
-    duration: needsTrim ? Math.min(config.targetDuration, parseFloat(stream.duration) - (config.trimStart || 0)) : undefined,
+    duration: needsTrim ? config.targetDuration : undefined,                        // :131
     trimStart: config.trimStart,
     scale: needsResize,
   });

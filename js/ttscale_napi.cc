@@ -5,6 +5,8 @@
 //   parseVf(vf, iw, ih)            -> { in_w, in_h, sc_w, ..., out_w, out_h }
 //   frameBytes(w, h)               -> bytes of a packed I420 frame
 //   runHost(vf, iw, ih, srcBuffer) -> Buffer with the processed frames (packed I420)
+//   trimRange(nFrames, fpsNum, fpsDen, start, duration)             -> { first, count }   (duration < 0: to the end)
+//   loopOrder(nFrames, fpsNum, fpsDen, start, duration, repeats)    -> [source frame of every output frame]
 // Errors are thrown as Error whose message carries INVALID_INPUT / INVALID_FORMAT /
 // INITIALIZATION_FAILED / PROCESSING_FAILED (web/src/tests/video/compression.test.js:62-90).
 #include <node_api.h>
@@ -98,12 +100,59 @@ napi_value RunHost(napi_env env, napi_callback_info info)
     return out;
 }
 
+// scripts/loopVideos.js:42-52 (`.seekInput(start).duration(d)`) and :54-100 (createLoopedVideo) as frame numbers
+bool timeline_args(napi_env env, napi_callback_info info, size_t want, int32_t *ints, double *dbl)
+{
+    size_t argc = want; napi_value argv[6];
+    if (napi_get_cb_info(env, info, &argc, argv, nullptr, nullptr) != napi_ok || argc < want) return false;
+    for (int i = 0; i < 3; ++i) if (napi_get_value_int32(env, argv[i], &ints[i]) != napi_ok) return false;
+    for (int i = 0; i < 2; ++i) if (napi_get_value_double(env, argv[3 + i], &dbl[i]) != napi_ok) return false;
+    if (want > 5 && napi_get_value_int32(env, argv[5], &ints[3]) != napi_ok) return false;
+    return true;
+}
+
+napi_value TrimRange(napi_env env, napi_callback_info info)
+{
+    int32_t a[4]; double d[2];
+    if (!timeline_args(env, info, 5, a, d)) return throw_status(env, "trimRange(nFrames, fpsNum, fpsDen, start, duration)", TTS_ERR_INVALID_INPUT);
+    int first = 0, count = 0;
+    const int rc = tts_trim_range(a[0], a[1], a[2], d[0], d[1], &first, &count);
+    if (rc) return throw_status(env, "trim range", rc);
+    napi_value obj, v;
+    napi_create_object(env, &obj);
+    napi_create_int32(env, first, &v); napi_set_named_property(env, obj, "first", v);
+    napi_create_int32(env, count, &v); napi_set_named_property(env, obj, "count", v);
+    return obj;
+}
+
+napi_value LoopOrder(napi_env env, napi_callback_info info)
+{
+    int32_t a[4]; double d[2];
+    if (!timeline_args(env, info, 6, a, d)) return throw_status(env, "loopOrder(nFrames, fpsNum, fpsDen, start, duration, repeats)", TTS_ERR_INVALID_INPUT);
+    const int n = tts_loop_order(a[0], a[1], a[2], d[0], d[1], a[3], nullptr, 0);
+    if (n < 0) return throw_status(env, "loop order", n);
+    std::string buf(size_t(n) * sizeof(int32_t), '\0');
+    int32_t *order = reinterpret_cast<int32_t *>(&buf[0]);
+    const int got = tts_loop_order(a[0], a[1], a[2], d[0], d[1], a[3], order, n);
+    if (got < 0) return throw_status(env, "loop order", got);
+    napi_value arr;
+    napi_create_array_with_length(env, size_t(got), &arr);
+    for (int i = 0; i < got; ++i) {
+        napi_value v;
+        napi_create_int32(env, order[i], &v);
+        napi_set_element(env, arr, uint32_t(i), v);
+    }
+    return arr;
+}
+
 napi_value Init(napi_env env, napi_value exports)
 {
     napi_property_descriptor props[] = {
         {"parseVf", nullptr, ParseVf, nullptr, nullptr, nullptr, napi_default, nullptr},
         {"frameBytes", nullptr, FrameBytes, nullptr, nullptr, nullptr, napi_default, nullptr},
         {"runHost", nullptr, RunHost, nullptr, nullptr, nullptr, napi_default, nullptr},
+        {"trimRange", nullptr, TrimRange, nullptr, nullptr, nullptr, napi_default, nullptr},
+        {"loopOrder", nullptr, LoopOrder, nullptr, nullptr, nullptr, napi_default, nullptr},
     };
     napi_define_properties(env, exports, sizeof(props) / sizeof(props[0]), props);
     return exports;

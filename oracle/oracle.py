@@ -104,3 +104,27 @@ def run_chain(geom, frames):
                                  d, d + ow * oh, d + ow * oh + ocw * och, ow, ocw, ocw)
         assert rc == 0
     return out
+
+
+# ---- time-domain steps (no pixels): which source frames a trimmed / looped clip holds ---------------
+
+def segment_frames(n_frames, fps, start, duration=None):
+    """Frames a `ffmpeg -ss start -i clip -t duration` extraction keeps (scripts/loopVideos.js:42-52,
+    scripts/processVideos.js:84-92): those whose timestamp i/fps lies in [start, start+duration).
+    Exact rational arithmetic, one frame at a time."""
+    from fractions import Fraction
+    fps, start = Fraction(fps).limit_denominator(1001 * 64), Fraction(start).limit_denominator(10 ** 6)
+    end = None if duration is None else start + Fraction(duration).limit_denominator(10 ** 6)
+    return [i for i in range(n_frames) if Fraction(i) / fps >= start and (end is None or Fraction(i) / fps < end)]
+
+
+def loop_order(n_frames, fps, extract_start, extract_duration, repeats):
+    """createLoopedVideo (scripts/loopVideos.js:54-100) as a list of source frame numbers: the three
+    extractions of :62, :66, :73 and the concat list of :77-81."""
+    loop = segment_frames(n_frames, fps, extract_start, extract_duration)
+    initial = segment_frames(n_frames, fps, 0, extract_start)
+    from fractions import Fraction
+    input_duration = Fraction(n_frames) / Fraction(fps).limit_denominator(1001 * 64)
+    end_duration = input_duration - (Fraction(extract_start).limit_denominator(10 ** 6) + Fraction(extract_duration).limit_denominator(10 ** 6))
+    end = segment_frames(n_frames, fps, extract_start + extract_duration, float(end_duration)) if end_duration > 0 else []
+    return initial + loop * repeats + end

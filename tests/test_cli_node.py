@@ -117,6 +117,46 @@ v.compress({type: 'video/mp4', width: 360, height: 640, data: fs.readFileSync(%r
     assert np.array_equal(got, oracle.run_chain(tts.parse_vf("scale=720:1280", 360, 640), src))
 
 
+@needs_node
+def test_loop_clips_driver(tts, oracle, tmp_path):
+    """js/loopClips.js on a manifest shaped like VIDEOS_TO_EXTEND (scripts/loopVideos.js:11-34): the clip
+    is replaced by initial + repeats x loop + end; no GPU involved (no pixel changes)."""
+    clip = synth.frames("random", 32, 18, 30)
+    (tmp_path / "birds_demo.yuv").write_bytes(clip.tobytes())
+    manifest = {
+        "birds_demo.yuv": {"width": 32, "height": 18, "fps": 5, "currentLength": 6, "targetLength": 10,
+                           "loopStrategy": {"extractStart": 3, "extractDuration": 2, "repeats": 3, "crossfade": 0.5}},
+        "missing.yuv": {"width": 32, "height": 18, "loopStrategy": {"extractStart": 0, "extractDuration": 1, "repeats": 2}},
+    }
+    (tmp_path / "manifest.json").write_text(json.dumps(manifest))
+    r = subprocess.run([NODE, os.path.join(ROOT, "js", "loopClips.js"), str(tmp_path / "manifest.json")], capture_output=True, text=True)
+    assert r.returncode == 0, r.stderr
+    rep = json.loads(r.stdout)
+    assert rep["birds_demo.yuv"] == {"frames": 50, "duration": "10.000000"} and "error" in rep["missing.yuv"]
+    got = np.frombuffer((tmp_path / "birds_demo.yuv").read_bytes(), np.uint8).reshape(50, -1)
+    assert np.array_equal(got, clip[oracle.loop_order(30, 5, 3, 2, 3)])
+    assert not (tmp_path / "extended_birds_demo.yuv").exists()
+
+
+@needs_node
+def test_shim_segment_extraction(tts, oracle, tmp_path):
+    """ffmpeg(path).seekInput(start).duration(d).output(out).on('end').on('error').run(), the call chain of
+    extractLoopSegment (scripts/loopVideos.js:42-52), on a raw clip at an NTSC rate."""
+    clip = synth.frames("random", 32, 18, 60)
+    (tmp_path / "in.yuv").write_bytes(clip.tobytes())
+    js = """
+const ffmpeg = require(%r);
+ffmpeg(%r).inputSize(32, 18).inputFPS(29.97).seekInput(0.5).duration(1)
+  .output(%r).on('end', () => console.log('END')).on('error', (e) => { console.log('ERR ' + e.message); process.exit(1); }).run();
+""" % (os.path.join(ROOT, "js"), str(tmp_path / "in.yuv"), str(tmp_path / "seg.yuv"))
+    r = subprocess.run([NODE, "-e", js], capture_output=True, text=True)
+    assert r.returncode == 0 and "END" in r.stdout, r.stdout + r.stderr
+    want = oracle.segment_frames(60, 30000 / 1001, 0.5, 1)
+    assert want == list(range(15, 45))
+    got = np.frombuffer((tmp_path / "seg.yuv").read_bytes(), np.uint8).reshape(len(want), -1)
+    assert np.array_equal(got, clip[want])
+
+
 @pytest.mark.gpu
 @needs_node
 def test_process_clips_batch_driver(tts, oracle, tmp_path):

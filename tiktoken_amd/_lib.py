@@ -33,6 +33,12 @@ SYMBOLS = {
     "tts_run": (ctypes.c_int, [ctypes.c_void_p, ctypes.POINTER(Frame), ctypes.POINTER(Frame), ctypes.c_int, ctypes.c_void_p]),
     "tts_run_batch": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_size_t, ctypes.c_void_p,
                                      ctypes.c_size_t, ctypes.c_int, ctypes.c_void_p]),
+    "tts_trim_range": (ctypes.c_int, [ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_double, ctypes.c_double,
+                                      ctypes.POINTER(ctypes.c_int), ctypes.POINTER(ctypes.c_int)]),
+    "tts_loop_order": (ctypes.c_int, [ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_double, ctypes.c_double,
+                                      ctypes.c_int, ctypes.c_void_p, ctypes.c_int]),
+    "tts_run_batch_order": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_size_t, ctypes.c_int, ctypes.c_void_p,
+                                           ctypes.c_size_t, ctypes.c_void_p, ctypes.c_int, ctypes.c_void_p]),
     "tts_run_host": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_int]),
     "tts_plan_filter": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_int, ctypes.c_int, ctypes.POINTER(ctypes.c_int),
                                        ctypes.POINTER(ctypes.c_int), ctypes.c_void_p, ctypes.c_void_p]),

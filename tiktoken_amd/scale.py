@@ -37,6 +37,35 @@ def build_filter(src, dst, one, alg):
     return coef, pos
 
 
+def _fps(fps):
+    from fractions import Fraction
+    f = Fraction(fps).limit_denominator(1001 * 64)
+    return f.numerator, f.denominator
+
+
+def trim_range(n_frames, fps, start, duration=None):
+    """(first, count) of `-ss start -t duration` on an n_frames clip (scripts/processVideos.js:84-92)."""
+    num, den = _fps(fps)
+    first, count = ctypes.c_int(), ctypes.c_int()
+    check(_lib.lib().tts_trim_range(n_frames, num, den, float(start), -1.0 if duration is None else float(duration),
+                                    ctypes.byref(first), ctypes.byref(count)))
+    return first.value, count.value
+
+
+def loop_order(n_frames, fps, extract_start, extract_duration, repeats):
+    """Source frame of every output frame of createLoopedVideo (scripts/loopVideos.js:54-100)."""
+    num, den = _fps(fps)
+    n = _lib.lib().tts_loop_order(n_frames, num, den, float(extract_start), float(extract_duration), repeats, None, 0)
+    if n < 0:
+        check(n)
+    order = np.zeros(n, np.int32)
+    got = _lib.lib().tts_loop_order(n_frames, num, den, float(extract_start), float(extract_duration), repeats,
+                                    order.ctypes.data_as(ctypes.c_void_p), n)
+    if got < 0:
+        check(got)
+    return order
+
+
 class Plan:
     """Immutable per-geometry state (coefficient tables in HBM on the current device)."""
 
@@ -107,6 +136,23 @@ class Plan:
             stream = torch.cuda.current_stream(src.device).cuda_stream
         check(_lib.lib().tts_run_batch(self._h, src.data_ptr(), self.in_bytes, dst.data_ptr(), self.out_bytes, n,
                                        ctypes.c_void_p(stream)))
+        return dst
+
+    def run_batch_order(self, src, order, dst=None, stream=None):
+        """Like run_batch, but output frame j comes from source frame order[j] (trimmed / looped clips)."""
+        import torch
+        if not (src.is_cuda and src.dtype == torch.uint8 and src.is_contiguous()) or src.numel() % self.in_bytes:
+            raise TtsError(-1, "src must be a contiguous uint8 CUDA tensor of whole frames")
+        order = np.ascontiguousarray(order, dtype=np.int32)
+        n_src, n = src.numel() // self.in_bytes, int(order.size)
+        if dst is None:
+            dst = torch.empty((n, self.out_bytes), dtype=torch.uint8, device=src.device)
+        if not (dst.is_cuda and dst.dtype == torch.uint8 and dst.is_contiguous() and dst.numel() == n * self.out_bytes):
+            raise TtsError(-1, "dst must be a contiguous uint8 CUDA tensor of n*out_bytes")
+        if stream is None:
+            stream = torch.cuda.current_stream(src.device).cuda_stream
+        check(_lib.lib().tts_run_batch_order(self._h, src.data_ptr(), self.in_bytes, n_src, dst.data_ptr(), self.out_bytes,
+                                             order.ctypes.data_as(ctypes.c_void_p), n, ctypes.c_void_p(stream)))
         return dst
 
     def run_frames(self, src_planes, dst_planes, src_strides, dst_strides, stream=None):
