@@ -149,6 +149,10 @@ int tts_build_filter(int src, int dst, int one, int alg, int *taps, int16_t *coe
  * gathers, 2 / 3 = LDS-staged strip walk with one / two LDS-DMAs per source row, 4 / 5 = column walk
  * (9..64 taps per axis) with one / two LDS-DMAs per source row. */
 int tts_plan_kernel_kind(const tts_plan *p, int plane_class);
+/* The same with the template arguments, for logs and tests: "strip_lds<6,6,grouped,1,1>" = window bytes,
+ * ring rows, grouped (one window per 4 columns) or percolumn windows, LDS-DMAs per row, rows in flight.
+ * Valid until the calling thread's next call. */
+const char *tts_plan_kernel_name(const tts_plan *p, int plane_class);
 
 size_t tts_frame_bytes(int w, int h);          /* packed I420 size of a w x h frame */
 const char *tts_strerror(int status);

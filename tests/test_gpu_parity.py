@@ -283,6 +283,54 @@ LDS_CASES = [
 ]
 
 
+# Grouped 12-byte windows (5-6 taps, ratios up to 4/3): (chain, iw, ih, frames, expected luma kernel)
+GROUPED6_CASES = [
+    ("scale=1080:1920:force_original_aspect_ratio=increase,crop=1080:1920", 3840, 2160, 2, "strip_lds<6,6,grouped,1,1>"),   # BASELINE config 4
+    ("scale=3413:1920,crop=1080:1920", 3840, 2160, 1, "strip_lds<6,6,grouped,1,1>"),
+    ("scale=640:ih", 720, 96, 5, "strip_lds<6,4,grouped,1,1>"),       # 1.125x horizontally only: ring of 4
+    ("scale=640:320", 720, 400, 3, "strip_lds<6,6,grouped,1,1>"),     # whole width: the last group sits against the row end
+    ("scale=600:300", 720, 400, 3, "strip_lds<6,6,grouped,1,1>"),     # 1.2x
+    ("scale=540:300", 720, 400, 3, "strip_lds<6,6,grouped,1,1>"),     # exactly 4/3: the fourth column's first tap is byte 4
+    ("scale=640:250", 720, 400, 3, "strip_lds<6,8,grouped,1,1>"),     # 1.6x vertically: ring of 8
+    ("scale=520:300", 720, 400, 3, "strip_lds<6,6,percolumn,1,1>"),   # 1.38x: four columns' windows pass 12 bytes
+]
+
+
+@pytest.mark.parametrize("vf,iw,ih,n,name", GROUPED6_CASES)
+def test_grouped_12_byte_windows(tts, oracle, vf, iw, ih, n, name):
+    import torch
+    plan = tts.Plan.from_vf(vf, iw, ih)
+    assert plan.kernel_name(0) == name
+    for pat in ("random", "impulse"):
+        src = synth.frames(pat, iw, ih, n)
+        got = plan.run_batch(torch.from_numpy(src).cuda()).cpu().numpy()
+        assert np.array_equal(got, oracle.run_chain(plan.geom, src)), pat
+
+
+def test_grouped_12_byte_windows_pointer_api(tts, oracle):
+    """Whole-width 1.125x downscale through tts_run, every plane its own tight allocation: the last group's
+    window hangs over the row's end, and the staged runs must still end with the plane."""
+    import torch
+    iw, ih, n = 720, 400, 5
+    plan = tts.Plan.from_vf("scale=640:320", iw, ih)
+    assert "grouped" in plan.kernel_name(0)
+    ow, oh = plan.out_size
+    src = synth.frames("random", iw, ih, n)
+    want = oracle.run_chain(plan.geom, src)
+    keep, sp, ss, dp, ds = [], [], [], [], []
+    for i in range(n):
+        planes = [torch.from_numpy(np.ascontiguousarray(pl)).cuda() for pl in synth.split(src[i], iw, ih)]
+        outs = [torch.full((oh if k == 0 else (oh + 1) // 2, ow if k == 0 else (ow + 1) // 2), 7, dtype=torch.uint8, device="cuda") for k in range(3)]
+        keep += planes + outs
+        sp.append([t.data_ptr() for t in planes]); ss.append([t.shape[1] for t in planes])
+        dp.append(outs); ds.append([t.shape[1] for t in outs])
+    plan.run_frames(sp, [[t.data_ptr() for t in o] for o in dp], ss, ds)
+    torch.cuda.synchronize()
+    for i in range(n):
+        for k, w in enumerate(synth.split(want[i], ow, oh)):
+            assert np.array_equal(dp[i][k].cpu().numpy(), w), (i, k)
+
+
 @pytest.mark.parametrize("vf,iw,ih,n,kind", LDS_CASES)
 def test_lds_kernel_variants(tts, oracle, vf, iw, ih, n, kind):
     import torch
@@ -296,11 +344,12 @@ def test_lds_kernel_variants(tts, oracle, vf, iw, ih, n, kind):
 
 
 @pytest.mark.parametrize("knob,val", [("TTS_PACED", "1"), ("TTS_PACED", "0"), ("TTS_LDS_BLOCK", "64"), ("TTS_LDS_BLOCK", "704"),
-                                      ("TTS_STRIP_D", "2"), ("TTS_NO_LDS", "1"), ("TTS_NO_G4", "1"), ("TTS_NO_MERGE", "1")])
+                                      ("TTS_STRIP_D", "2"), ("TTS_NO_LDS", "1"), ("TTS_NO_G4", "1"), ("TTS_NO_G6", "1"), ("TTS_NO_MERGE", "1")])
 def test_tuning_knobs_do_not_change_pixels(tts, oracle, monkeypatch, knob, val):
     import torch
     monkeypatch.setenv(knob, val)
-    for vf, iw, ih in (("scale=355:267", 200, 150), ("scale=120:90:flags=area", 200, 150), ("scale=136:96", 100, 60)):
+    for vf, iw, ih in (("scale=355:267", 200, 150), ("scale=120:90:flags=area", 200, 150), ("scale=136:96", 100, 60),
+                       ("scale=176:132", 200, 150)):
         plan = tts.Plan.from_vf(vf, iw, ih)
         src = synth.frames("random", iw, ih, 21)
         got = plan.run_batch(torch.from_numpy(src).cuda()).cpu().numpy()

@@ -45,6 +45,7 @@ SYMBOLS = {
     "tts_build_filter": (ctypes.c_int, [ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_int,
                                         ctypes.POINTER(ctypes.c_int), ctypes.c_void_p, ctypes.c_void_p]),
     "tts_plan_kernel_kind": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_int]),
+    "tts_plan_kernel_name": (ctypes.c_char_p, [ctypes.c_void_p, ctypes.c_int]),
     "tts_frame_bytes": (ctypes.c_size_t, [ctypes.c_int, ctypes.c_int]),
     "tts_strerror": (ctypes.c_char_p, [ctypes.c_int]),
     "tts_last_error": (ctypes.c_char_p, []),

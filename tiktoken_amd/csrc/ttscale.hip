@@ -73,6 +73,7 @@ struct StripClass {
     int32_t  paced;                // LDS-staged kernel: strip-major workgroup order + barrier before every row's store
     uint32_t src_begin_rel;        // bytes from a plane's first byte to its (pre-cropped) origin
     uint32_t src_end_rel;          // bytes from a plane's (pre-cropped) origin to one past its last byte
+    uint32_t src_row_rel;          // bytes from that origin to the end of its row
 };
 
 struct StripArgs {
@@ -363,6 +364,12 @@ struct Win3 { u32x2_t lo; uint32_t hi; };
                  "s_waitcnt lgkmcnt(0)"                                                                           \
                  : "=&v"(w[0][0]), "=&v"(w[0][1]), "=&v"(w[0][2]), "=&v"(w[1][0]), "=&v"(w[1][1]), "=&v"(w[1][2])   \
                  : "v"(p[0]), "v"(p[1]), "n"(off) : "memory")
+// two windows of four aligned dwords (grouped 12-byte windows at any byte phase)
+#define TTS_LDS_READ_WIN4_X2(w, p)                                                                                \
+    asm volatile("ds_read2_b32 %0, %4 offset1:1\n\tds_read2_b32 %1, %4 offset0:2 offset1:3\n\t"                     \
+                 "ds_read2_b32 %2, %5 offset1:1\n\tds_read2_b32 %3, %5 offset0:2 offset1:3\n\t"                     \
+                 "s_waitcnt lgkmcnt(0)"                                                                           \
+                 : "=&v"(w[0][0]), "=&v"(w[0][1]), "=&v"(w[1][0]), "=&v"(w[1][1]) : "v"(p[0]), "v"(p[1]) : "memory")
 [[maybe_unused]] __device__ __forceinline__ void lds_read_win3(Win3 (&w)[8], const uint32_t (&p)[8])
 {
     asm volatile("ds_read2_b32 %0, %16 offset1:1\n\tds_read_b32 %1, %16 offset:8\n\t"
@@ -452,10 +459,11 @@ __device__ __forceinline__ void plan_runs(const StripArgs &a, const StripClass &
 // LW-byte window per column; NDMA: 1 KiB LDS-DMAs per source row (the wave's runs hold <= 64 * NDMA
 // sixteen-byte chunks).  Eight columns per lane.
 template <int LW, int R, bool G4, int NDMA, int D>
-__global__ __launch_bounds__(kMaxLdsBlock, (G4 && R == 4) ? 8 : 4) void strip_lds_kernel(const uint8_t *__restrict__ src, uint8_t *__restrict__ dst,
+__global__ __launch_bounds__(kMaxLdsBlock, (G4 && R == 4 && LW == 4) ? 8 : 4) void strip_lds_kernel(const uint8_t *__restrict__ src, uint8_t *__restrict__ dst,
                                                                                const uint32_t *__restrict__ tab, const StripArgs a)
 {
-    static_assert(R % 2 == 0 && (LW == 4 || LW == 6 || LW == 8) && (!G4 || LW == 4) && (NDMA == 1 || NDMA == 2), "see strip_kernel");
+    static_assert(R % 2 == 0 && (LW == 4 || LW == 6 || LW == 8) && (!G4 || LW == 4 || LW == 6) && (NDMA == 1 || NDMA == 2), "see strip_kernel");
+    static_assert(!(G4 && LW == 6) || D == 1, "the 12-byte group reader addresses slot 0 only");
     static_assert(D >= 1 && R % D == 0, "D source rows in flight, one LDS slot each, rotating with the ring");
 #if defined(__HIP_DEVICE_COMPILE__)   // the LDS-DMA builtin exists in the device pass only
     constexpr int N = 8;
@@ -514,15 +522,17 @@ __global__ __launch_bounds__(kMaxLdsBlock, (G4 && R == 4) ? 8 : 4) void strip_ld
         }
     }
 
-    constexpr uint32_t kWin = G4 ? 8u : uint32_t(LW);
+    constexpr uint32_t kWin = G4 ? (LW == 4 ? 8u : 12u) : uint32_t(LW);   // grouped: one 8- / 12-byte window per 4 columns
     const int rstart = int(uni(tab[c.seginfo + 2 * seg]));
     const int nrows  = int(uni(tab[c.seginfo + 2 * seg + 1]));
     const int src_stride = int(uni(uint32_t(c.src_stride)));
     const uint32_t row0_off = uint32_t(rstart) * uint32_t(src_stride);
     uint32_t csrc[NDMA];
     uint32_t lbase;
-    plan_runs<NDMA>(a, c, off[0] + row0_off, off[NW - 1] + kWin + row0_off, soff, lane > 0 && strip == 0 && live, lane,
-                    uint32_t(nrows - 1) * uint32_t(src_stride), csrc, lbase);
+    // (a 12-byte group window may hang over the row's end by the bytes its taps do not use: the run stops
+    // at the row's end, and what the window read picks up behind it meets zero taps)
+    plan_runs<NDMA>(a, c, off[0] + row0_off, min(off[NW - 1] + kWin, soff + c.src_row_rel) + row0_off, soff,
+                    lane > 0 && strip == 0 && live, lane, uint32_t(nrows - 1) * uint32_t(src_stride), csrc, lbase);
 
     const uint32_t lds_wave = uint32_t(reinterpret_cast<uintptr_t>((lds_void_t *)&lds[wave][0][0]));   // LDS byte address
     uint32_t lpos[NW];                               // aligned LDS address of each window's first dword
@@ -585,8 +595,14 @@ __global__ __launch_bounds__(kMaxLdsBlock, (G4 && R == 4) ? 8 : 4) void strip_ld
 #pragma unroll
             for (int r = 0; r < D; ++r) younger += hist[r];
             wait_vm_plus<(D - 1) * NDMA>(younger);
-            uint32_t wk[NW][3];                                 // the aligned dwords holding each window
-            if constexpr (G4) {
+            constexpr int GD = G4 && LW == 6 ? 4 : 3;
+            uint32_t wk[NW][GD];                                // the aligned dwords holding each window
+            if constexpr (G4 && LW == 6) {
+                u32x2_t wv[NW][2];
+                TTS_LDS_READ_WIN4_X2(wv, lpos);
+#pragma unroll
+                for (int j = 0; j < NW; ++j) { wk[j][0] = wv[j][0].x; wk[j][1] = wv[j][0].y; wk[j][2] = wv[j][1].x; wk[j][3] = wv[j][1].y; }
+            } else if constexpr (G4) {
                 TTS_LDS_READ_WIN3_X2(wk, lpos, (s % D) * kSlotBytes);
             } else if constexpr (LW > 4) {
                 static_assert(G4 || D == 1, "per-column readers address slot 0 only");
@@ -600,12 +616,11 @@ __global__ __launch_bounds__(kMaxLdsBlock, (G4 && R == 4) ? 8 : 4) void strip_ld
 #pragma unroll
                 for (int j = 0; j < NW; ++j) { wk[j][0] = wv[j].x; wk[j][1] = wv[j].y; wk[j][2] = 0; }
             }
-            if constexpr (G4) {                                 // rebuild the two 8-byte windows
+            if constexpr (G4) {                                 // rebuild the two 8- / 12-byte windows
 #pragma unroll
-                for (int j = 0; j < NW; ++j) {
-                    wk[j][0] = __builtin_amdgcn_alignbyte(wk[j][1], wk[j][0], phase[j]);
-                    wk[j][1] = __builtin_amdgcn_alignbyte(wk[j][2], wk[j][1], phase[j]);
-                }
+                for (int j = 0; j < NW; ++j)
+#pragma unroll
+                    for (int q = 0; q + 1 < GD; ++q) wk[j][q] = __builtin_amdgcn_alignbyte(wk[j][q + 1], wk[j][q], phase[j]);
             }
             // the slot is free again (its bytes sit in registers): request row k + D into it
 #pragma unroll
@@ -618,6 +633,8 @@ __global__ __launch_bounds__(kMaxLdsBlock, (G4 && R == 4) ? 8 : 4) void strip_ld
                 if constexpr (G4) {
                     acc = dot2(__builtin_amdgcn_perm(wk[i / 4][1], wk[i / 4][0], sel[i][0]), hc[i][0], acc);
                     acc = dot2(__builtin_amdgcn_perm(wk[i / 4][1], wk[i / 4][0], sel[i][1]), hc[i][1], acc);
+                    // taps 4, 5 sit four bytes on: the first selector again, one dword further
+                    if constexpr (LW == 6) acc = dot2(__builtin_amdgcn_perm(wk[i / 4][2], wk[i / 4][1], sel[i][0]), hc[i][2], acc);
                 } else {
 #pragma unroll
                     for (int tp = 0; tp < LW / 2; ++tp)         // taps 2tp, 2tp+1 sit at bytes o + 2 (tp % 2) of dwords tp / 2, tp / 2 + 1
@@ -936,6 +953,9 @@ struct HTables {
     int lds_g4 = 0, lds_col = 0;                   // LDS-staged kernel: 1 KiB DMAs per row it needs with grouped /
                                                    // per-column windows (0 = not usable)
     uint32_t hoff6 = 0, hcoef6 = 0;                // 5-6 taps: 6-byte windows for the LDS-staged kernel (3 tap pairs a column)
+    bool g6 = false;                               // 5-6 taps, mild downscale: grouped 12-byte windows (LDS-staged kernel only)
+    uint32_t hoff6g = 0, hsel6g = 0, hcoef6g = 0;
+    int lds_g6 = 0;
 };
 
 struct ClassPlan {
@@ -1211,6 +1231,42 @@ int build_class(const tts_geom &g, int sub, ClassPlan &c, std::vector<uint32_t> 
             for (int i = 0; i < ncols; ++i) lo[i] = int(tab[t.hoff + i]);
         }
         t.lds_col = lds_dmas(c, t, N, lo.data(), N, c.LWlds);
+        // 5-6 taps at ratios up to 4/3 (4K -> portrait is 1.125): four columns' windows fit 12 bytes, and one
+        // 4-dword read per group replaces four 3-dword reads.  Tap j of a column whose first tap is byte d of
+        // the group window is picked out of the dword pair (j/4, j/4 + 1): d + j - 4 (j/4) must stay <= 7.
+        t.g6 = c.LWlds == 6 && c.src_w >= 12 && !env_int("TTS_NO_G4", 0) && !env_int("TTS_NO_G6", 0);
+        if (t.g6) {
+            auto column = [&](int i) { return c.x0 + std::min(std::min((i / N) * N, std::max(c.ow - N, 0)) + i % N, c.ow - 1); };
+            std::vector<int> glo(ncols / 4);
+            for (int q = 0; q < ncols / 4 && t.g6; ++q) {
+                glo[q] = c.h.pos[column(4 * q)];        // not pulled back from the row's end: see the kernel's run bounds
+                for (int j = 0; j < 4 && t.g6; ++j) {
+                    const int d = c.h.pos[column(4 * q + j)] - glo[q];
+                    if (d < 0 || d + HT > 12) t.g6 = false;
+                    for (int k = 0; k < HT && t.g6; ++k)
+                        if (d + k - 4 * (k / 4) > 7) t.g6 = false;
+                }
+            }
+            if (t.g6) {
+                t.hoff6g = uint32_t(tab.size());
+                tab.resize(tab.size() + ncols / 4);
+                t.hsel6g = uint32_t(tab.size());
+                tab.resize(tab.size() + size_t(ncols) * 2);
+                t.hcoef6g = uint32_t(tab.size());
+                tab.resize(tab.size() + size_t(ncols) * 3, 0);
+                for (int i = 0; i < ncols; ++i) {
+                    const int vx = column(i);
+                    const uint32_t d = uint32_t(c.h.pos[vx] - glo[i / 4]);
+                    int16_t t6[6] = {0, 0, 0, 0, 0, 0};
+                    for (int j = 0; j < HT; ++j) t6[j] = c.h.taps[size_t(vx) * HT + j];
+                    if (i % 4 == 0) tab[t.hoff6g + i / 4] = uint32_t(glo[i / 4]);
+                    tab[t.hsel6g + 2 * size_t(i)]     = 0x0c000c00u | d | ((d + 1) << 16);
+                    tab[t.hsel6g + 2 * size_t(i) + 1] = 0x0c000c00u | (d + 2) | ((d + 3) << 16);
+                    for (int k = 0; k < 3; ++k) tab[t.hcoef6g + 3 * size_t(i) + k] = pack16(t6[2 * k], t6[2 * k + 1]);
+                }
+                t.lds_g6 = lds_dmas(c, t, N, glo.data(), N / 4, 12);
+            }
+        }
     }
     std::vector<int> opts(kSegOptions, kSegOptions + kNumSegOptions);
     const int forced = env_int("TTS_SEG_ROWS", 0);
@@ -1231,7 +1287,7 @@ void free_class(ClassPlan &c)
 typedef void (*strip_fn)(const uint8_t *, uint8_t *, const uint32_t *, const StripArgs);
 
 // lds: LDS-DMAs per row of the LDS-staged kernel, 0 = register kernel; depth: its source rows in flight
-struct StripChoice { int LW, R, N; bool g4; int lds; int depth; };
+struct StripChoice { int LW, R, N; bool g4; int lds; int depth; bool g6 = false; };
 
 StripChoice strip_choice(const ClassPlan &c, const Knobs &kn)
 {
@@ -1242,6 +1298,7 @@ StripChoice strip_choice(const ClassPlan &c, const Knobs &kn)
     ch.lds = t.g4 ? t.lds_g4 : t.lds_col;
     if (t.g4 && ch.lds != 1) { ch.lds = t.lds_col; if (ch.lds) ch.g4 = false; }   // grouped windows ride in one DMA only
     if (ch.lds && !ch.g4) ch.LW = c.LWlds;
+    if (!ch.g4 && t.g6 && t.lds_g6 == 1) { ch.g4 = ch.g6 = true; ch.lds = 1; ch.LW = 6; }   // (LDS-staged kernel only)
     if (ch.lds && ch.g4 && ch.R == 4) ch.depth = kn.strip_d == 2 ? 2 : 1;
     return ch;
 }
@@ -1249,10 +1306,11 @@ StripChoice strip_choice(const ClassPlan &c, const Knobs &kn)
 strip_fn pick_strip(const StripChoice &ch, const Knobs &kn)
 {
     const int D = kn.strip_d;                          // rows in flight of the register kernels (tuning knob)
-    if (ch.lds && ch.g4) {
+    if (ch.lds && ch.g4 && !ch.g6) {
         if (ch.R == 4) return ch.depth == 2 ? strip_lds_kernel<4, 4, true, 1, 2> : strip_lds_kernel<4, 4, true, 1, 1>;
         return ch.R == 6 ? strip_lds_kernel<4, 6, true, 1, 1> : strip_lds_kernel<4, 8, true, 1, 1>;
     }
+    if (ch.lds && ch.g6) return ch.R == 4 ? strip_lds_kernel<6, 4, true, 1, 1> : ch.R == 6 ? strip_lds_kernel<6, 6, true, 1, 1> : strip_lds_kernel<6, 8, true, 1, 1>;
     if (ch.lds) {
 #define TTS_LDS_PICK(LW_, R_) (ch.lds == 1 ? strip_lds_kernel<LW_, R_, false, 1, 1> : strip_lds_kernel<LW_, R_, false, 2, 1>)
         if (ch.LW == 4) return ch.R == 4 ? TTS_LDS_PICK(4, 4) : ch.R == 6 ? TTS_LDS_PICK(4, 6) : TTS_LDS_PICK(4, 8);
@@ -1280,6 +1338,7 @@ void fill_strip_class(const tts_plan *p, int ci, int n, int N, bool g4, int lw, 
     const HTables &t = c.ht[N == 16];
     sc.hoff = g4 ? t.hoff4 : t.hoff; sc.hcoef = g4 ? t.hcoef4 : t.hcoef; sc.hsel = t.hsel4;
     if (!g4 && lw == 6) { sc.hoff = t.hoff6; sc.hcoef = t.hcoef6; }
+    if (g4 && lw == 6) { sc.hoff = t.hoff6g; sc.hcoef = t.hcoef6g; sc.hsel = t.hsel6g; }
     sc.seginfo = st.seginfo; sc.emit = st.emit; sc.vcoef = st.vcoef;
     sc.maxrows = st.maxrows; sc.nseg = st.nseg; sc.seg_rows = st.seg_rows;
     sc.strips = t.strips;
@@ -1293,6 +1352,8 @@ void fill_strip_class(const tts_plan *p, int ci, int n, int N, bool g4, int lw, 
         const int plane_w = ceil_shift(p->g.in_w, sub), plane_h = ceil_shift(p->g.in_h, sub);
         sc.src_begin_rel = uint32_t(p->g.pre_y >> sub) * uint32_t(src_stride) + uint32_t(p->g.pre_x >> sub);
         sc.src_end_rel = uint32_t(plane_h - (p->g.pre_y >> sub) - 1) * uint32_t(src_stride) + uint32_t(plane_w - (p->g.pre_x >> sub));
+    sc.src_row_rel = uint32_t(plane_w - (p->g.pre_x >> sub));
+        sc.src_row_rel = uint32_t(plane_w - (p->g.pre_x >> sub));
     }
 }
 
@@ -1475,7 +1536,7 @@ int launch_all(const tts_plan *p, const uint8_t *src, uint8_t *dst, int n, const
             const ClassPlan &cj = p->cls[strip_cls[j]];
             short_plane |= cj.oh <= cj.segs[0].seg_rows || cj.src_w < 48 || cj.src_h < 32;
         }
-        if (src_span < 4096u || (addr.use_table && short_plane)) { ch.lds = 0; ch.depth = 1; ch.LW = p->cls[ci].LW; }
+        if (src_span < 4096u || (addr.use_table && short_plane)) { ch.lds = 0; ch.depth = 1; ch.LW = p->cls[ci].LW; if (ch.g6) ch.g4 = ch.g6 = false; }
         strip_fn fn = pick_strip(ch, p->knobs);
         if (!fn) return TTS_ERR_UNSUPPORTED;
         size_t si[2];
@@ -1661,6 +1722,21 @@ int tts_plan_kernel_kind(const tts_plan *p, int plane_class)
     if (c.kind == 0) return 0;
     if (c.kind == 2) return 3 + c.col_dmas;
     return 1 + strip_choice(c, p->knobs).lds;
+}
+
+const char *tts_plan_kernel_name(const tts_plan *p, int plane_class)
+{
+    static thread_local char buf[96];
+    if (!p || plane_class < 0 || plane_class > 1) return "";
+    const ClassPlan &c = p->cls[plane_class];
+    if (c.kind == 0) std::snprintf(buf, sizeof buf, "generic");
+    else if (c.kind == 2) std::snprintf(buf, sizeof buf, "column_lds<%d,%d,%d>", c.NTP, c.Rc, c.col_dmas);
+    else {
+        const StripChoice ch = strip_choice(c, p->knobs);
+        if (ch.lds) std::snprintf(buf, sizeof buf, "strip_lds<%d,%d,%s,%d,%d>", ch.LW, ch.R, ch.g4 ? "grouped" : "percolumn", ch.lds, ch.depth);
+        else std::snprintf(buf, sizeof buf, "strip<%d,%d,%d,%s>", ch.LW, ch.R, ch.N, ch.g4 ? "grouped" : "percolumn");
+    }
+    return buf;
 }
 
 size_t tts_frame_bytes(int w, int h)

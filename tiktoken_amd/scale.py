@@ -109,6 +109,9 @@ class Plan:
     def kernel_kind(self, plane_class):
         return _lib.lib().tts_plan_kernel_kind(self._h, plane_class)
 
+    def kernel_name(self, plane_class):
+        return _lib.lib().tts_plan_kernel_name(self._h, plane_class).decode()
+
     def filter(self, plane_class, axis):
         """(taps[n_out, size] int16, pos[n_out] int32) of one plane class / axis."""
         taps, n = ctypes.c_int(), ctypes.c_int()
