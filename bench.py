@@ -108,9 +108,7 @@ def main():
         fps = world * n * args.steps / wall
         # A step is ONE launch of the strip kernel (luma and chroma planes ride in one grid), so its
         # average launch duration is the event time per step and a launch moves a whole step's bytes.
-        span = 0xFF000000                          # bytes one launch addresses (include/ttscale.h): longer batches are cut
-        per_launch = 1 + min((span - plan.in_bytes) // plan.in_bytes, (span - plan.out_bytes) // plan.out_bytes)
-        launches = -(-n // per_launch)
+        launches = 1                               # (tts_run_batch covers a batch of any length with one launch)
         launch_ms = dev_ms / args.steps / launches
         algo_bytes_launch = ALGO_BYTES_PER_FRAME * n / launches
         achieved = algo_bytes_launch / (launch_ms * 1e-3) / 1e9

@@ -393,10 +393,13 @@ def test_pointer_api_shuffled_placements(tts, oracle):
                 assert np.array_equal(dp[i][k].cpu().numpy(), w), "rep %d frame %d plane %d" % (rep, i, k)
 
 
-def test_batch_longer_than_one_launch_span(tts, oracle):
-    """1,500 frames of 1080x1920 (4.7 GB of source) exceed the 32-bit offset span of one launch:
-    tts_run_batch cuts the batch into launches; every frame must still come out right."""
+@pytest.mark.parametrize("chunks", [0, 1])
+def test_batch_longer_than_32_bit_offsets(tts, oracle, monkeypatch, chunks):
+    """1,500 frames of 1080x1920 (4.7 GB of source) pass what 32-bit lane offsets reach from one base:
+    every wave addresses from its own first frame (one launch), or -- TTS_SPAN_CHUNKS=1, the path kept for
+    huge frame pitches -- the batch is cut into launches; every frame must come out right either way."""
     import torch
+    monkeypatch.setenv("TTS_SPAN_CHUNKS", str(chunks))
     iw, ih, n, distinct = 1080, 1920, 1500, 6
     plan = tts.Plan.from_vf("scale=320:568:flags=area", iw, ih)
     assert n * plan.in_bytes > 0xFF000000
@@ -407,6 +410,25 @@ def test_batch_longer_than_one_launch_span(tts, oracle):
     torch.cuda.synchronize()
     idx = torch.arange(n, device="cuda") % distinct
     assert bool((out == want[idx]).all())
+
+
+def test_more_planes_than_grid_z(tts, oracle):
+    """40,000 tiny frames with a pad and a range step: the fill / range kernels index planes by grid.z
+    (65,535 at most), so the launch is repeated over frame ranges."""
+    import torch
+    iw, ih, n, distinct = 16, 16, 40000, 5
+    plan = tts.Plan.from_vf("scale=24:20,pad=32:24:-1:-1:color=white,format=yuvj420p", iw, ih)
+    base = synth.frames("random", iw, ih, distinct)
+    want = torch.from_numpy(oracle.run_chain(plan.geom, base)).cuda()
+    src = torch.from_numpy(base).cuda().repeat(n // distinct, 1).contiguous()
+    out = plan.run_batch(src)
+    assert bool((out == want[torch.arange(n, device="cuda") % distinct]).all())
+    # the generic kernel likewise
+    plan = tts.Plan.from_vf("scale=2:2", iw, ih)
+    assert plan.kernel_name(0) == "generic"
+    want = torch.from_numpy(oracle.run_chain(plan.geom, base)).cuda()
+    out = plan.run_batch(src)
+    assert bool((out == want[torch.arange(n, device="cuda") % distinct]).all())
 
 
 # The column walk (9..64 taps per axis): (chain, iw, ih, frames, expected kernel kind of the luma class); 4 / 5 = one /

@@ -58,6 +58,7 @@ struct FrameAddr {
     uint32_t src_pitch, dst_pitch;            // packed mode: bytes between frames
     uint32_t src_plane[3], dst_plane[3];      // packed mode: plane origin inside a frame
     int32_t  use_table;                        // table mode: explicit per-frame offsets
+    int32_t  wave_base;                        // packed mode: spans pass kMaxSpan, waves address from their own first frame
     uint32_t src_tab[3][kMaxTableFrames];
     uint32_t dst_tab[3][kMaxTableFrames];
 };
@@ -78,7 +79,7 @@ struct StripClass {
 
 struct StripArgs {
     StripClass c[2];
-    uint32_t src_span, dst_span;   // bytes reachable from the base pointers (buffer range check)
+    uint64_t src_span, dst_span;   // bytes reachable from the base pointers (buffer range check)
     FrameAddr addr;
 };
 
@@ -90,6 +91,33 @@ __device__ __forceinline__ int dot2(uint32_t a, uint32_t b, int c)
 }
 
 __device__ __forceinline__ uint32_t uni(uint32_t v) { return uint32_t(__builtin_amdgcn_readfirstlane(int(v))); }
+
+// Where this lane's plane lies.  Lane offsets are 32-bit, a launch is not: in packed mode every wave
+// addresses from ITS first frame (lanes are ordered by frame, so that is lane 0's; the host checks that
+// the few frames a wave's 64 items can touch fit kMaxSpan), with the buffer range cut to what is left of
+// the launch's span from there.  Table mode: offsets from the launch's bases, as given.
+// Call with all lanes active.
+__device__ __forceinline__ void frame_offsets(const StripArgs &a, int plane, int frame, const uint8_t *&src, uint8_t *&dst,
+                                              uint32_t &src_rec, uint32_t &dst_rec, uint32_t &soff, uint32_t &doff)
+{
+    if (a.addr.use_table) {
+        soff = a.addr.src_tab[plane][frame];
+        doff = a.addr.dst_tab[plane][frame];
+        src_rec = uint32_t(a.src_span); dst_rec = uint32_t(a.dst_span);
+    } else if (!a.addr.wave_base) {                  // the whole launch lies within kMaxSpan of its bases
+        soff = uint32_t(frame) * a.addr.src_pitch + a.addr.src_plane[plane];
+        doff = uint32_t(frame) * a.addr.dst_pitch + a.addr.dst_plane[plane];
+        src_rec = uint32_t(a.src_span); dst_rec = uint32_t(a.dst_span);
+    } else {
+        const uint32_t f0 = uni(uint32_t(frame));
+        const uint64_t so = uint64_t(f0) * a.addr.src_pitch, dof = uint64_t(f0) * a.addr.dst_pitch;
+        src += so; dst += dof;
+        src_rec = a.src_span > so ? uint32_t(min(a.src_span - so, uint64_t(kMaxSpan))) : 0u;
+        dst_rec = a.dst_span > dof ? uint32_t(min(a.dst_span - dof, uint64_t(kMaxSpan))) : 0u;
+        soff = (uint32_t(frame) - f0) * a.addr.src_pitch + a.addr.src_plane[plane];
+        doff = (uint32_t(frame) - f0) * a.addr.dst_pitch + a.addr.dst_plane[plane];
+    }
+}
 
 // Blocks are dealt round-robin over the 8 XCDs; give each XCD a contiguous run of
 // logical blocks so neighbouring strips and row segments share one L2.
@@ -200,14 +228,10 @@ __global__ __launch_bounds__(kBlock) void strip_kernel(const uint8_t *__restrict
     const int fp    = g / c.strips;
     const int plane = c.plane0 + fp % c.planes;
     const int frame = fp / c.planes;
-    uint32_t soff, doff;
-    if (a.addr.use_table) {
-        soff = a.addr.src_tab[plane][frame];
-        doff = a.addr.dst_tab[plane][frame];
-    } else {
-        soff = uint32_t(frame) * a.addr.src_pitch + a.addr.src_plane[plane];
-        doff = uint32_t(frame) * a.addr.dst_pitch + a.addr.dst_plane[plane];
-    }
+    uint32_t soff, doff, src_rec, dst_rec;
+    const uint8_t *wsrc = src;                       // this wave's bases
+    uint8_t *wdst = dst;
+    frame_offsets(a, plane, frame, wsrc, wdst, src_rec, dst_rec, soff, doff);
     doff += uint32_t(min(strip * N, max(c.ow - N, 0)));      // the last strip is slid left, not cut short
 
     // per-lane horizontal tables stay in registers for the whole walk
@@ -246,9 +270,9 @@ __global__ __launch_bounds__(kBlock) void strip_kernel(const uint8_t *__restrict
 
     // Buffer addressing: wave-uniform descriptor + per-lane 32-bit byte offset + scalar row
     // offset, so a row step costs no vector instructions; reads past the span return 0.
-    const __amdgpu_buffer_rsrc_t srs = __builtin_amdgcn_make_buffer_rsrc(const_cast<uint8_t *>(src), 0, a.src_span, 0x00020000);
-    const uint64_t dbase = reinterpret_cast<uint64_t>(dst);
-    const u32x4_t drs = {uni(uint32_t(dbase)), uni(uint32_t(dbase >> 32) & 0xffffu), uni(a.dst_span), 0x00020000u};
+    const __amdgpu_buffer_rsrc_t srs = __builtin_amdgcn_make_buffer_rsrc(const_cast<uint8_t *>(wsrc), 0, src_rec, 0x00020000);
+    const uint64_t dbase = reinterpret_cast<uint64_t>(wdst);
+    const u32x4_t drs = {uni(uint32_t(dbase)), uni(uint32_t(dbase >> 32) & 0xffffu), uni(dst_rec), 0x00020000u};
 
     // D source rows are kept in flight so a row's bytes are requested D iterations before use.
     uint32_t w[D][RW::NL][RW::WD];
@@ -490,14 +514,10 @@ __global__ __launch_bounds__(kMaxLdsBlock, (G4 && R == 4 && LW == 4) ? 8 : 4) vo
 
     const int plane = c.plane0 + fp % c.planes;
     const int frame = fp / c.planes;
-    uint32_t soff, doff;
-    if (a.addr.use_table) {
-        soff = a.addr.src_tab[plane][frame];
-        doff = a.addr.dst_tab[plane][frame];
-    } else {
-        soff = uint32_t(frame) * a.addr.src_pitch + a.addr.src_plane[plane];
-        doff = uint32_t(frame) * a.addr.dst_pitch + a.addr.dst_plane[plane];
-    }
+    uint32_t soff, doff, src_rec, dst_rec;
+    const uint8_t *wsrc = src;                       // this wave's bases
+    uint8_t *wdst = dst;
+    frame_offsets(a, plane, frame, wsrc, wdst, src_rec, dst_rec, soff, doff);
     doff += uint32_t(min(strip * N, c.ow - N));              // the last strip is slid left, not cut short
     // Dead lanes run the same instruction stream (so the wave's store count stays uniform) with an
     // offset past the end of the buffer: the descriptor's range check discards their stores.
@@ -565,9 +585,9 @@ __global__ __launch_bounds__(kMaxLdsBlock, (G4 && R == 4 && LW == 4) ? 8 : 4) vo
     const int last_y = c.oh - 1;
     const bool bar = c.paced != 0;
 
-    const __amdgpu_buffer_rsrc_t srs = __builtin_amdgcn_make_buffer_rsrc(const_cast<uint8_t *>(src), 0, a.src_span, 0x00020000);
-    const uint64_t dbase = reinterpret_cast<uint64_t>(dst);
-    const u32x4_t drs = {uni(uint32_t(dbase)), uni(uint32_t(dbase >> 32) & 0xffffu), uni(a.dst_span), 0x00020000u};
+    const __amdgpu_buffer_rsrc_t srs = __builtin_amdgcn_make_buffer_rsrc(const_cast<uint8_t *>(wsrc), 0, src_rec, 0x00020000);
+    const uint64_t dbase = reinterpret_cast<uint64_t>(wdst);
+    const u32x4_t drs = {uni(uint32_t(dbase)), uni(uint32_t(dbase >> 32) & 0xffffu), uni(dst_rec), 0x00020000u};
 
 #pragma unroll
     for (int r = 0; r < D; ++r)
@@ -746,14 +766,10 @@ __global__ __launch_bounds__(kBlock) void column_lds_kernel(const uint8_t *__res
 
     const int plane = c.plane0 + fp % c.planes;
     const int frame = fp / c.planes;
-    uint32_t soff, doff;
-    if (a.addr.use_table) {
-        soff = a.addr.src_tab[plane][frame];
-        doff = a.addr.dst_tab[plane][frame];
-    } else {
-        soff = uint32_t(frame) * a.addr.src_pitch + a.addr.src_plane[plane];
-        doff = uint32_t(frame) * a.addr.dst_pitch + a.addr.dst_plane[plane];
-    }
+    uint32_t soff, doff, src_rec, dst_rec;
+    const uint8_t *wsrc = src;                       // this wave's bases
+    uint8_t *wdst = dst;
+    frame_offsets(a, plane, frame, wsrc, wdst, src_rec, dst_rec, soff, doff);
     doff += uint32_t(col);
     if (!live) doff = kDiscard;                    // see strip_lds_kernel
 
@@ -785,9 +801,9 @@ __global__ __launch_bounds__(kBlock) void column_lds_kernel(const uint8_t *__res
     int y = seg * c.seg_rows;
     const int dst_stride = int(uni(uint32_t(c.dst_stride)));
 
-    const __amdgpu_buffer_rsrc_t srs = __builtin_amdgcn_make_buffer_rsrc(const_cast<uint8_t *>(src), 0, a.src_span, 0x00020000);
-    const uint64_t dbase = reinterpret_cast<uint64_t>(dst);
-    const u32x4_t drs = {uni(uint32_t(dbase)), uni(uint32_t(dbase >> 32) & 0xffffu), uni(a.dst_span), 0x00020000u};
+    const __amdgpu_buffer_rsrc_t srs = __builtin_amdgcn_make_buffer_rsrc(const_cast<uint8_t *>(wsrc), 0, src_rec, 0x00020000);
+    const uint64_t dbase = reinterpret_cast<uint64_t>(wdst);
+    const u32x4_t drs = {uni(uint32_t(dbase)), uni(uint32_t(dbase >> 32) & 0xffffu), uni(dst_rec), 0x00020000u};
 
 #pragma unroll
     for (int d = 0; d < NDMA; ++d)
@@ -841,6 +857,7 @@ struct GenericArgs {
     int32_t x0, y0, ow, oh;
     int32_t src_stride, dst_stride;
     int32_t planes, plane0;
+    int32_t frame0;                    // first frame of this launch (grid.z holds at most 65535 planes)
     FrameAddr addr;
 };
 
@@ -850,14 +867,14 @@ __global__ __launch_bounds__(kBlock) void generic_kernel(const GenericArgs a)
     const int y  = int(blockIdx.y) * 4 + int(threadIdx.x >> 6);
     const int fp = int(blockIdx.z);
     if (x >= a.ow || y >= a.oh) return;
-    const int plane = a.plane0 + fp % a.planes, frame = fp / a.planes;
-    uint32_t soff, doff;
+    const int plane = a.plane0 + fp % a.planes, frame = a.frame0 + fp / a.planes;
+    size_t soff, doff;
     if (a.addr.use_table) {
         soff = a.addr.src_tab[plane][frame];
         doff = a.addr.dst_tab[plane][frame];
     } else {
-        soff = uint32_t(frame) * a.addr.src_pitch + a.addr.src_plane[plane];
-        doff = uint32_t(frame) * a.addr.dst_pitch + a.addr.dst_plane[plane];
+        soff = size_t(frame) * a.addr.src_pitch + a.addr.src_plane[plane];
+        doff = size_t(frame) * a.addr.dst_pitch + a.addr.dst_plane[plane];
     }
     const int vx = a.x0 + x, vy = a.y0 + y;
     const int hp = a.hpos[vx], vp = a.vpos[vy];
@@ -883,6 +900,7 @@ struct FillArgs {
     int32_t px, py, pw, ph;            // picture rectangle that is left alone
     int32_t planes, plane0;
     int32_t fill[3];
+    int32_t frame0;
     uint32_t origin;                   // bytes from the canvas origin to the picture origin
     FrameAddr addr;                    // dst side only (plane origins point at the picture)
 };
@@ -893,9 +911,9 @@ __global__ __launch_bounds__(kBlock) void fill_kernel(const FillArgs a)
     const int y  = int(blockIdx.y) * 4 + int(threadIdx.x >> 6);
     const int fp = int(blockIdx.z);
     if (x >= a.w || y >= a.h) return;
-    const int plane = a.plane0 + fp % a.planes, frame = fp / a.planes;
-    const uint32_t doff = (a.addr.use_table ? a.addr.dst_tab[plane][frame]
-                                            : uint32_t(frame) * a.addr.dst_pitch + a.addr.dst_plane[plane]) - a.origin;
+    const int plane = a.plane0 + fp % a.planes, frame = a.frame0 + fp / a.planes;
+    const size_t doff = (a.addr.use_table ? size_t(a.addr.dst_tab[plane][frame])
+                                          : size_t(frame) * a.addr.dst_pitch + a.addr.dst_plane[plane]) - a.origin;
     uint8_t *row = a.dst + doff + size_t(y) * size_t(a.stride);
     const uint8_t f = uint8_t(a.fill[plane]);
     const bool in_rows = y >= a.py && y < a.py + a.ph;
@@ -909,6 +927,7 @@ struct RangeArgs {
     uint8_t *dst;
     int32_t w, h, stride;              // canvas of this plane class
     int32_t planes, plane0;
+    int32_t frame0;
     uint32_t origin;                   // bytes from the canvas origin to the picture origin
     FrameAddr addr;
     uint8_t lut[256];
@@ -920,9 +939,9 @@ __global__ __launch_bounds__(kBlock) void range_kernel(const RangeArgs a)
     const int y  = int(blockIdx.y) * 4 + int(threadIdx.x >> 6);
     const int fp = int(blockIdx.z);
     if (x >= a.w || y >= a.h) return;
-    const int plane = a.plane0 + fp % a.planes, frame = fp / a.planes;
-    const uint32_t doff = (a.addr.use_table ? a.addr.dst_tab[plane][frame]
-                                            : uint32_t(frame) * a.addr.dst_pitch + a.addr.dst_plane[plane]) - a.origin;
+    const int plane = a.plane0 + fp % a.planes, frame = a.frame0 + fp / a.planes;
+    const size_t doff = (a.addr.use_table ? size_t(a.addr.dst_tab[plane][frame])
+                                          : size_t(frame) * a.addr.dst_pitch + a.addr.dst_plane[plane]) - a.origin;
     uint8_t *row = a.dst + doff + size_t(y) * size_t(a.stride);
     for (int i = x; i < min(x + 4, a.w); ++i) row[i] = a.lut[row[i]];
 }
@@ -1003,6 +1022,7 @@ struct Knobs {
     int strip_n = 8, strip_d = 0, paced = -1, lds_block = 0, no_merge = 0;
     int exp_nosrc = 0, exp_nodst = 0, exp_srcpitch0 = 0, exp_dstpitch0 = 0, exp_stride0 = 0;
     int planewise = 0;                // tts_run: always take the plane-by-plane path (test knob)
+    int span_chunks = 0;              // tts_run_batch: always cut batches into launches whose whole span fits 32 bits (test knob)
     void read()
     {
         strip_n = env_int("TTS_STRIP_N", 8); strip_d = env_int("TTS_STRIP_D", 0);
@@ -1011,6 +1031,7 @@ struct Knobs {
         exp_srcpitch0 = env_int("TTS_EXP_SRCPITCH0", 0); exp_dstpitch0 = env_int("TTS_EXP_DSTPITCH0", 0);
         exp_stride0 = env_int("TTS_EXP_STRIDE0", 0);
         planewise = env_int("TTS_PLANEWISE", 0);
+        span_chunks = env_int("TTS_SPAN_CHUNKS", 0);
     }
 };
 
@@ -1485,9 +1506,14 @@ size_t choose_column_segs(const tts_plan *p, const int *cis, int ncls, int n, in
 // `only_plane` >= 0 restricts the launch set to that one plane (per-frame pointers whose planes lie
 // too far apart for one base + 32-bit offsets are processed plane by plane).
 int launch_all(const tts_plan *p, const uint8_t *src, uint8_t *dst, int n, const int src_stride[2],
-               const int dst_stride[2], uint32_t src_span, uint32_t dst_span, const FrameAddr &addr, hipStream_t st,
+               const int dst_stride[2], uint64_t src_span, uint64_t dst_span, const FrameAddr &addr, hipStream_t st,
                int only_plane = -1)
 {
+    // the plain kernels index frames by grid.z (at most 65535 planes a launch)
+    auto z_launches = [&](int planes, auto &&launch) {
+        const int per = 65535 / planes;
+        for (int f0 = 0; f0 < n; f0 += per) launch(f0, std::min(per, n - f0));
+    };
     auto active  = [&](int ci) { return only_plane < 0 || ci == (only_plane ? 1 : 0); };
     auto nplanes = [&](int ci) { return only_plane < 0 ? (ci ? 2 : 1) : 1; };
     auto plane0  = [&](int ci) { return only_plane < 0 ? (ci ? 1 : 0) : only_plane; };
@@ -1502,8 +1528,11 @@ int launch_all(const tts_plan *p, const uint8_t *src, uint8_t *dst, int n, const
             f.fill[0] = p->g.fill_y; f.fill[1] = p->g.fill_u; f.fill[2] = p->g.fill_v;
             f.origin = uint32_t(c.pad_y) * uint32_t(dst_stride[ci]) + uint32_t(c.pad_x);
             f.addr = addr;
-            dim3 grid((c.canvas_w + 255) / 256, (c.canvas_h + 3) / 4, n * f.planes);
-            hipLaunchKernelGGL(fill_kernel, grid, dim3(kBlock), 0, st, f);
+            z_launches(f.planes, [&](int f0, int nf) {
+                f.frame0 = f0;
+                dim3 grid((c.canvas_w + 255) / 256, (c.canvas_h + 3) / 4, nf * f.planes);
+                hipLaunchKernelGGL(fill_kernel, grid, dim3(kBlock), 0, st, f);
+            });
         }
     }
 
@@ -1612,8 +1641,11 @@ int launch_all(const tts_plan *p, const uint8_t *src, uint8_t *dst, int n, const
         a.src_stride = src_stride[ci]; a.dst_stride = dst_stride[ci];
         a.planes = nplanes(ci); a.plane0 = plane0(ci);
         a.addr = addr;
-        dim3 grid((c.ow + 63) / 64, (c.oh + 3) / 4, n * a.planes);
-        hipLaunchKernelGGL(generic_kernel, grid, dim3(kBlock), 0, st, a);
+        z_launches(a.planes, [&](int f0, int nf) {
+            a.frame0 = f0;
+            dim3 grid((c.ow + 63) / 64, (c.oh + 3) / 4, nf * a.planes);
+            hipLaunchKernelGGL(generic_kernel, grid, dim3(kBlock), 0, st, a);
+        });
     }
     if (p->g.out_range != TTS_RANGE_KEEP) {
         for (int ci = 0; ci < 2; ++ci) {
@@ -1625,8 +1657,11 @@ int launch_all(const tts_plan *p, const uint8_t *src, uint8_t *dst, int n, const
             r.origin = uint32_t(c.pad_y) * uint32_t(dst_stride[ci]) + uint32_t(c.pad_x);
             r.addr = addr;
             tts::build_range_lut(p->g.out_range, ci != 0, r.lut);
-            dim3 grid((c.canvas_w + 255) / 256, (c.canvas_h + 3) / 4, n * r.planes);
-            hipLaunchKernelGGL(range_kernel, grid, dim3(kBlock), 0, st, r);
+            z_launches(r.planes, [&](int f0, int nf) {
+                r.frame0 = f0;
+                dim3 grid((c.canvas_w + 255) / 256, (c.canvas_h + 3) / 4, nf * r.planes);
+                hipLaunchKernelGGL(range_kernel, grid, dim3(kBlock), 0, st, r);
+            });
         }
     }
     return hipGetLastError() == hipSuccess ? TTS_OK : TTS_ERR_PROCESSING_FAILED;
@@ -1770,15 +1805,26 @@ int tts_run_batch(const tts_plan *p, const void *src, size_t src_pitch, void *ds
         splane += uint32_t(sstride[ci]) * ceil_shift(g.in_h, ci);
         dplane += uint32_t(dstride[ci]) * ceil_shift(g.out_h, ci);
     }
-    // 32-bit lane offsets: keep each launch's span under kMaxSpan (offsets above it mean "discard")
+    // Lane offsets are 32-bit and count from the first frame of the lane's WAVE (frame_offsets), so a
+    // launch may cover any number of frames as long as the frames one wave can touch stay within
+    // kMaxSpan: a wave holds 64 items, a frame at least `ipf` of them.  (Pitches so large that they do
+    // not -- hundreds of megabytes between frames -- fall back to launches whose whole span fits.)
     if (sbytes > kMaxSpan || dbytes > kMaxSpan) return TTS_ERR_UNSUPPORTED;
-    const int chunk = int(std::min<size_t>(1 + std::min((kMaxSpan - sbytes) / src_pitch, (kMaxSpan - dbytes) / dst_pitch), size_t(1) << 30));
+    const int ipf = std::max(1, (std::min(p->cls[0].ow, p->cls[1].ow) + 15) / 16);
+    const size_t wave_frames = size_t(63 / ipf + 2);
+    const bool any_size = wave_frames * src_pitch + sbytes <= kMaxSpan && wave_frames * dst_pitch + dbytes <= kMaxSpan && !p->knobs.span_chunks;
+    // items and workgroups are counted in 32 bits: at most 2^30 output columns a launch
+    const size_t cols_per_frame = size_t(p->cls[0].ow) + 2 * size_t(p->cls[1].ow);
+    const size_t max_frames = std::max<size_t>(1, (size_t(1) << 30) / std::max<size_t>(cols_per_frame, 1));
+    const size_t by_span = 1 + std::min((kMaxSpan - sbytes) / src_pitch, (kMaxSpan - dbytes) / dst_pitch);
+    const int chunk = int(std::min(any_size ? max_frames : std::min(by_span, max_frames), size_t(1) << 30));
     for (int f0 = 0; f0 < n_frames; f0 += chunk) {
         const int n = std::min(chunk, n_frames - f0);
         const uint8_t *s = static_cast<const uint8_t *>(src) + size_t(f0) * src_pitch;
         uint8_t *d = static_cast<uint8_t *>(dst) + size_t(f0) * dst_pitch;
-        const int rc = launch_all(p, s, d, n, sstride, dstride, uint32_t(size_t(n - 1) * src_pitch + sbytes),
-                                  uint32_t(size_t(n - 1) * dst_pitch + dbytes), addr, st);
+        const uint64_t sspan = uint64_t(n - 1) * src_pitch + sbytes, dspan = uint64_t(n - 1) * dst_pitch + dbytes;
+        addr.wave_base = sspan > kMaxSpan || dspan > kMaxSpan;
+        const int rc = launch_all(p, s, d, n, sstride, dstride, sspan, dspan, addr, st);
         if (rc) return rc;
     }
     return TTS_OK;
