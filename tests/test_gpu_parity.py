@@ -459,3 +459,64 @@ def test_column_kernel_variants(tts, oracle, vf, iw, ih, n, kind):
         src = synth.frames(pat, iw, ih, n)
         got = plan.run_batch(torch.from_numpy(src).cuda()).cpu().numpy()
         assert np.array_equal(got, oracle.run_chain(plan.geom, src)), pat
+
+
+def test_plan_shared_by_host_threads(tts, oracle):
+    """SURVEY.md 8b threading: one immutable plan, several host threads, each with its own HIP stream
+    and its own frames, all in flight together."""
+    import threading
+    import torch
+    iw, ih, n, workers = 320, 180, 12, 4
+    plan = tts.Plan.from_vf("scale=568:320", iw, ih)
+    srcs = [synth.frames("random", iw, ih, n) + np.uint8(w) for w in range(workers)]
+    outs, errs = [None] * workers, []
+
+    def work(w):
+        try:
+            st = torch.cuda.Stream()
+            with torch.cuda.stream(st):
+                d_src = torch.from_numpy(srcs[w]).cuda()
+                res = None
+                for _ in range(20):                       # keep the streams busy at the same time
+                    res = plan.run_batch(d_src, stream=st.cuda_stream)
+                st.synchronize()
+                outs[w] = res.cpu().numpy()
+        except Exception as e:                            # noqa: BLE001
+            errs.append(e)
+
+    threads = [threading.Thread(target=work, args=(w,)) for w in range(workers)]
+    for t in threads:
+        t.start()
+    for t in threads:
+        t.join()
+    assert not errs, errs
+    for w in range(workers):
+        assert np.array_equal(outs[w], oracle.run_chain(plan.geom, srcs[w])), w
+
+
+def test_runs_under_hip_graph_capture(tts, oracle):
+    """tts_run_batch allocates nothing and only launches kernels, so a serving loop can capture it once
+    and replay it: capture on a side stream, replay with new frames in the same buffers."""
+    import torch
+    iw, ih, n = 320, 180, 6
+    plan = tts.Plan.from_vf("scale=320x180:force_original_aspect_ratio=decrease,pad=320x180:-1:-1:color=black,format=yuvj420p", 180, 320)
+    plan2 = tts.Plan.from_vf("scale=568:320", iw, ih)
+    a = synth.frames("random", 180, 320, n)
+    b = synth.frames("random", iw, ih, n)
+    d_a, d_b = torch.from_numpy(a).cuda(), torch.from_numpy(b).cuda()
+    o_a = torch.zeros((n, plan.out_bytes), dtype=torch.uint8, device="cuda")
+    o_b = torch.zeros((n, plan2.out_bytes), dtype=torch.uint8, device="cuda")
+    graph = torch.cuda.CUDAGraph()
+    with torch.cuda.graph(graph):
+        st = torch.cuda.current_stream().cuda_stream
+        plan.run_batch(d_a, o_a, stream=st)              # fill + column walk + range pass: three dependent launches
+        plan2.run_batch(d_b, o_b, stream=st)
+    for rep in range(3):
+        a2 = np.roll(a, rep + 1, axis=0) ^ np.uint8(rep)
+        b2 = np.roll(b, rep + 1, axis=0) ^ np.uint8(3 * rep)
+        d_a.copy_(torch.from_numpy(a2)); d_b.copy_(torch.from_numpy(b2))
+        o_a.zero_(); o_b.zero_()
+        graph.replay()
+        torch.cuda.synchronize()
+        assert np.array_equal(o_a.cpu().numpy(), oracle.run_chain(plan.geom, a2)), rep
+        assert np.array_equal(o_b.cpu().numpy(), oracle.run_chain(plan2.geom, b2)), rep
