@@ -120,6 +120,8 @@ def test_row_segmentation_is_invisible(tts, oracle, monkeypatch, seg):
     # the column walk in pointer mode
     (THUMB_REF, 1920, 1080, 3, False),
     (THUMB_REF, 1283, 721, 1, "planewise"),
+    ("scale=213:121", 640, 360, 3, False),                  # ... two columns per lane
+    ("scale=213:121", 640, 360, 1, "planewise"),
     ("scale=20:12", 200, 120, 40, False),                   # 12-row planes: single segment -> generic kernel in pointer mode
     # source planes too small for a staged run to be slid inside them: 24 / 12-byte rows, 6 / 3-row planes
     ("scale=136:96", 24, 60, 33, False),
@@ -344,12 +346,12 @@ def test_lds_kernel_variants(tts, oracle, vf, iw, ih, n, kind):
 
 
 @pytest.mark.parametrize("knob,val", [("TTS_PACED", "1"), ("TTS_PACED", "0"), ("TTS_LDS_BLOCK", "64"), ("TTS_LDS_BLOCK", "704"),
-                                      ("TTS_STRIP_D", "2"), ("TTS_NO_LDS", "1"), ("TTS_NO_G4", "1"), ("TTS_NO_G6", "1"), ("TTS_NO_MERGE", "1")])
+                                      ("TTS_STRIP_D", "2"), ("TTS_NO_LDS", "1"), ("TTS_NO_G4", "1"), ("TTS_NO_G6", "1"), ("TTS_NO_MERGE", "1"), ("TTS_COL_NC", "1")])
 def test_tuning_knobs_do_not_change_pixels(tts, oracle, monkeypatch, knob, val):
     import torch
     monkeypatch.setenv(knob, val)
     for vf, iw, ih in (("scale=355:267", 200, 150), ("scale=120:90:flags=area", 200, 150), ("scale=136:96", 100, 60),
-                       ("scale=176:132", 200, 150)):
+                       ("scale=176:132", 200, 150), ("scale=67:49", 200, 150)):
         plan = tts.Plan.from_vf(vf, iw, ih)
         src = synth.frames("random", iw, ih, 21)
         got = plan.run_batch(torch.from_numpy(src).cuda()).cpu().numpy()
@@ -441,12 +443,16 @@ COLUMN_CASES = [
     ("scale=160:90", 1920, 1080, 5, 4),
     ("scale=40:ih", 640, 48, 33, 5),                       # 16x horizontally only: runs of 1.1 KB, vertical taps = 1
     ("scale=iw:30", 64, 480, 33, 4),                       # 16x vertically only
-    ("scale=320:180:flags=area", 3840, 2160, 2, 4),        # 12x area: 13 taps
+    ("scale=320:180:flags=area", 3840, 2160, 2, 5),        # 12x area: 13 taps, two columns per lane: 1.5 KB runs
     ("scale=20:12", 200, 120, 200, 4),                     # 20-column planes: 3-4 pieces per wave
     ("crop=1280:720:320:180,scale=160:90", 1920, 1080, 3, 4),   # pre-crop: windows start inside the rows
     ("scale=720:1280", 2160, 3840, 1, 4),                  # web compress of a 4K portrait clip: 3x, 13 taps (8 tap pairs, ring of 16)
     ("scale=480:270", 1920, 1080, 4, 4),                   # 4x: 17 taps -> 16 tap pairs
     ("scale=64:36", 1920, 1080, 2, 0),                     # 30x: 121 taps -> generic kernel
+    # two columns per lane (8 tap pairs): odd widths slide the last strip left; 3 / 2-column planes fall back to one
+    ("scale=213:121", 640, 360, 7, 4),
+    ("scale=3:50", 10, 150, 40, None),
+    ("scale=1280:720", 3840, 2160, 1, 4),
 ]
 
 
@@ -454,7 +460,10 @@ COLUMN_CASES = [
 def test_column_kernel_variants(tts, oracle, vf, iw, ih, n, kind):
     import torch
     plan = tts.Plan.from_vf(vf, iw, ih)
-    assert plan.kernel_kind(0) == kind, "luma class runs kernel kind %d, expected %d" % (plan.kernel_kind(0), kind)
+    if kind is not None:
+        assert plan.kernel_kind(0) == kind, "luma class runs kernel kind %d, expected %d" % (plan.kernel_kind(0), kind)
+    if vf in ("scale=213:121", "scale=1280:720", "scale=720:1280"):
+        assert plan.kernel_name(0) == "column_lds<8,16,1,2>"
     for pat in ("random", "impulse"):
         src = synth.frames(pat, iw, ih, n)
         got = plan.run_batch(torch.from_numpy(src).cuda()).cpu().numpy()

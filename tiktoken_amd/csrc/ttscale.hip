@@ -166,6 +166,14 @@ __device__ __forceinline__ void store_b8(uint32_t v, u32x4_t rs, uint32_t off, i
 {
     asm volatile("buffer_store_byte %0, %1, %2, %3 offen" :: "v"(v), "v"(off), "s"(rs), "s"(soff));
 }
+[[maybe_unused]] __device__ __forceinline__ void store_b16(uint32_t v, u32x4_t rs, uint32_t off, int soff)
+{
+    asm volatile("buffer_store_short %0, %1, %2, %3 offen" :: "v"(v), "v"(off), "s"(rs), "s"(soff));
+}
+[[maybe_unused]] __device__ __forceinline__ void store_b32(uint32_t v, u32x4_t rs, uint32_t off, int soff)
+{
+    asm volatile("buffer_store_dword %0, %1, %2, %3 offen" :: "v"(v), "v"(off), "s"(rs), "s"(soff));
+}
 
 // How a lane fetches the source bytes of its N columns from one source row:
 //   kGroup4 (taps <= 4, 4 columns span <= 8 bytes): one 8-byte window per 4 columns; each column
@@ -738,12 +746,16 @@ template <>
     w[8] = e.x; w[9] = e.y; w[10] = f.x; w[11] = f.y; w[12] = g.x; w[13] = g.y; w[14] = h.x; w[15] = h.y; w[16] = i;
 }
 
-// NTP: tap pairs per column (window = 2 * NTP bytes); R: ring depth >= vertical taps; NDMA as above.
-template <int NTP, int R, int NDMA>
+// NTP: tap pairs per column (window = 2 * NTP bytes); R: ring depth >= vertical taps; NDMA as above;
+// NC: adjacent output columns per lane (1, 2 or 4: the per-row bookkeeping -- DMA, waits, loop control,
+// the store -- is the same for 1 byte or 4, so small ratios, where it weighs most, take the widest
+// strip their registers allow; the last strip of a row is slid left like strip_lds_kernel's).
+template <int NTP, int R, int NDMA, int NC>
 __global__ __launch_bounds__(kBlock) void column_lds_kernel(const uint8_t *__restrict__ src, uint8_t *__restrict__ dst,
                                                             const uint32_t *__restrict__ tab, const StripArgs a)
 {
     static_assert(NTP % 2 == 0 && R % 2 == 0 && (NDMA == 1 || NDMA == 2), "window is whole dwords; ring holds row pairs");
+    static_assert(NC == 1 || NC == 2 || NC == 4, "one byte, short or dword store per lane and row");
 #if defined(__HIP_DEVICE_COMPILE__)   // the LDS-DMA builtin exists in the device pass only
     constexpr int NDW = NTP / 2 + 1;                 // aligned dwords that hold a 2 * NTP-byte window at any byte phase
     constexpr int kSlotBytes = NDMA * 1024 + 16;
@@ -759,8 +771,9 @@ __global__ __launch_bounds__(kBlock) void column_lds_kernel(const uint8_t *__res
     int       g   = sb * kBlock + int(threadIdx.x);
     const bool live = g < c.n_items;
     if (!live) g = c.n_items - 1;                  // dead lanes (a suffix of the last workgroup) shadow the last live one
-    const int col   = g % c.strips;                // one output column per lane: strips == ow
+    const int strip = g % c.strips;                // NC output columns per lane
     const int fp    = g / c.strips;
+    const int col   = min(strip * NC, c.ow - NC);  // the last strip is slid left, not cut short
     const int wave = __builtin_amdgcn_readfirstlane(int(threadIdx.x) >> 6);
     const int lane = int(threadIdx.x) & 63;
 
@@ -773,10 +786,14 @@ __global__ __launch_bounds__(kBlock) void column_lds_kernel(const uint8_t *__res
     doff += uint32_t(col);
     if (!live) doff = kDiscard;                    // see strip_lds_kernel
 
-    uint32_t hc[NTP];
+    uint32_t hc[NC][NTP];
+    uint32_t off[NC];
 #pragma unroll
-    for (int k = 0; k < NTP; ++k) hc[k] = tab[c.hcoef + col * NTP + k];
-    const uint32_t off = tab[c.hoff + col] + soff;
+    for (int j = 0; j < NC; ++j) {
+#pragma unroll
+        for (int k = 0; k < NTP; ++k) hc[j][k] = tab[c.hcoef + (col + j) * NTP + k];
+        off[j] = tab[c.hoff + col + j] + soff;
+    }
 
     const int rstart = int(uni(tab[c.seginfo + 2 * seg]));
     const int nrows  = int(uni(tab[c.seginfo + 2 * seg + 1]));
@@ -784,17 +801,25 @@ __global__ __launch_bounds__(kBlock) void column_lds_kernel(const uint8_t *__res
     const uint32_t row0_off = uint32_t(rstart) * uint32_t(src_stride);
     uint32_t csrc[NDMA];
     uint32_t lbase;
-    plan_runs<NDMA>(a, c, off + row0_off, off + 2u * NTP + row0_off, soff, lane > 0 && col == 0 && live, lane,
+    plan_runs<NDMA>(a, c, off[0] + row0_off, off[NC - 1] + 2u * NTP + row0_off, soff, lane > 0 && strip == 0 && live, lane,
                     uint32_t(nrows - 1) * uint32_t(src_stride), csrc, lbase);
 
-    const uint32_t pos = off + row0_off + lbase + uint32_t(reinterpret_cast<uintptr_t>((lds_void_t *)&lds[wave][0]));
-    const uint32_t lpos = pos & ~3u, o = pos & 3u;
-    // taps 2tp, 2tp+1 (as 16-bit lanes) sit at bytes o + 2 (tp % 2), +1 of dwords tp / 2, tp / 2 + 1
-    const uint32_t psel[2] = {0x0c000c00u | o | ((o + 1u) << 16), 0x0c000c00u | (o + 2u) | ((o + 3u) << 16)};
-
-    uint32_t ring[R / 2];
+    uint32_t lpos[NC], psel[NC][2];
 #pragma unroll
-    for (int k = 0; k < R / 2; ++k) ring[k] = 0;
+    for (int j = 0; j < NC; ++j) {
+        const uint32_t pos = off[j] + row0_off + lbase + uint32_t(reinterpret_cast<uintptr_t>((lds_void_t *)&lds[wave][0]));
+        const uint32_t o = pos & 3u;
+        lpos[j] = pos & ~3u;
+        // taps 2tp, 2tp+1 (as 16-bit lanes) sit at bytes o + 2 (tp % 2), +1 of dwords tp / 2, tp / 2 + 1
+        psel[j][0] = 0x0c000c00u | o | ((o + 1u) << 16);
+        psel[j][1] = 0x0c000c00u | (o + 2u) | ((o + 3u) << 16);
+    }
+
+    uint32_t ring[NC][R / 2];
+#pragma unroll
+    for (int j = 0; j < NC; ++j)
+#pragma unroll
+        for (int k = 0; k < R / 2; ++k) ring[j][k] = 0;
 
     const uint32_t *emit = tab + c.emit + seg * c.maxrows;
     const uint32_t *vco  = tab + c.vcoef;
@@ -819,27 +844,43 @@ __global__ __launch_bounds__(kBlock) void column_lds_kernel(const uint8_t *__res
             const int cnt = cnt_next;
             cnt_next = int(uni(emit[min(k + 1, nrows - 1)]));
             wait_vm_plus<0>(prev_cnt);                          // row k's DMA has landed; younger stores may still fly
-            uint32_t w[NDW];
-            lds_read_dwords<NDW>(w, lpos);
+            uint32_t w[NC][NDW];
+#pragma unroll
+            for (int j = 0; j < NC; ++j) lds_read_dwords<NDW>(w[j], lpos[j]);
             // the slot is free again (its bytes sit in registers): request row k + 1 into it
 #pragma unroll
             for (int d = 0; d < NDMA; ++d)
                 __builtin_amdgcn_raw_ptr_buffer_load_lds(srs, (lds_void_t *)&lds[wave][d * 1024], 16, csrc[d],
                                                          min(k + 1, nrows - 1) * src_stride, 0, 0);
-            int acc = 0;
 #pragma unroll
-            for (int tp = 0; tp < NTP; ++tp)
-                acc = dot2(__builtin_amdgcn_perm(w[tp / 2 + 1], w[tp / 2], psel[tp % 2]), hc[tp], acc);
-            const uint32_t t = hfinish(acc);
-            ring[s / 2] = (s & 1) ? __builtin_amdgcn_perm(t, ring[s / 2], 0x05040100)
-                                  : __builtin_amdgcn_perm(ring[s / 2], t, 0x07060100);
+            for (int j = 0; j < NC; ++j) {
+                int acc = 0;
+#pragma unroll
+                for (int tp = 0; tp < NTP; ++tp)
+                    acc = dot2(__builtin_amdgcn_perm(w[j][tp / 2 + 1], w[j][tp / 2], psel[j][tp % 2]), hc[j][tp], acc);
+                const uint32_t t = hfinish(acc);
+                ring[j][s / 2] = (s & 1) ? __builtin_amdgcn_perm(t, ring[j][s / 2], 0x05040100)
+                                         : __builtin_amdgcn_perm(ring[j][s / 2], t, 0x07060100);
+            }
             for (int e = 0; e < cnt; ++e) {                     // wave-uniform
-                int v = 64 << 12;
+                int v[NC];
 #pragma unroll
-                for (int q = 0; q < R / 2; ++q) v = dot2(ring[q], uni(vco[y * (R / 2) + q]), v);
-                v >>= 19;
-                v = v < 0 ? 0 : v > 255 ? 255 : v;
-                store_b8(uint32_t(v), drs, doff, int(uni(uint32_t(y * dst_stride))));
+                for (int j = 0; j < NC; ++j) v[j] = 64 << 12;
+#pragma unroll
+                for (int q = 0; q < R / 2; ++q) {
+                    const uint32_t vk = uni(vco[y * (R / 2) + q]);
+#pragma unroll
+                    for (int j = 0; j < NC; ++j) v[j] = dot2(ring[j][q], vk, v[j]);
+                }
+                const int yoff = int(uni(uint32_t(y * dst_stride)));
+                if constexpr (NC == 4) {
+                    store_b32(pack4(v[0], v[1], v[2], v[3]), drs, doff, yoff);
+                } else {
+#pragma unroll
+                    for (int j = 0; j < NC; ++j) { v[j] >>= 19; v[j] = v[j] < 0 ? 0 : v[j] > 255 ? 255 : v[j]; }
+                    if constexpr (NC == 2) store_b16(uint32_t(v[0]) | (uint32_t(v[1]) << 8), drs, doff, yoff);
+                    else store_b8(uint32_t(v[0]), drs, doff, yoff);
+                }
                 ++y;
             }
             prev_cnt = cnt;
@@ -989,6 +1030,7 @@ struct ClassPlan {
     int LWlds = 0;                     // window width of the LDS-staged kernel's per-column mode (6 when 5-6 taps)
     // kind 2: column walk (9..64 taps): one output column per lane
     int NTP = 0, Rc = 0, col_dmas = 0; // tap pairs per column, ring depth, LDS-DMAs per source row
+    int col_nc = 1;                    // output columns per lane (1, 2, 4)
     uint32_t hoff1 = 0, hcoef1 = 0;    // window start per column, taps per column [ow][NTP]
     HTables ht[2];                     // horizontal tables for N = 8 and N = 16 columns per lane
     std::vector<SegTables> segs;
@@ -1091,7 +1133,7 @@ void build_seg_tables(const ClassPlan &c, int R, int seg_rows, std::vector<uint3
 // `nw` windows of a strip, `win` their width.  0 = not usable.
 int lds_dmas(const ClassPlan &c, const HTables &t, int N, const int *lo, int nw, int win)
 {
-    if ((N != 8 && N != 1) || c.ow < N || t.strips < 2 || env_int("TTS_NO_LDS", 0)) return 0;
+    if ((N != 8 && N != 4 && N != 2 && N != 1) || c.ow < N || t.strips < 2 || env_int("TTS_NO_LDS", 0)) return 0;
     auto chunks = [&](int s0, int s1) {   // strips [s0, s1] of one row
         const uint32_t b = uint32_t(lo[size_t(s0) * nw]), e = uint32_t(lo[size_t(s1) * nw + nw - 1] + win);
         return (e - b + 30u) >> 4;
@@ -1156,9 +1198,22 @@ int build_class(const tts_geom &g, int sub, ClassPlan &c, std::vector<uint32_t> 
             tab[hoff1 + i] = uint32_t(lo[i]);
             for (int k = 0; k < NTP; ++k) tab[hcoef1 + size_t(i) * NTP + k] = pack16(slot[2 * k], slot[2 * k + 1]);
         }
-        const int dmas = lds_dmas(c, t, 1, lo.data(), 1, 2 * NTP);
+        // columns per lane: two at 8 tap pairs (2160x3840 -> 720x1280: 25 -> 41 % of peak; four measured the
+        // same there and 5 % slower on 4K -> 720p, at 110 VGPRs), one above (two at 16 tap pairs made no
+        // difference to the 1080p thumbnail), if the 64-strip runs fit the LDS slot
+        int dmas = 0, nc = NTP == 8 ? 2 : 1;
+        const int forced_nc = env_int("TTS_COL_NC", 0);
+        if (forced_nc == 1 || forced_nc == 2) nc = std::min(nc, forced_nc);
+        for (; nc >= 1 && !dmas; nc = dmas ? nc : nc / 2) {
+            t.strips = (c.ow + nc - 1) / nc;
+            std::vector<int> lo_nc(size_t(t.strips) * nc);
+            for (int s = 0; s < t.strips; ++s)
+                for (int j = 0; j < nc; ++j) lo_nc[size_t(s) * nc + j] = lo[std::min(std::min(s * nc, std::max(c.ow - nc, 0)) + j, c.ow - 1)];
+            dmas = lds_dmas(c, t, nc, lo_nc.data(), nc, 2 * NTP);
+            if (dmas) break;
+        }
         if (!dmas) return TTS_OK;
-        c.kind = 2; c.NTP = NTP; c.Rc = Rc; c.col_dmas = dmas; c.hoff1 = hoff1; c.hcoef1 = hcoef1;
+        c.kind = 2; c.NTP = NTP; c.Rc = Rc; c.col_dmas = dmas; c.col_nc = nc; c.hoff1 = hoff1; c.hcoef1 = hcoef1;
         // Segment lengths on offer: the luma plane cut into 1..32 EQUAL parts (outputs here are small --
         // a ragged last segment would be most of the tail), the same list for both classes, ascending.
         std::vector<int> opts;
@@ -1453,9 +1508,11 @@ void choose_segs(const tts_plan *p, const int *cis, int ncls, int n, int N, stri
 
 strip_fn pick_column(const ClassPlan &c)
 {
-    if (c.NTP == 8 && c.Rc == 16) return c.col_dmas == 1 ? column_lds_kernel<8, 16, 1> : column_lds_kernel<8, 16, 2>;
-    if (c.NTP == 16 && c.Rc == 32) return c.col_dmas == 1 ? column_lds_kernel<16, 32, 1> : column_lds_kernel<16, 32, 2>;
-    if (c.NTP == 32 && c.Rc == 64) return c.col_dmas == 1 ? column_lds_kernel<32, 64, 1> : column_lds_kernel<32, 64, 2>;
+#define TTS_COL_PICK(NTP_, R_, NC_) (c.col_dmas == 1 ? column_lds_kernel<NTP_, R_, 1, NC_> : column_lds_kernel<NTP_, R_, 2, NC_>)
+    if (c.NTP == 8 && c.Rc == 16) return c.col_nc == 2 ? TTS_COL_PICK(8, 16, 2) : TTS_COL_PICK(8, 16, 1);
+    if (c.NTP == 16 && c.Rc == 32 && c.col_nc == 1) return TTS_COL_PICK(16, 32, 1);
+    if (c.NTP == 32 && c.Rc == 64 && c.col_nc == 1) return TTS_COL_PICK(32, 64, 1);
+#undef TTS_COL_PICK
     return nullptr;
 }
 
@@ -1467,9 +1524,9 @@ void fill_column_class(const tts_plan *p, int ci, int n, int src_stride, int dst
     sc.hoff = c.hoff1; sc.hcoef = c.hcoef1;
     sc.seginfo = st.seginfo; sc.emit = st.emit; sc.vcoef = st.vcoef;
     sc.maxrows = st.maxrows; sc.nseg = st.nseg; sc.seg_rows = st.seg_rows;
-    sc.strips = c.ow;                                  // one column per lane
+    sc.strips = (c.ow + c.col_nc - 1) / c.col_nc;      // col_nc columns per lane
     sc.planes = planes; sc.plane0 = plane0;
-    sc.n_items = n * planes * c.ow;
+    sc.n_items = n * planes * sc.strips;
     sc.ow = c.ow; sc.oh = c.oh; sc.src_stride = src_stride; sc.dst_stride = dst_stride;
     sc.nblocks = uint32_t((sc.n_items + kBlock - 1) / kBlock) * uint32_t(st.nseg);
     const int sub = ci ? 1 : 0;
@@ -1490,7 +1547,7 @@ size_t choose_column_segs(const tts_plan *p, const int *cis, int ncls, int n, in
         double blocks = 0;
         for (int k = 0; k < ncls; ++k) {
             const ClassPlan &c = p->cls[cis[k]];
-            blocks += double((int64_t(n) * planes_each[k] * c.ow + kBlock - 1) / kBlock) * c.segs[i].nseg;
+            blocks += double((int64_t(n) * planes_each[k] * ((c.ow + c.col_nc - 1) / c.col_nc) + kBlock - 1) / kBlock) * c.segs[i].nseg;
         }
         if (i == 0 || blocks >= 1.5 * slots) best = i;
     }
@@ -1765,7 +1822,7 @@ const char *tts_plan_kernel_name(const tts_plan *p, int plane_class)
     if (!p || plane_class < 0 || plane_class > 1) return "";
     const ClassPlan &c = p->cls[plane_class];
     if (c.kind == 0) std::snprintf(buf, sizeof buf, "generic");
-    else if (c.kind == 2) std::snprintf(buf, sizeof buf, "column_lds<%d,%d,%d>", c.NTP, c.Rc, c.col_dmas);
+    else if (c.kind == 2) std::snprintf(buf, sizeof buf, "column_lds<%d,%d,%d,%d>", c.NTP, c.Rc, c.col_dmas, c.col_nc);
     else {
         const StripChoice ch = strip_choice(c, p->knobs);
         if (ch.lds) std::snprintf(buf, sizeof buf, "strip_lds<%d,%d,%s,%d,%d>", ch.LW, ch.R, ch.g4 ? "grouped" : "percolumn", ch.lds, ch.depth);
