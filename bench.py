@@ -130,7 +130,7 @@ def main():
                        "vf": VF, "frames_per_gpu": n, "settle_launches": args.settle, "parallelism": "clip-sharded x%d, no collective" % world},
             "roofline": {"bound": "hbm", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": traffic,
-                         "kernel": "strip_lds_kernel<4, 4, true, 1, 1>", "launch_ms": round(launch_ms, 4),
+                         "kernel": "strip_lds_kernel<4, 4, 4, 1, 1>", "launch_ms": round(launch_ms, 4),
                          "algo_bytes_per_launch": int(algo_bytes_launch)},
         }
         if world == 1 and not args.no_cpu_baseline:

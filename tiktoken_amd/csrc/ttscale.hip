@@ -402,6 +402,15 @@ struct Win3 { u32x2_t lo; uint32_t hi; };
                  "ds_read2_b32 %2, %5 offset1:1\n\tds_read2_b32 %3, %5 offset0:2 offset1:3\n\t"                     \
                  "s_waitcnt lgkmcnt(0)"                                                                           \
                  : "=&v"(w[0][0]), "=&v"(w[0][1]), "=&v"(w[1][0]), "=&v"(w[1][1]) : "v"(p[0]), "v"(p[1]) : "memory")
+#define TTS_LDS_READ_WIN4_X4(w, p)                                                                                \
+    asm volatile("ds_read2_b32 %0, %8 offset1:1\n\tds_read2_b32 %1, %8 offset0:2 offset1:3\n\t"                     \
+                 "ds_read2_b32 %2, %9 offset1:1\n\tds_read2_b32 %3, %9 offset0:2 offset1:3\n\t"                     \
+                 "ds_read2_b32 %4, %10 offset1:1\n\tds_read2_b32 %5, %10 offset0:2 offset1:3\n\t"                   \
+                 "ds_read2_b32 %6, %11 offset1:1\n\tds_read2_b32 %7, %11 offset0:2 offset1:3\n\t"                   \
+                 "s_waitcnt lgkmcnt(0)"                                                                           \
+                 : "=&v"(w[0][0]), "=&v"(w[0][1]), "=&v"(w[1][0]), "=&v"(w[1][1]),                                 \
+                   "=&v"(w[2][0]), "=&v"(w[2][1]), "=&v"(w[3][0]), "=&v"(w[3][1])                                  \
+                 : "v"(p[0]), "v"(p[1]), "v"(p[2]), "v"(p[3]) : "memory")
 [[maybe_unused]] __device__ __forceinline__ void lds_read_win3(Win3 (&w)[8], const uint32_t (&p)[8])
 {
     asm volatile("ds_read2_b32 %0, %16 offset1:1\n\tds_read_b32 %1, %16 offset:8\n\t"
@@ -490,16 +499,20 @@ __device__ __forceinline__ void plan_runs(const StripArgs &a, const StripClass &
 // LW, R as in strip_kernel; G4: grouped windows (two 8-byte windows per lane, taps <= 4), else one
 // LW-byte window per column; NDMA: 1 KiB LDS-DMAs per source row (the wave's runs hold <= 64 * NDMA
 // sixteen-byte chunks).  Eight columns per lane.
-template <int LW, int R, bool G4, int NDMA, int D>
-__global__ __launch_bounds__(kMaxLdsBlock, (G4 && R == 4 && LW == 4) ? 8 : 4) void strip_lds_kernel(const uint8_t *__restrict__ src, uint8_t *__restrict__ dst,
+template <int LW, int R, int GC, int NDMA, int D>
+__global__ __launch_bounds__(kMaxLdsBlock, (GC == 4 && R == 4 && LW == 4) ? 8 : 4) void strip_lds_kernel(const uint8_t *__restrict__ src, uint8_t *__restrict__ dst,
                                                                                const uint32_t *__restrict__ tab, const StripArgs a)
 {
-    static_assert(R % 2 == 0 && (LW == 4 || LW == 6 || LW == 8) && (!G4 || LW == 4 || LW == 6) && (NDMA == 1 || NDMA == 2), "see strip_kernel");
-    static_assert(!(G4 && LW == 6) || D == 1, "the 12-byte group reader addresses slot 0 only");
+    // GC: columns that share one window (0: every column its own LW-byte window; 4 with LW = 4: 8-byte
+    // windows; 4 with LW = 6, 2 with LW = 6 or 8: 12-byte windows)
+    constexpr bool G4 = GC != 0;
+    static_assert(R % 2 == 0 && (LW == 4 || LW == 6 || LW == 8) && (NDMA == 1 || NDMA == 2), "see strip_kernel");
+    static_assert(GC == 0 || (GC == 4 && (LW == 4 || LW == 6)) || (GC == 2 && (LW == 6 || LW == 8)), "window shapes on offer");
+    static_assert(!(G4 && LW >= 6) || D == 1, "the 12-byte group readers address slot 0 only");
     static_assert(D >= 1 && R % D == 0, "D source rows in flight, one LDS slot each, rotating with the ring");
 #if defined(__HIP_DEVICE_COMPILE__)   // the LDS-DMA builtin exists in the device pass only
     constexpr int N = 8;
-    constexpr int NW = G4 ? 2 : N;                   // windows per row per lane
+    constexpr int NW = G4 ? N / GC : N;              // windows per row per lane
     constexpr int kSlotBytes = NDMA * 1024 + 16;
     extern __shared__ __attribute__((aligned(16))) uint8_t lds_raw[];      // (blockDim.x / 64) x D slots
     uint8_t (*lds)[D][kSlotBytes] = reinterpret_cast<uint8_t (*)[D][kSlotBytes]>(lds_raw);
@@ -623,11 +636,11 @@ __global__ __launch_bounds__(kMaxLdsBlock, (G4 && R == 4 && LW == 4) ? 8 : 4) vo
 #pragma unroll
             for (int r = 0; r < D; ++r) younger += hist[r];
             wait_vm_plus<(D - 1) * NDMA>(younger);
-            constexpr int GD = G4 && LW == 6 ? 4 : 3;
+            constexpr int GD = G4 && LW >= 6 ? 4 : 3;
             uint32_t wk[NW][GD];                                // the aligned dwords holding each window
-            if constexpr (G4 && LW == 6) {
+            if constexpr (G4 && LW >= 6) {
                 u32x2_t wv[NW][2];
-                TTS_LDS_READ_WIN4_X2(wv, lpos);
+                if constexpr (NW == 2) TTS_LDS_READ_WIN4_X2(wv, lpos); else TTS_LDS_READ_WIN4_X4(wv, lpos);
 #pragma unroll
                 for (int j = 0; j < NW; ++j) { wk[j][0] = wv[j][0].x; wk[j][1] = wv[j][0].y; wk[j][2] = wv[j][1].x; wk[j][3] = wv[j][1].y; }
             } else if constexpr (G4) {
@@ -659,10 +672,12 @@ __global__ __launch_bounds__(kMaxLdsBlock, (G4 && R == 4 && LW == 4) ? 8 : 4) vo
             for (int i = 0; i < N; ++i) {
                 int acc = 0;
                 if constexpr (G4) {
-                    acc = dot2(__builtin_amdgcn_perm(wk[i / 4][1], wk[i / 4][0], sel[i][0]), hc[i][0], acc);
-                    acc = dot2(__builtin_amdgcn_perm(wk[i / 4][1], wk[i / 4][0], sel[i][1]), hc[i][1], acc);
-                    // taps 4, 5 sit four bytes on: the first selector again, one dword further
-                    if constexpr (LW == 6) acc = dot2(__builtin_amdgcn_perm(wk[i / 4][2], wk[i / 4][1], sel[i][0]), hc[i][2], acc);
+                    constexpr int gi_div = GC;
+                    acc = dot2(__builtin_amdgcn_perm(wk[i / gi_div][1], wk[i / gi_div][0], sel[i][0]), hc[i][0], acc);
+                    acc = dot2(__builtin_amdgcn_perm(wk[i / gi_div][1], wk[i / gi_div][0], sel[i][1]), hc[i][1], acc);
+                    // taps 4..7 sit four bytes on: the same selectors, one dword further
+                    if constexpr (LW >= 6) acc = dot2(__builtin_amdgcn_perm(wk[i / gi_div][2], wk[i / gi_div][1], sel[i][0]), hc[i][2], acc);
+                    if constexpr (LW == 8) acc = dot2(__builtin_amdgcn_perm(wk[i / gi_div][2], wk[i / gi_div][1], sel[i][1]), hc[i][3], acc);
                 } else {
 #pragma unroll
                     for (int tp = 0; tp < LW / 2; ++tp)         // taps 2tp, 2tp+1 sit at bytes o + 2 (tp % 2) of dwords tp / 2, tp / 2 + 1
@@ -1013,9 +1028,9 @@ struct HTables {
     int lds_g4 = 0, lds_col = 0;                   // LDS-staged kernel: 1 KiB DMAs per row it needs with grouped /
                                                    // per-column windows (0 = not usable)
     uint32_t hoff6 = 0, hcoef6 = 0;                // 5-6 taps: 6-byte windows for the LDS-staged kernel (3 tap pairs a column)
-    bool g6 = false;                               // 5-6 taps, mild downscale: grouped 12-byte windows (LDS-staged kernel only)
-    uint32_t hoff6g = 0, hsel6g = 0, hcoef6g = 0;
-    int lds_g6 = 0;
+    // grouped 12-byte windows (LDS-staged kernel only): 5-6 taps with 4 or 2 columns a window, 7-8 taps with 2
+    struct Grouped12 { int lw = 0, gc = 0; uint32_t hoff = 0, hsel = 0, hcoef = 0; int lds = 0; };
+    Grouped12 g12;                                 // the variant this class takes (lds == 0: none)
 };
 
 struct ClassPlan {
@@ -1307,40 +1322,49 @@ int build_class(const tts_geom &g, int sub, ClassPlan &c, std::vector<uint32_t> 
             for (int i = 0; i < ncols; ++i) lo[i] = int(tab[t.hoff + i]);
         }
         t.lds_col = lds_dmas(c, t, N, lo.data(), N, c.LWlds);
-        // 5-6 taps at ratios up to 4/3 (4K -> portrait is 1.125): four columns' windows fit 12 bytes, and one
-        // 4-dword read per group replaces four 3-dword reads.  Tap j of a column whose first tap is byte d of
-        // the group window is picked out of the dword pair (j/4, j/4 + 1): d + j - 4 (j/4) must stay <= 7.
-        t.g6 = c.LWlds == 6 && c.src_w >= 12 && !env_int("TTS_NO_G4", 0) && !env_int("TTS_NO_G6", 0);
-        if (t.g6) {
+        // Grouped 12-byte windows: GC columns share one window, read as four aligned dwords -- 8 (GC = 4) or
+        // 16 (GC = 2) LDS dwords per lane and row instead of 24.  Tap j of a column whose first tap is byte d
+        // of the window is picked out of the dword pair (j/4, j/4 + 1): d + j - 4 (j/4) must stay <= 7, and
+        // d + taps <= 12.  5-6 taps: four columns up to ratios of about 1.5 (4K -> portrait is 1.125), two
+        // beyond (the 3.4x area thumbnails); 7-8 taps: two columns (1.5x .. 2x: 4K -> 1080p).
+        if (c.src_w >= 12 && HT >= 5 && !env_int("TTS_NO_G4", 0) && !env_int("TTS_NO_G6", 0)) {
             auto column = [&](int i) { return c.x0 + std::min(std::min((i / N) * N, std::max(c.ow - N, 0)) + i % N, c.ow - 1); };
-            std::vector<int> glo(ncols / 4);
-            for (int q = 0; q < ncols / 4 && t.g6; ++q) {
-                glo[q] = c.h.pos[column(4 * q)];        // not pulled back from the row's end: see the kernel's run bounds
-                for (int j = 0; j < 4 && t.g6; ++j) {
-                    const int d = c.h.pos[column(4 * q + j)] - glo[q];
-                    if (d < 0 || d + HT > 12) t.g6 = false;
-                    for (int k = 0; k < HT && t.g6; ++k)
-                        if (d + k - 4 * (k / 4) > 7) t.g6 = false;
+            const int lw = HT <= 6 ? 6 : 8;
+            const int forced_gc = env_int("TTS_G12_GC", 0);
+            for (int gc : {4, 2}) {
+                if ((lw == 8 && gc == 4) || t.g12.lds || (forced_gc && gc != forced_gc)) continue;
+                std::vector<int> glo(ncols / gc);
+                bool ok = true;
+                for (int q = 0; q < ncols / gc && ok; ++q) {
+                    glo[q] = c.h.pos[column(gc * q)];   // not pulled back from the row's end: see the kernel's run bounds
+                    for (int j = 0; j < gc && ok; ++j) {
+                        const int d = c.h.pos[column(gc * q + j)] - glo[q];
+                        if (d < 0 || d + HT > 12) ok = false;
+                        for (int k = 0; k < HT && ok; ++k)
+                            if (d + k - 4 * (k / 4) > 7) ok = false;
+                    }
                 }
-            }
-            if (t.g6) {
-                t.hoff6g = uint32_t(tab.size());
-                tab.resize(tab.size() + ncols / 4);
-                t.hsel6g = uint32_t(tab.size());
+                if (!ok) continue;
+                const int lds = lds_dmas(c, t, N, glo.data(), N / gc, 12);
+                if (!lds || (gc == 4 && lds != 1)) continue;            // (the 4-column kernels exist for one DMA only)
+                HTables::Grouped12 &gr = t.g12;
+                gr.lw = lw; gr.gc = gc; gr.lds = lds;
+                gr.hoff = uint32_t(tab.size());
+                tab.resize(tab.size() + ncols / gc);
+                gr.hsel = uint32_t(tab.size());
                 tab.resize(tab.size() + size_t(ncols) * 2);
-                t.hcoef6g = uint32_t(tab.size());
-                tab.resize(tab.size() + size_t(ncols) * 3, 0);
+                gr.hcoef = uint32_t(tab.size());
+                tab.resize(tab.size() + size_t(ncols) * (lw / 2), 0);
                 for (int i = 0; i < ncols; ++i) {
                     const int vx = column(i);
-                    const uint32_t d = uint32_t(c.h.pos[vx] - glo[i / 4]);
-                    int16_t t6[6] = {0, 0, 0, 0, 0, 0};
-                    for (int j = 0; j < HT; ++j) t6[j] = c.h.taps[size_t(vx) * HT + j];
-                    if (i % 4 == 0) tab[t.hoff6g + i / 4] = uint32_t(glo[i / 4]);
-                    tab[t.hsel6g + 2 * size_t(i)]     = 0x0c000c00u | d | ((d + 1) << 16);
-                    tab[t.hsel6g + 2 * size_t(i) + 1] = 0x0c000c00u | (d + 2) | ((d + 3) << 16);
-                    for (int k = 0; k < 3; ++k) tab[t.hcoef6g + 3 * size_t(i) + k] = pack16(t6[2 * k], t6[2 * k + 1]);
+                    const uint32_t d = uint32_t(c.h.pos[vx] - glo[i / gc]);
+                    int16_t t8[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+                    for (int k = 0; k < HT; ++k) t8[k] = c.h.taps[size_t(vx) * HT + k];
+                    if (i % gc == 0) tab[gr.hoff + i / gc] = uint32_t(glo[i / gc]);
+                    tab[gr.hsel + 2 * size_t(i)]     = 0x0c000c00u | d | ((d + 1) << 16);
+                    tab[gr.hsel + 2 * size_t(i) + 1] = 0x0c000c00u | (d + 2) | ((d + 3) << 16);
+                    for (int k = 0; k < lw / 2; ++k) tab[gr.hcoef + size_t(lw / 2) * i + k] = pack16(t8[2 * k], t8[2 * k + 1]);
                 }
-                t.lds_g6 = lds_dmas(c, t, N, glo.data(), N / 4, 12);
             }
         }
     }
@@ -1363,7 +1387,7 @@ void free_class(ClassPlan &c)
 typedef void (*strip_fn)(const uint8_t *, uint8_t *, const uint32_t *, const StripArgs);
 
 // lds: LDS-DMAs per row of the LDS-staged kernel, 0 = register kernel; depth: its source rows in flight
-struct StripChoice { int LW, R, N; bool g4; int lds; int depth; bool g6 = false; };
+struct StripChoice { int LW, R, N; bool g4; int lds; int depth; int g12 = 0; };   // g12: columns per 12-byte window, 0 = none
 
 StripChoice strip_choice(const ClassPlan &c, const Knobs &kn)
 {
@@ -1374,7 +1398,7 @@ StripChoice strip_choice(const ClassPlan &c, const Knobs &kn)
     ch.lds = t.g4 ? t.lds_g4 : t.lds_col;
     if (t.g4 && ch.lds != 1) { ch.lds = t.lds_col; if (ch.lds) ch.g4 = false; }   // grouped windows ride in one DMA only
     if (ch.lds && !ch.g4) ch.LW = c.LWlds;
-    if (!ch.g4 && t.g6 && t.lds_g6 == 1) { ch.g4 = ch.g6 = true; ch.lds = 1; ch.LW = 6; }   // (LDS-staged kernel only)
+    if (!ch.g4 && t.g12.lds) { ch.g4 = true; ch.g12 = t.g12.gc; ch.lds = t.g12.lds; ch.LW = t.g12.lw; }   // (LDS-staged kernel only)
     if (ch.lds && ch.g4 && ch.R == 4) ch.depth = kn.strip_d == 2 ? 2 : 1;
     return ch;
 }
@@ -1382,13 +1406,19 @@ StripChoice strip_choice(const ClassPlan &c, const Knobs &kn)
 strip_fn pick_strip(const StripChoice &ch, const Knobs &kn)
 {
     const int D = kn.strip_d;                          // rows in flight of the register kernels (tuning knob)
-    if (ch.lds && ch.g4 && !ch.g6) {
-        if (ch.R == 4) return ch.depth == 2 ? strip_lds_kernel<4, 4, true, 1, 2> : strip_lds_kernel<4, 4, true, 1, 1>;
-        return ch.R == 6 ? strip_lds_kernel<4, 6, true, 1, 1> : strip_lds_kernel<4, 8, true, 1, 1>;
+    if (ch.lds && ch.g4 && !ch.g12) {
+        if (ch.R == 4) return ch.depth == 2 ? strip_lds_kernel<4, 4, 4, 1, 2> : strip_lds_kernel<4, 4, 4, 1, 1>;
+        return ch.R == 6 ? strip_lds_kernel<4, 6, 4, 1, 1> : strip_lds_kernel<4, 8, 4, 1, 1>;
     }
-    if (ch.lds && ch.g6) return ch.R == 4 ? strip_lds_kernel<6, 4, true, 1, 1> : ch.R == 6 ? strip_lds_kernel<6, 6, true, 1, 1> : strip_lds_kernel<6, 8, true, 1, 1>;
+    if (ch.lds && ch.g12 == 4) return ch.R == 4 ? strip_lds_kernel<6, 4, 4, 1, 1> : ch.R == 6 ? strip_lds_kernel<6, 6, 4, 1, 1> : strip_lds_kernel<6, 8, 4, 1, 1>;
+    if (ch.lds && ch.g12 == 2) {
+#define TTS_G2_PICK(LW_, R_) (ch.lds == 1 ? strip_lds_kernel<LW_, R_, 2, 1, 1> : strip_lds_kernel<LW_, R_, 2, 2, 1>)
+        if (ch.LW == 6) return ch.R == 4 ? TTS_G2_PICK(6, 4) : ch.R == 6 ? TTS_G2_PICK(6, 6) : TTS_G2_PICK(6, 8);
+        return ch.R == 4 ? TTS_G2_PICK(8, 4) : ch.R == 6 ? TTS_G2_PICK(8, 6) : TTS_G2_PICK(8, 8);
+#undef TTS_G2_PICK
+    }
     if (ch.lds) {
-#define TTS_LDS_PICK(LW_, R_) (ch.lds == 1 ? strip_lds_kernel<LW_, R_, false, 1, 1> : strip_lds_kernel<LW_, R_, false, 2, 1>)
+#define TTS_LDS_PICK(LW_, R_) (ch.lds == 1 ? strip_lds_kernel<LW_, R_, 0, 1, 1> : strip_lds_kernel<LW_, R_, 0, 2, 1>)
         if (ch.LW == 4) return ch.R == 4 ? TTS_LDS_PICK(4, 4) : ch.R == 6 ? TTS_LDS_PICK(4, 6) : TTS_LDS_PICK(4, 8);
         if (ch.LW == 6) return ch.R == 4 ? TTS_LDS_PICK(6, 4) : ch.R == 6 ? TTS_LDS_PICK(6, 6) : TTS_LDS_PICK(6, 8);
         return ch.R == 4 ? TTS_LDS_PICK(8, 4) : ch.R == 6 ? TTS_LDS_PICK(8, 6) : TTS_LDS_PICK(8, 8);
@@ -1414,7 +1444,7 @@ void fill_strip_class(const tts_plan *p, int ci, int n, int N, bool g4, int lw, 
     const HTables &t = c.ht[N == 16];
     sc.hoff = g4 ? t.hoff4 : t.hoff; sc.hcoef = g4 ? t.hcoef4 : t.hcoef; sc.hsel = t.hsel4;
     if (!g4 && lw == 6) { sc.hoff = t.hoff6; sc.hcoef = t.hcoef6; }
-    if (g4 && lw == 6) { sc.hoff = t.hoff6g; sc.hcoef = t.hcoef6g; sc.hsel = t.hsel6g; }
+    if (g4 && lw >= 6) { sc.hoff = t.g12.hoff; sc.hcoef = t.g12.hcoef; sc.hsel = t.g12.hsel; }
     sc.seginfo = st.seginfo; sc.emit = st.emit; sc.vcoef = st.vcoef;
     sc.maxrows = st.maxrows; sc.nseg = st.nseg; sc.seg_rows = st.seg_rows;
     sc.strips = t.strips;
@@ -1599,7 +1629,7 @@ int launch_all(const tts_plan *p, const uint8_t *src, uint8_t *dst, int n, const
     bool merged = false;
     if (ns == 2 && !p->knobs.no_merge) {
         const StripChoice a0 = strip_choice(p->cls[0], p->knobs), a1 = strip_choice(p->cls[1], p->knobs);
-        merged = a0.LW == a1.LW && a0.R == a1.R && a0.N == a1.N && a0.g4 == a1.g4 && a0.lds == a1.lds && a0.depth == a1.depth;
+        merged = a0.LW == a1.LW && a0.R == a1.R && a0.N == a1.N && a0.g4 == a1.g4 && a0.g12 == a1.g12 && a0.lds == a1.lds && a0.depth == a1.depth;
     }
     for (int k = 0; k < ns; ++k) {
         StripArgs a{};
@@ -1622,7 +1652,7 @@ int launch_all(const tts_plan *p, const uint8_t *src, uint8_t *dst, int n, const
             const ClassPlan &cj = p->cls[strip_cls[j]];
             short_plane |= cj.oh <= cj.segs[0].seg_rows || cj.src_w < 48 || cj.src_h < 32;
         }
-        if (src_span < 4096u || (addr.use_table && short_plane)) { ch.lds = 0; ch.depth = 1; ch.LW = p->cls[ci].LW; if (ch.g6) ch.g4 = ch.g6 = false; }
+        if (src_span < 4096u || (addr.use_table && short_plane)) { ch.lds = 0; ch.depth = 1; ch.LW = p->cls[ci].LW; if (ch.g12) { ch.g4 = false; ch.g12 = 0; } }
         strip_fn fn = pick_strip(ch, p->knobs);
         if (!fn) return TTS_ERR_UNSUPPORTED;
         size_t si[2];
@@ -1825,7 +1855,7 @@ const char *tts_plan_kernel_name(const tts_plan *p, int plane_class)
     else if (c.kind == 2) std::snprintf(buf, sizeof buf, "column_lds<%d,%d,%d,%d>", c.NTP, c.Rc, c.col_dmas, c.col_nc);
     else {
         const StripChoice ch = strip_choice(c, p->knobs);
-        if (ch.lds) std::snprintf(buf, sizeof buf, "strip_lds<%d,%d,%s,%d,%d>", ch.LW, ch.R, ch.g4 ? "grouped" : "percolumn", ch.lds, ch.depth);
+        if (ch.lds) std::snprintf(buf, sizeof buf, "strip_lds<%d,%d,%s,%d,%d>", ch.LW, ch.R, ch.g12 == 2 ? "grouped2" : ch.g4 ? "grouped" : "percolumn", ch.lds, ch.depth);
         else std::snprintf(buf, sizeof buf, "strip<%d,%d,%d,%s>", ch.LW, ch.R, ch.N, ch.g4 ? "grouped" : "percolumn");
     }
     return buf;
