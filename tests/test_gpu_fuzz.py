@@ -1,0 +1,115 @@
+"""Randomised geometries through every kernel family, batch and pointer APIs, against the oracle.
+Seeded, so a failure names a reproducible case.  Sizes are kept small (the oracle is scalar C)."""
+import numpy as np
+import pytest
+
+import synth
+
+pytestmark = pytest.mark.gpu
+
+
+def _case(rng):
+    iw, ih = int(rng.integers(8, 420)), int(rng.integers(8, 300))
+    kind = rng.choice(["up", "mild", "down", "deep", "mixed"])
+    def axis(n):
+        if kind == "up":
+            return int(n * rng.uniform(1.0, 3.0))
+        if kind == "mild":
+            return int(n / rng.uniform(1.0, 2.0))
+        if kind == "down":
+            return int(n / rng.uniform(2.0, 6.0))
+        if kind == "deep":
+            return int(n / rng.uniform(6.0, 20.0))
+        return int(n * rng.choice([rng.uniform(0.1, 1.0), rng.uniform(1.0, 2.5)]))
+    ow, oh = max(2, axis(iw)), max(2, axis(ih))
+    flags = rng.choice(["", ":flags=area", ":flags=bilinear", ""])
+    vf = "scale=%d:%d%s" % (ow, oh, flags)
+    if rng.random() < 0.25 and iw > 40 and ih > 40:          # crop before the scale
+        cw, chh = int(rng.integers(16, iw)), int(rng.integers(16, ih))
+        vf = "crop=%d:%d:%d:%d," % (cw, chh, int(rng.integers(0, iw - cw + 1)), int(rng.integers(0, ih - chh + 1))) + vf
+    if rng.random() < 0.3 and ow > 12 and oh > 12:           # crop after it
+        vf += ",crop=%d:%d" % (int(rng.integers(8, ow)), int(rng.integers(8, oh)))
+    if rng.random() < 0.2:
+        vf += ",pad=iw+%d:ih+%d:-1:-1:color=black" % (2 * int(rng.integers(0, 20)), 2 * int(rng.integers(0, 20)))
+    if rng.random() < 0.15:
+        vf += ",format=yuvj420p"
+    return vf, iw, ih, int(rng.choice([1, 2, 3, 7, 19, 70]))
+
+
+@pytest.mark.parametrize("seed", range(int(__import__("os").environ.get("TTS_FUZZ_SEEDS", "24"))))
+def test_random_geometries(tts, oracle, seed):
+    import torch
+    rng = np.random.default_rng(1000 + seed)
+    seen = set()
+    for _ in range(16):
+        vf, iw, ih, n = _case(rng)
+        try:
+            plan = tts.Plan.from_vf(vf, iw, ih)
+        except tts.TtsError:
+            continue                                           # a chain the parser rejects (crop larger than the frame ...)
+        seen.add(plan.kernel_name(0).split("<")[0])
+        src = synth.frames("random", iw, ih, n)
+        want = oracle.run_chain(plan.geom, src)
+        got = plan.run_batch(torch.from_numpy(src).cuda()).cpu().numpy()
+        bad = np.flatnonzero(got != want)
+        assert bad.size == 0, "%s %dx%d n=%d [%s | %s]: %d bytes differ, first at %d" % (
+            vf, iw, ih, n, plan.kernel_name(0), plan.kernel_name(1), bad.size, bad[0])
+        if rng.random() < 0.4:                                 # the same through per-plane pointers, tight strides
+            ow, oh = plan.out_size
+            keep, sp, ss, dp, ds = [], [], [], [], []
+            for i in range(n):
+                planes = [torch.from_numpy(np.ascontiguousarray(pl)).cuda() for pl in synth.split(src[i], iw, ih)]
+                outs = [torch.full(((oh + k) // (1 + k) if k else oh, (ow + 1) // 2 if k else ow), 9, dtype=torch.uint8, device="cuda")
+                        for k in (0, 1, 1)]
+                keep += planes + outs
+                sp.append([t.data_ptr() for t in planes]); ss.append([t.shape[1] for t in planes])
+                dp.append(outs); ds.append([t.shape[1] for t in outs])
+            plan.run_frames(sp, [[t.data_ptr() for t in o] for o in dp], ss, ds)
+            torch.cuda.synchronize()
+            for i in range(n):
+                for k, w in enumerate(synth.split(want[i], ow, oh)):
+                    assert np.array_equal(dp[i][k].cpu().numpy(), w), "pointer API: %s %dx%d n=%d frame %d plane %d [%s]" % (
+                        vf, iw, ih, n, i, k, plan.kernel_name(0))
+    assert seen, "no case ran"
+
+
+@pytest.mark.parametrize("seed", range(int(__import__("os").environ.get("TTS_FUZZ_BIG_SEEDS", "6"))))
+def test_random_geometries_larger_frames(tts, oracle, seed):
+    """Frames up to ~1600 columns: long rows (two DMAs per row, paced workgroups, several row segments),
+    padded strides through the pointer API."""
+    import torch
+    rng = np.random.default_rng(5000 + seed)
+    for _ in range(5):
+        iw, ih = int(rng.integers(300, 1700)), int(rng.integers(120, 700))
+        r = float(rng.choice([rng.uniform(0.3, 1.0), rng.uniform(1.0, 4.0), rng.uniform(4.0, 14.0)]))
+        ow, oh = max(4, int(iw / r)), max(4, int(ih / (r * rng.uniform(0.8, 1.25))))
+        if ow * oh > 2_000_000:
+            continue
+        vf = "scale=%d:%d%s" % (ow, oh, rng.choice(["", ":flags=area", ""]))
+        n = int(rng.choice([1, 3, 9]))
+        plan = tts.Plan.from_vf(vf, iw, ih)
+        src = synth.frames(str(rng.choice(["random", "impulse"])), iw, ih, n)
+        want = oracle.run_chain(plan.geom, src)
+        got = plan.run_batch(torch.from_numpy(src).cuda()).cpu().numpy()
+        bad = np.flatnonzero(got != want)
+        assert bad.size == 0, "%s %dx%d n=%d [%s | %s]: %d bytes differ, first at %d" % (
+            vf, iw, ih, n, plan.kernel_name(0), plan.kernel_name(1), bad.size, bad[0])
+        # pointer API, padded strides
+        keep, sp, ss, dp, ds = [], [], [], [], []
+        pad_s, pad_d = int(rng.integers(0, 40)), int(rng.integers(0, 40))
+        for i in range(n):
+            planes, strides = [], []
+            for pl in synth.split(src[i], iw, ih):
+                t = torch.zeros((pl.shape[0], pl.shape[1] + pad_s), dtype=torch.uint8, device="cuda")
+                t[:, : pl.shape[1]] = torch.from_numpy(np.ascontiguousarray(pl)).cuda()
+                keep.append(t); planes.append(t.data_ptr()); strides.append(t.shape[1])
+            outs = [torch.full(((oh + 1) // 2 if k else oh, ((ow + 1) // 2 if k else ow) + pad_d), 9, dtype=torch.uint8, device="cuda") for k in (0, 1, 1)]
+            keep += outs
+            sp.append(planes); ss.append(strides); dp.append(outs); ds.append([t.shape[1] for t in outs])
+        plan.run_frames(sp, [[t.data_ptr() for t in o] for o in dp], ss, ds)
+        torch.cuda.synchronize()
+        for i in range(n):
+            for k, w in enumerate(synth.split(want[i], ow, oh)):
+                g = dp[i][k].cpu().numpy()
+                assert np.array_equal(g[:, : w.shape[1]], w), "pointer API: %s %dx%d n=%d frame %d plane %d [%s]" % (vf, iw, ih, n, i, k, plan.kernel_name(0))
+                assert (g[:, w.shape[1]:] == 9).all(), "wrote into the stride padding: %s" % vf

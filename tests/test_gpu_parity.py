@@ -122,6 +122,7 @@ def test_row_segmentation_is_invisible(tts, oracle, monkeypatch, seg):
     (THUMB_REF, 1283, 721, 1, "planewise"),
     ("scale=213:121", 640, 360, 3, False),                  # ... two columns per lane
     ("scale=213:121", 640, 360, 1, "planewise"),
+    ("scale=57:17", 324, 105, 2, False),                    # 26 vertical taps on 53 chroma rows: the first of two segments reaches the last row
     ("scale=20:12", 200, 120, 40, False),                   # 12-row planes: single segment -> generic kernel in pointer mode
     # source planes too small for a staged run to be slid inside them: 24 / 12-byte rows, 6 / 3-row planes
     ("scale=136:96", 24, 60, 33, False),

@@ -1017,6 +1017,7 @@ struct SegTables {
     int seg_rows = 0, nseg = 0, maxrows = 0;
     uint32_t seginfo = 0, emit = 0, vcoef = 0;     // dword offsets into the plan's table buffer
     int total_src_rows = 0;                        // sum over segments (halo cost model)
+    bool spans_plane = false;                      // some segment needs both the first and the last source row
 };
 
 // Horizontal tables of one plane class for one strip width (dword offsets into the table buffer).
@@ -1124,6 +1125,7 @@ void build_seg_tables(const ClassPlan &c, int R, int seg_rows, std::vector<uint3
         rows[s] = c.v.pos[c.y0 + y1 - 1] + VT - first[s];
         st.maxrows = std::max(st.maxrows, rows[s]);
         st.total_src_rows += rows[s];
+        st.spans_plane |= first[s] == 0 && first[s] + rows[s] >= c.src_h;
     }
     st.seginfo = uint32_t(tab.size());
     for (int s = 0; s < st.nseg; ++s) { tab.push_back(uint32_t(first[s])); tab.push_back(uint32_t(rows[s])); }
@@ -1530,7 +1532,7 @@ void choose_segs(const tts_plan *p, const int *cis, int ncls, int n, int N, stri
     }
     for (bool ok = false; !ok && best > 0; ) {         // pointer mode + LDS-staged kernel: at least min_segs segments per plane
         ok = true;
-        for (int k = 0; k < ncls; ++k) ok &= p->cls[cis[k]].segs[best].nseg >= min_segs;
+        for (int k = 0; k < ncls; ++k) ok &= p->cls[cis[k]].segs[best].nseg >= min_segs && !(min_segs > 1 && p->cls[cis[k]].segs[best].spans_plane);
         if (!ok) --best;
     }
     out_idx[0] = out_idx[1] = best;
@@ -1583,7 +1585,7 @@ size_t choose_column_segs(const tts_plan *p, const int *cis, int ncls, int n, in
     }
     for (bool ok = false; !ok && best > 0; ) {
         ok = true;
-        for (int k = 0; k < ncls; ++k) ok &= p->cls[cis[k]].segs[best].nseg >= min_segs;
+        for (int k = 0; k < ncls; ++k) ok &= p->cls[cis[k]].segs[best].nseg >= min_segs && !(min_segs > 1 && p->cls[cis[k]].segs[best].spans_plane);
         if (!ok) --best;
     }
     return best;
@@ -1643,14 +1645,15 @@ int launch_all(const tts_plan *p, const uint8_t *src, uint8_t *dst, int n, const
         const int ci = strip_cls[k];
         StripChoice ch = strip_choice(p->cls[ci], p->knobs);
         // Per-frame plane pointers: a segment of the LDS-staged kernel must not hold both the first and
-        // the last source row of a plane (see the kernel), so planes shorter than two of the shortest
-        // segments take the register kernel; taller ones are cut into at least two segments below.
+        // the last source row of a plane (see the kernel): planes whose shortest segments still do -- a
+        // single segment, or so many vertical taps that the first segment reaches the last row -- take
+        // the register kernel; others are cut into segments that do not (choose_segs).
         // (source planes under 48 bytes a row or 32 rows likewise: a run slid down from the plane's end
         // must still begin inside the plane)
         bool short_plane = false;
         for (int j = 0; j < ns; ++j) {
             const ClassPlan &cj = p->cls[strip_cls[j]];
-            short_plane |= cj.oh <= cj.segs[0].seg_rows || cj.src_w < 48 || cj.src_h < 32;
+            short_plane |= cj.segs[0].nseg < 2 || cj.segs[0].spans_plane || cj.src_w < 48 || cj.src_h < 32;
         }
         if (src_span < 4096u || (addr.use_table && short_plane)) { ch.lds = 0; ch.depth = 1; ch.LW = p->cls[ci].LW; if (ch.g12) { ch.g4 = false; ch.g12 = 0; } }
         strip_fn fn = pick_strip(ch, p->knobs);
@@ -1689,7 +1692,7 @@ int launch_all(const tts_plan *p, const uint8_t *src, uint8_t *dst, int n, const
             const ClassPlan &c = p->cls[ci];
             if (c.kind != 2 || !active(ci)) continue;
             // (per-frame plane pointers: see the strip classes above; tiny sources likewise)
-            if (src_span < 4096u || (addr.use_table && (c.oh <= c.segs[0].seg_rows || c.src_w < 48 || c.src_h < 32))) to_generic[ci] = true;
+            if (src_span < 4096u || (addr.use_table && (c.segs[0].nseg < 2 || c.segs[0].spans_plane || c.src_w < 48 || c.src_h < 32))) to_generic[ci] = true;
             else col_cls[nc++] = ci;
         }
         const bool cmerged = nc == 2 && !p->knobs.no_merge && pick_column(p->cls[0]) == pick_column(p->cls[1]);
