@@ -538,3 +538,18 @@ def test_runs_under_hip_graph_capture(tts, oracle):
         torch.cuda.synchronize()
         assert np.array_equal(o_a.cpu().numpy(), oracle.run_chain(plan.geom, a2)), rep
         assert np.array_equal(o_b.cpu().numpy(), oracle.run_chain(plan2.geom, b2)), rep
+
+
+def test_run_host_pipeline_of_many_chunks(tts, oracle, monkeypatch):
+    """tts_run_host moves a clip in chunks over two slots / two streams: with 1 MB chunks 37 small frames
+    take seven of them, the last one short; a preallocated output is filled in place."""
+    monkeypatch.setenv("TTS_HOST_CHUNK_MB", "1")
+    iw, ih, n = 320, 180, 37
+    plan = tts.Plan.from_vf("scale=426:240", iw, ih)
+    src = synth.frames("random", iw, ih, n)
+    want = oracle.run_chain(plan.geom, src)
+    assert np.array_equal(plan.run_host(src), want)
+    out = np.zeros((n, plan.out_bytes), np.uint8)
+    assert plan.run_host(src, out) is out and np.array_equal(out, want)
+    with pytest.raises(tts.TtsError):
+        plan.run_host(src, np.zeros(5, np.uint8))

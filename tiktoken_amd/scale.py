@@ -175,11 +175,14 @@ class Plan:
             stream = torch.cuda.current_stream().cuda_stream
         check(_lib.lib().tts_run(self._h, S, D, n, ctypes.c_void_p(stream)))
 
-    def run_host(self, src):
-        """numpy uint8 [n, in_bytes] on the host -> numpy [n, out_bytes]; stages through HBM."""
+    def run_host(self, src, out=None):
+        """numpy uint8 [n, in_bytes] on the host -> numpy [n, out_bytes] (`out`, if given: a C-contiguous
+        uint8 array of that size, e.g. a view of pinned memory); pipelined through HBM in chunks."""
         src = np.ascontiguousarray(src, dtype=np.uint8)
         n = src.size // self.in_bytes
-        dst = np.empty((n, self.out_bytes), np.uint8)
+        if out is not None and not (out.dtype == np.uint8 and out.flags.c_contiguous and out.size == n * self.out_bytes):
+            raise TtsError(-1, "out must be a C-contiguous uint8 array of n*out_bytes")
+        dst = np.empty((n, self.out_bytes), np.uint8) if out is None else out
         check(_lib.lib().tts_run_host(self._h, src.ctypes.data_as(ctypes.c_void_p),
                                       dst.ctypes.data_as(ctypes.c_void_p), n))
         return dst
