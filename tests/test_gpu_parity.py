@@ -404,6 +404,28 @@ def test_pointer_api_shuffled_placements(tts, oracle):
                 assert np.array_equal(dp[i][k].cpu().numpy(), w), "rep %d frame %d plane %d" % (rep, i, k)
 
 
+@pytest.mark.parametrize("vf,iw,ih,n", [
+    (PORTRAIT, 1920, 1080, 1400),                  # the paced 1024-thread workgroups, 4.35 GB in and out
+    (THUMB_REF, 1920, 1080, 1400),                 # the column walk
+    (PORTRAIT, 3840, 2160, 350),                   # grouped 12-byte windows
+])
+def test_batch_longer_than_32_bit_offsets_other_kernels(tts, oracle, vf, iw, ih, n):
+    """The same for the other walk kernels: every wave addresses from its own first frame."""
+    import torch
+    distinct = 4
+    plan = tts.Plan.from_vf(vf, iw, ih)
+    assert n * plan.in_bytes > 0xFF000000
+    base = synth.frames("random", iw, ih, distinct)
+    want = torch.from_numpy(oracle.run_chain(plan.geom, base)).cuda()
+    src = torch.from_numpy(base).cuda().repeat((n + distinct - 1) // distinct, 1)[:n].contiguous()
+    out = plan.run_batch(src)
+    torch.cuda.synchronize()
+    idx = torch.arange(n, device="cuda") % distinct
+    assert bool((out == want[idx]).all())
+    del src, out
+    torch.cuda.empty_cache()
+
+
 @pytest.mark.parametrize("chunks", [0, 1])
 def test_batch_longer_than_32_bit_offsets(tts, oracle, monkeypatch, chunks):
     """1,500 frames of 1080x1920 (4.7 GB of source) pass what 32-bit lane offsets reach from one base:
