@@ -1,13 +1,13 @@
 #!/usr/bin/env python3
 """CPU baseline of every BASELINE config: the repo's own oracle (oracle/swscale_oracle.c, NOT ffmpeg), one thread
-and T threads (frames are independent; ctypes releases the GIL).  Usage: python tools/cpu_baseline.py [threads] [seconds]"""
+and T threads (frames are independent; ctypes releases the GIL).  Usage: python tests/tools/cpu_baseline.py [threads] [seconds]"""
 import json
 import os
 import sys
 import time
 from concurrent.futures import ThreadPoolExecutor
 
-ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 sys.path.insert(0, ROOT)
 sys.path.insert(0, os.path.join(ROOT, "tests"))
 import synth

@@ -1,8 +1,9 @@
 #!/usr/bin/env python3
 """Debug helper: one chain through tts_run (every plane its own allocation, tight strides); where does it differ from the oracle?"""
 import os, sys
-sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
-sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tests"))
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, ROOT)
+sys.path.insert(0, os.path.join(ROOT, "tests"))
 import numpy as np, torch
 import tiktoken_amd as tts, synth
 from oracle import oracle

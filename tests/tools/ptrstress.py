@@ -1,8 +1,9 @@
 #!/usr/bin/env python3
 """Stress helper: one chain through tts_run many times with shuffled plane placement; report mismatches vs the oracle."""
 import os, sys, random
-sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
-sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tests"))
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, ROOT)
+sys.path.insert(0, os.path.join(ROOT, "tests"))
 import numpy as np, torch
 import tiktoken_amd as tts, synth
 from oracle import oracle
