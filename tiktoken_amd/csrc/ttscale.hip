@@ -513,6 +513,13 @@ __global__ __launch_bounds__(kMaxLdsBlock, (GC == 4 && R == 4 && LW == 4) ? 8 : 
 #if defined(__HIP_DEVICE_COMPILE__)   // the LDS-DMA builtin exists in the device pass only
     constexpr int N = 8;
     constexpr int NW = G4 ? N / GC : N;              // windows per row per lane
+    // HB ("high byte", the 4-column groups): the horizontal sum is formed as 256 x itself so that its
+    // finish is two instructions instead of three.  Pixels enter as (p - 128) << 8 -- one v_xor 0x80808080
+    // per window dword, the selectors place the byte high -- and the accumulator starts at
+    // 128 * 256 * (sum of taps) = 1 << 29 (every column's taps sum to 1 << 14 exactly), which gives
+    // 256 * sum(p * tap) with no overflow on the way.  Then val >> 7 clipped to 32767 is the high half of
+    // the SATURATING sum acc + acc (v_add_i32 clamp), and the ring insert picks that half.
+    constexpr bool HB = GC == 4;
     constexpr int kSlotBytes = NDMA * 1024 + 16;
     extern __shared__ __attribute__((aligned(16))) uint8_t lds_raw[];      // (blockDim.x / 64) x D slots
     uint8_t (*lds)[D][kSlotBytes] = reinterpret_cast<uint8_t (*)[D][kSlotBytes]>(lds_raw);
@@ -560,6 +567,11 @@ __global__ __launch_bounds__(kMaxLdsBlock, (GC == 4 && R == 4 && LW == 4) ? 8 : 
             const uint32_t *hs = tab + c.hsel + strip * N * 2;
 #pragma unroll
             for (int i = 0; i < N; ++i) { sel[i][0] = hs[2 * i]; sel[i][1] = hs[2 * i + 1]; }
+            // HB: the selectors put each pixel into the HIGH byte of its 16-bit lane (low byte zero)
+            if constexpr (HB) {
+#pragma unroll
+                for (int i = 0; i < N; ++i) { sel[i][0] = (sel[i][0] << 8) | 0x0cu; sel[i][1] = (sel[i][1] << 8) | 0x0cu; }
+            }
         }
     }
 
@@ -661,7 +673,10 @@ __global__ __launch_bounds__(kMaxLdsBlock, (GC == 4 && R == 4 && LW == 4) ? 8 : 
 #pragma unroll
                 for (int j = 0; j < NW; ++j)
 #pragma unroll
-                    for (int q = 0; q + 1 < GD; ++q) wk[j][q] = __builtin_amdgcn_alignbyte(wk[j][q + 1], wk[j][q], phase[j]);
+                    for (int q = 0; q + 1 < GD; ++q) {
+                        wk[j][q] = __builtin_amdgcn_alignbyte(wk[j][q + 1], wk[j][q], phase[j]);
+                        if constexpr (HB) wk[j][q] ^= 0x80808080u;
+                    }
             }
             // the slot is free again (its bytes sit in registers): request row k + D into it
 #pragma unroll
@@ -670,7 +685,7 @@ __global__ __launch_bounds__(kMaxLdsBlock, (GC == 4 && R == 4 && LW == 4) ? 8 : 
                                                          min(k + D, nrows - 1) * src_stride, 0, 0);
 #pragma unroll
             for (int i = 0; i < N; ++i) {
-                int acc = 0;
+                int acc = HB ? (1 << 29) : 0;
                 if constexpr (G4) {
                     constexpr int gi_div = GC;
                     acc = dot2(__builtin_amdgcn_perm(wk[i / gi_div][1], wk[i / gi_div][0], sel[i][0]), hc[i][0], acc);
@@ -683,9 +698,16 @@ __global__ __launch_bounds__(kMaxLdsBlock, (GC == 4 && R == 4 && LW == 4) ? 8 : 
                     for (int tp = 0; tp < LW / 2; ++tp)         // taps 2tp, 2tp+1 sit at bytes o + 2 (tp % 2) of dwords tp / 2, tp / 2 + 1
                         acc = dot2(__builtin_amdgcn_perm(wk[i][tp / 2 + 1], wk[i][tp / 2], psel[i][tp % 2]), hc[i][tp], acc);
                 }
-                const uint32_t t = hfinish(acc);
-                ring[i][s / 2] = (s & 1) ? __builtin_amdgcn_perm(t, ring[i][s / 2], 0x05040100)
-                                         : __builtin_amdgcn_perm(ring[i][s / 2], t, 0x07060100);
+                if constexpr (HB) {
+                    uint32_t t2;
+                    asm("v_add_i32 %0, %1, %1 clamp" : "=v"(t2) : "v"(acc));
+                    ring[i][s / 2] = (s & 1) ? __builtin_amdgcn_perm(t2, ring[i][s / 2], 0x07060100)
+                                             : __builtin_amdgcn_perm(ring[i][s / 2], t2, 0x07060302);
+                } else {
+                    const uint32_t t = hfinish(acc);
+                    ring[i][s / 2] = (s & 1) ? __builtin_amdgcn_perm(t, ring[i][s / 2], 0x05040100)
+                                             : __builtin_amdgcn_perm(ring[i][s / 2], t, 0x07060100);
+                }
             }
             for (int e = 0; e < cnt; ++e) {                     // wave-uniform
                 uint32_t vk[R / 2];
