@@ -1096,8 +1096,11 @@ int env_int(const char *name, int dflt)
 
 }  // namespace
 
-// Tuning / experiment knobs (environment), read ONCE when a plan is created so that tts_run*
-// never calls getenv.  Defaults are the product behaviour; tools/sweep.py sets them per plan.
+// Tuning knobs (environment), read ONCE when a plan is created so that tts_run* never calls getenv.
+// Defaults are the product behaviour; none of them changes a pixel (tests/test_gpu_parity.py checks
+// that); tools/sweep.py sets them per plan.  The TTS_EXP_* timing experiments of DESIGN.md 4.5 DO
+// produce wrong output (they drop or alias traffic to see what a launch costs without it) and exist
+// only in builds made with -DTTS_EXPERIMENTS.
 struct Knobs {
     int strip_n = 8, strip_d = 0, paced = -1, lds_block = 0, no_merge = 0;
     int exp_nosrc = 0, exp_nodst = 0, exp_srcpitch0 = 0, exp_dstpitch0 = 0, exp_stride0 = 0;
@@ -1107,9 +1110,11 @@ struct Knobs {
     {
         strip_n = env_int("TTS_STRIP_N", 8); strip_d = env_int("TTS_STRIP_D", 0);
         paced = env_int("TTS_PACED", -1); lds_block = env_int("TTS_LDS_BLOCK", 0); no_merge = env_int("TTS_NO_MERGE", 0);
+#ifdef TTS_EXPERIMENTS
         exp_nosrc = env_int("TTS_EXP_NOSRC", 0); exp_nodst = env_int("TTS_EXP_NODST", 0);
         exp_srcpitch0 = env_int("TTS_EXP_SRCPITCH0", 0); exp_dstpitch0 = env_int("TTS_EXP_DSTPITCH0", 0);
         exp_stride0 = env_int("TTS_EXP_STRIDE0", 0);
+#endif
         planewise = env_int("TTS_PLANEWISE", 0);
         span_chunks = env_int("TTS_SPAN_CHUNKS", 0);
     }
