@@ -94,8 +94,9 @@ def main():
     for _ in range(args.steps):
         plan.run_batch(src, dst)
     ev1.record()
-    sync()
-    wall = time.perf_counter() - t0
+    torch.cuda.synchronize()
+    wall = time.perf_counter() - t0              # this rank's K steps; the MAX over ranks is taken below
+    sync()                                       # closing bracket: barrier + synchronize
     dev_ms = ev0.elapsed_time(ev1)               # HIP events on the launch stream (torch's current stream)
 
     if dist is not None:
