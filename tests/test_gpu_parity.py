@@ -575,3 +575,41 @@ def test_run_host_pipeline_of_many_chunks(tts, oracle, monkeypatch):
     assert plan.run_host(src, out) is out and np.array_equal(out, want)
     with pytest.raises(tts.TtsError):
         plan.run_host(src, np.zeros(5, np.uint8))
+
+
+@pytest.mark.parametrize("vf,iw,ih,ss,ds", [
+    (PORTRAIT, 1920, 1080, (1984, 992), (1088, 576)),          # decoder-style line sizes in, 64-byte-aligned rows out
+    ("scale=w=720:h=1280", 480, 854, (480, 240), (768, 384)),
+    (THUMB_REF, 1283, 721, (1344, 704), (320, 160)),           # odd source, padded in, packed out (column walk + pad)
+    ("scale=320:568:flags=area", 1080, 1920, (1088, 544), (384, 192)),
+])
+def test_strided_batch_api(tts, oracle, vf, iw, ih, ss, ds):
+    """tts_run_batch_strided: packed batches whose rows carry padding (AVFrame.linesize style)."""
+    import torch
+    n = 3
+    plan = tts.Plan.from_vf(vf, iw, ih)
+    ow, oh = plan.out_size
+    src = synth.frames("random", iw, ih, n)
+    want = oracle.run_chain(plan.geom, src)
+    sp, dp = plan.strided_bytes("in", *ss), plan.strided_bytes("out", *ds)
+
+    def planes(buf, w, h, st):                         # views of the three planes of every frame of a strided buffer
+        ch, cw = (h + 1) // 2, (w + 1) // 2
+        y = buf[:, : st[0] * h].reshape(-1, h, st[0])
+        u = buf[:, st[0] * h: st[0] * h + st[1] * ch].reshape(-1, ch, st[1])
+        v = buf[:, st[0] * h + st[1] * ch: st[0] * h + 2 * st[1] * ch].reshape(-1, ch, st[1])
+        return (y, w), (u, cw), (v, cw)
+
+    s_host = np.full((n, sp), 0x5A, np.uint8)
+    for i in range(n):
+        for (view, w), pl in zip(planes(s_host, iw, ih, ss), synth.split(src[i], iw, ih)):
+            view[i, :, :w] = pl
+    d_dev = torch.full((n, dp), 7, dtype=torch.uint8, device="cuda")
+    plan.run_batch_strided(torch.from_numpy(s_host).cuda(), ss, d_dev, ds, n)
+    got = d_dev.cpu().numpy()
+    for i in range(n):
+        for (view, w), pl in zip(planes(got, ow, oh, ds), synth.split(want[i], ow, oh)):
+            assert np.array_equal(view[i, :, :w], pl), (vf, i)
+            assert (view[i, :, w:] == 7).all(), "wrote into the row padding"
+    with pytest.raises(tts.TtsError):
+        plan.run_batch_strided(torch.from_numpy(s_host).cuda(), (iw - 1, ss[1]), d_dev, ds, n)

@@ -140,26 +140,33 @@ size_t tts_frame_bytes(int w, int h)
     return size_t(w) * h + 2 * size_t((w + 1) / 2) * ((h + 1) / 2);
 }
 
-int tts_run_batch(const tts_plan *p, const void *src, size_t src_pitch, void *dst, size_t dst_pitch,
-                  int n_frames, void *hip_stream)
+}  // extern "C"
+
+namespace {
+
+// Frames at a fixed pitch, Y / U / V back to back inside a frame, rows `sstride[class]` / `dstride[class]`
+// bytes apart (class 0 = luma, 1 = both chroma planes).
+int run_batch_impl(const tts_plan *p, const void *src, size_t src_pitch, const int sstride[2], void *dst, size_t dst_pitch,
+                   const int dstride[2], int n_frames, void *hip_stream)
 {
     if (!p || n_frames < 0) return TTS_ERR_INVALID_INPUT;
     if (n_frames == 0) return TTS_OK;
     if (!src || !dst) return TTS_ERR_INVALID_INPUT;
     const tts_geom &g = p->g;
-    const size_t sbytes = tts_frame_bytes(g.in_w, g.in_h), dbytes = tts_frame_bytes(g.out_w, g.out_h);
+    for (int ci = 0; ci < 2; ++ci)
+        if (sstride[ci] < ceil_shift(g.in_w, ci) || dstride[ci] < ceil_shift(g.out_w, ci)) return TTS_ERR_INVALID_INPUT;
+    const size_t sbytes = size_t(sstride[0]) * g.in_h + 2 * size_t(sstride[1]) * ceil_shift(g.in_h, 1);
+    const size_t dbytes = size_t(dstride[0]) * g.out_h + 2 * size_t(dstride[1]) * ceil_shift(g.out_h, 1);
     if (src_pitch < sbytes || dst_pitch < dbytes) return TTS_ERR_INVALID_INPUT;
     if (src_pitch >= (size_t(1) << 31) || dst_pitch >= (size_t(1) << 31)) return TTS_ERR_UNSUPPORTED;
     hipStream_t st = static_cast<hipStream_t>(hip_stream);
 
     FrameAddr addr{};
     addr.src_pitch = uint32_t(src_pitch); addr.dst_pitch = uint32_t(dst_pitch);
-    int sstride[2], dstride[2];
     uint32_t splane = 0, dplane = 0;
     for (int k = 0; k < 3; ++k) {
         const int ci = k ? 1 : 0;
         const ClassPlan &c = p->cls[ci];
-        sstride[ci] = ceil_shift(g.in_w, ci); dstride[ci] = ceil_shift(g.out_w, ci);
         addr.src_plane[k] = splane + uint32_t(g.pre_y >> ci) * sstride[ci] + uint32_t(g.pre_x >> ci);
         addr.dst_plane[k] = dplane + uint32_t(c.pad_y) * dstride[ci] + uint32_t(c.pad_x);
         splane += uint32_t(sstride[ci]) * ceil_shift(g.in_h, ci);
@@ -188,6 +195,25 @@ int tts_run_batch(const tts_plan *p, const void *src, size_t src_pitch, void *ds
         if (rc) return rc;
     }
     return TTS_OK;
+}
+
+}  // namespace
+
+extern "C" {
+
+int tts_run_batch(const tts_plan *p, const void *src, size_t src_pitch, void *dst, size_t dst_pitch,
+                  int n_frames, void *hip_stream)
+{
+    if (!p) return TTS_ERR_INVALID_INPUT;
+    const int sstride[2] = {p->g.in_w, ceil_shift(p->g.in_w, 1)}, dstride[2] = {p->g.out_w, ceil_shift(p->g.out_w, 1)};
+    return run_batch_impl(p, src, src_pitch, sstride, dst, dst_pitch, dstride, n_frames, hip_stream);
+}
+
+int tts_run_batch_strided(const tts_plan *p, const void *src, size_t src_frame_pitch, int src_stride_y, int src_stride_c,
+                          void *dst, size_t dst_frame_pitch, int dst_stride_y, int dst_stride_c, int n_frames, void *hip_stream)
+{
+    const int sstride[2] = {src_stride_y, src_stride_c}, dstride[2] = {dst_stride_y, dst_stride_c};
+    return run_batch_impl(p, src, src_frame_pitch, sstride, dst, dst_frame_pitch, dstride, n_frames, hip_stream);
 }
 
 int tts_run(const tts_plan *p, const tts_frame *src, const tts_frame *dst, int n_frames, void *hip_stream)

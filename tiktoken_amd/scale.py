@@ -141,6 +141,24 @@ class Plan:
                                        ctypes.c_void_p(stream)))
         return dst
 
+    def strided_bytes(self, which, stride_y, stride_c):
+        """Bytes of one frame (which = "in" / "out") whose rows lie stride_y / stride_c bytes apart."""
+        w, h = self.in_size if which == "in" else self.out_size
+        return stride_y * h + 2 * stride_c * ((h + 1) // 2)
+
+    def run_batch_strided(self, src, src_strides, dst, dst_strides, n, stream=None):
+        """Packed batches with padded rows: src / dst are uint8 CUDA tensors holding n frames of
+        strided_bytes(...) each; *_strides = (luma stride, chroma stride)."""
+        import torch
+        sp, dp = self.strided_bytes("in", *src_strides), self.strided_bytes("out", *dst_strides)
+        if src.numel() < n * sp or dst.numel() < n * dp:
+            raise TtsError(-1, "buffers are smaller than n strided frames")
+        if stream is None:
+            stream = torch.cuda.current_stream(src.device).cuda_stream
+        check(_lib.lib().tts_run_batch_strided(self._h, src.data_ptr(), sp, src_strides[0], src_strides[1], dst.data_ptr(), dp,
+                                               dst_strides[0], dst_strides[1], n, ctypes.c_void_p(stream)))
+        return dst
+
     def run_batch_order(self, src, order, dst=None, stream=None):
         """Like run_batch, but output frame j comes from source frame order[j] (trimmed / looped clips)."""
         import torch
