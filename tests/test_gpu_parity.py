@@ -299,7 +299,7 @@ GROUPED6_CASES = [
     ("scale=360:200", 720, 400, 3, None),                             # 2x: 8 taps, two columns a window
     ("scale=214:120:flags=area", 720, 400, 3, None),                  # 3.4x area (BASELINE configs[2]'s ratio): 5 taps, two columns a window
     ("scale=320:568:flags=area", 1080, 1920, 2, "strip_lds<6,6,grouped2,2,1>"),   # BASELINE configs[2]
-    ("scale=1920:1080", 3840, 2160, 1, "strip_lds<8,8,grouped2,2,1>"),            # 4K -> 1080p
+    ("scale=1920:1080", 3840, 2160, 1, "strip_lds<8,8,grouped2,2,4>"),            # 4K -> 1080p: four source rows in flight
     ("scale=960:400", 1920, 400, 2, None),                            # 2x horizontally only: ring of 4
 ]
 

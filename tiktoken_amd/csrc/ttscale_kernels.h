@@ -476,10 +476,9 @@ __global__ __launch_bounds__(kMaxLdsBlock, (GC == 4 && R == 4 && LW == 4) ? 8 : 
 {
     // GC: columns that share one window (0: every column its own LW-byte window; 4 with LW = 4: 8-byte
     // windows; 4 with LW = 6, 2 with LW = 6 or 8: 12-byte windows)
-    constexpr bool G4 = GC != 0;
+    [[maybe_unused]] constexpr bool G4 = GC != 0;
     static_assert(R % 2 == 0 && (LW == 4 || LW == 6 || LW == 8) && (NDMA == 1 || NDMA == 2), "see strip_kernel");
     static_assert(GC == 0 || (GC == 4 && (LW == 4 || LW == 6)) || (GC == 2 && (LW == 6 || LW == 8)), "window shapes on offer");
-    static_assert(!(G4 && LW >= 6) || D == 1, "the 12-byte group readers address slot 0 only");
     static_assert(D >= 1 && R % D == 0, "D source rows in flight, one LDS slot each, rotating with the ring");
 #if defined(__HIP_DEVICE_COMPILE__)   // the LDS-DMA builtin exists in the device pass only
     constexpr int N = 8;
@@ -623,7 +622,11 @@ __global__ __launch_bounds__(kMaxLdsBlock, (GC == 4 && R == 4 && LW == 4) ? 8 : 
             uint32_t wk[NW][GD];                                // the aligned dwords holding each window
             if constexpr (G4 && LW >= 6) {
                 u32x2_t wv[NW][2];
-                if constexpr (NW == 2) TTS_LDS_READ_WIN4_X2(wv, lpos); else TTS_LDS_READ_WIN4_X4(wv, lpos);
+                // (ds_read2's 8-bit dword offsets cannot reach the second slot: its addresses are a few VALU adds)
+                uint32_t lp[NW];
+#pragma unroll
+                for (int j = 0; j < NW; ++j) lp[j] = lpos[j] + uint32_t(s % D) * uint32_t(kSlotBytes);
+                if constexpr (NW == 2) TTS_LDS_READ_WIN4_X2(wv, lp); else TTS_LDS_READ_WIN4_X4(wv, lp);
 #pragma unroll
                 for (int j = 0; j < NW; ++j) { wk[j][0] = wv[j][0].x; wk[j][1] = wv[j][0].y; wk[j][2] = wv[j][1].x; wk[j][3] = wv[j][1].y; }
             } else if constexpr (G4) {
