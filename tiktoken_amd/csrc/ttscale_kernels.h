@@ -722,39 +722,37 @@ __global__ __launch_bounds__(kMaxLdsBlock, (GC == 4 && R == 4 && LW == 4) ? 8 : 
 // int16 pairs; an output row is R/2 v_dot2 against the wave-uniform vertical taps and one byte
 // store per lane (a wave stores 64 contiguous bytes).  Every source byte is read once per row
 // segment; the generic kernel re-reads each one taps^2 / ratio^2 times.
+// NDW aligned dwords starting at LDS address p, any NDW: ds_read2_b32 pairs (+ one ds_read_b32), ONE wait,
+// then every register is passed through an empty asm so that no use can be scheduled before the wait
+// (volatile asm statements keep their order; the compiler knows nothing of the reads themselves, so it adds
+// no waits of its own -- see the window readers above).
+template <int I> __device__ __forceinline__ void lds_rd2(u32x2_t &t, uint32_t p)
+{
+    asm volatile("ds_read2_b32 %0, %1 offset0:%2 offset1:%3" : "=v"(t) : "v"(p), "n"(I), "n"(I + 1) : "memory");
+}
+template <int I> __device__ __forceinline__ void lds_rd1(uint32_t &t, uint32_t p)
+{
+    asm volatile("ds_read_b32 %0, %1 offset:%2" : "=v"(t) : "v"(p), "n"(4 * I) : "memory");
+}
+__device__ __forceinline__ void lds_landed(u32x2_t &t) { asm volatile("" : "+v"(t)); }
+__device__ __forceinline__ void lds_landed(uint32_t &t) { asm volatile("" : "+v"(t)); }
+template <int NDW, int... I>
+__device__ __forceinline__ void lds_read_dwords_impl(uint32_t (&w)[NDW], uint32_t p, std::integer_sequence<int, I...>)
+{
+    u32x2_t t[NDW / 2];
+    uint32_t last = 0;
+    (lds_rd2<2 * I>(t[I], p), ...);
+    if constexpr (NDW % 2 != 0) lds_rd1<NDW - 1>(last, p);
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    (lds_landed(t[I]), ...);
+    if constexpr (NDW % 2 != 0) lds_landed(last);
+    ((w[2 * I] = t[I].x, w[2 * I + 1] = t[I].y), ...);
+    if constexpr (NDW % 2 != 0) w[NDW - 1] = last;
+}
 template <int NDW>
-__device__ __forceinline__ void lds_read_dwords(uint32_t (&w)[NDW], uint32_t p);
-template <>
-[[maybe_unused]] __device__ __forceinline__ void lds_read_dwords<5>(uint32_t (&w)[5], uint32_t p)
+__device__ __forceinline__ void lds_read_dwords(uint32_t (&w)[NDW], uint32_t p)
 {
-    u32x2_t a, b; uint32_t e;
-    asm volatile("ds_read2_b32 %0, %3 offset1:1\n\tds_read2_b32 %1, %3 offset0:2 offset1:3\n\t"
-                 "ds_read_b32 %2, %3 offset:16\n\ts_waitcnt lgkmcnt(0)"
-                 : "=&v"(a), "=&v"(b), "=&v"(e) : "v"(p) : "memory");
-    w[0] = a.x; w[1] = a.y; w[2] = b.x; w[3] = b.y; w[4] = e;
-}
-template <>
-[[maybe_unused]] __device__ __forceinline__ void lds_read_dwords<9>(uint32_t (&w)[9], uint32_t p)
-{
-    u32x2_t a, b, c, d; uint32_t e;
-    asm volatile("ds_read2_b32 %0, %5 offset1:1\n\tds_read2_b32 %1, %5 offset0:2 offset1:3\n\t"
-                 "ds_read2_b32 %2, %5 offset0:4 offset1:5\n\tds_read2_b32 %3, %5 offset0:6 offset1:7\n\t"
-                 "ds_read_b32 %4, %5 offset:32\n\ts_waitcnt lgkmcnt(0)"
-                 : "=&v"(a), "=&v"(b), "=&v"(c), "=&v"(d), "=&v"(e) : "v"(p) : "memory");
-    w[0] = a.x; w[1] = a.y; w[2] = b.x; w[3] = b.y; w[4] = c.x; w[5] = c.y; w[6] = d.x; w[7] = d.y; w[8] = e;
-}
-template <>
-[[maybe_unused]] __device__ __forceinline__ void lds_read_dwords<17>(uint32_t (&w)[17], uint32_t p)
-{
-    u32x2_t a, b, c, d, e, f, g, h; uint32_t i;
-    asm volatile("ds_read2_b32 %0, %9 offset1:1\n\tds_read2_b32 %1, %9 offset0:2 offset1:3\n\t"
-                 "ds_read2_b32 %2, %9 offset0:4 offset1:5\n\tds_read2_b32 %3, %9 offset0:6 offset1:7\n\t"
-                 "ds_read2_b32 %4, %9 offset0:8 offset1:9\n\tds_read2_b32 %5, %9 offset0:10 offset1:11\n\t"
-                 "ds_read2_b32 %6, %9 offset0:12 offset1:13\n\tds_read2_b32 %7, %9 offset0:14 offset1:15\n\t"
-                 "ds_read_b32 %8, %9 offset:64\n\ts_waitcnt lgkmcnt(0)"
-                 : "=&v"(a), "=&v"(b), "=&v"(c), "=&v"(d), "=&v"(e), "=&v"(f), "=&v"(g), "=&v"(h), "=&v"(i) : "v"(p) : "memory");
-    w[0] = a.x; w[1] = a.y; w[2] = b.x; w[3] = b.y; w[4] = c.x; w[5] = c.y; w[6] = d.x; w[7] = d.y;
-    w[8] = e.x; w[9] = e.y; w[10] = f.x; w[11] = f.y; w[12] = g.x; w[13] = g.y; w[14] = h.x; w[15] = h.y; w[16] = i;
+    lds_read_dwords_impl<NDW>(w, p, std::make_integer_sequence<int, NDW / 2>{});
 }
 
 // NTP: tap pairs per column (window = 2 * NTP bytes); R: ring depth >= vertical taps; NDMA as above;

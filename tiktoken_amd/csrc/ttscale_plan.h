@@ -198,9 +198,11 @@ int build_class(const tts_geom &g, int sub, ClassPlan &c, std::vector<uint32_t> 
     if (!strip_ok) {
         // Many taps: the column walk, if the taps fit its windows and ring and the runs fit its slot.
         c.kind = 0;
-        // three instantiations, by the larger tap count of the two axes: up to 16, 32, 64 taps
+        // one instantiation per 4 taps of the larger tap count of the two axes: 6, 8, ... 32 tap pairs
+        // (windows of 2 NTP bytes, ring of 2 NTP rows) -- the work is one v_perm + v_dot2 per tap pair per
+        // source row, so a window cut to fit the taps is that much less arithmetic
         const int mt = std::max(HT, VT);
-        const int NTP = mt <= 16 ? 8 : mt <= 32 ? 16 : 32, Rc = 2 * NTP;
+        const int NTP = std::max(6, ((mt + 1) / 2 + 1) & ~1), Rc = 2 * NTP;
         if (HT > 64 || VT > 64 || c.src_w < 2 * NTP || !monotone(c.v.pos) || env_int("TTS_FORCE_GENERIC", 0)) return TTS_OK;
         HTables t;                                     // (only `strips` is used by lds_dmas)
         t.strips = c.ow;
@@ -220,7 +222,7 @@ int build_class(const tts_geom &g, int sub, ClassPlan &c, std::vector<uint32_t> 
         // columns per lane: two at 8 tap pairs (2160x3840 -> 720x1280: 25 -> 41 % of peak; four measured the
         // same there and 5 % slower on 4K -> 720p, at 110 VGPRs), one above (two at 16 tap pairs made no
         // difference to the 1080p thumbnail), if the 64-strip runs fit the LDS slot
-        int dmas = 0, nc = NTP == 8 ? 2 : 1;
+        int dmas = 0, nc = NTP <= 8 ? 2 : 1;
         const int forced_nc = env_int("TTS_COL_NC", 0);
         if (forced_nc == 1 || forced_nc == 2) nc = std::min(nc, forced_nc);
         for (; nc >= 1 && !dmas; nc = dmas ? nc : nc / 2) {
@@ -547,12 +549,27 @@ void choose_segs(const tts_plan *p, const int *cis, int ncls, int n, int N, stri
 
 strip_fn pick_column(const ClassPlan &c)
 {
-#define TTS_COL_PICK(NTP_, R_, NC_) (c.col_dmas == 1 ? column_lds_kernel<NTP_, R_, 1, NC_> : column_lds_kernel<NTP_, R_, 2, NC_>)
-    if (c.NTP == 8 && c.Rc == 16) return c.col_nc == 2 ? TTS_COL_PICK(8, 16, 2) : TTS_COL_PICK(8, 16, 1);
-    if (c.NTP == 16 && c.Rc == 32 && c.col_nc == 1) return TTS_COL_PICK(16, 32, 1);
-    if (c.NTP == 32 && c.Rc == 64 && c.col_nc == 1) return TTS_COL_PICK(32, 64, 1);
+#define TTS_COL_PICK(NTP_, NC_) (c.col_dmas == 1 ? column_lds_kernel<NTP_, 2 * NTP_, 1, NC_> : column_lds_kernel<NTP_, 2 * NTP_, 2, NC_>)
+    if (c.Rc != 2 * c.NTP) return nullptr;
+    if (c.col_nc == 2) return c.NTP == 6 ? TTS_COL_PICK(6, 2) : c.NTP == 8 ? TTS_COL_PICK(8, 2) : nullptr;
+    switch (c.NTP) {
+    case 6: return TTS_COL_PICK(6, 1);
+    case 8: return TTS_COL_PICK(8, 1);
+    case 10: return TTS_COL_PICK(10, 1);
+    case 12: return TTS_COL_PICK(12, 1);
+    case 14: return TTS_COL_PICK(14, 1);
+    case 16: return TTS_COL_PICK(16, 1);
+    case 18: return TTS_COL_PICK(18, 1);
+    case 20: return TTS_COL_PICK(20, 1);
+    case 22: return TTS_COL_PICK(22, 1);
+    case 24: return TTS_COL_PICK(24, 1);
+    case 26: return TTS_COL_PICK(26, 1);
+    case 28: return TTS_COL_PICK(28, 1);
+    case 30: return TTS_COL_PICK(30, 1);
+    case 32: return TTS_COL_PICK(32, 1);
+    default: return nullptr;
+    }
 #undef TTS_COL_PICK
-    return nullptr;
 }
 
 void fill_column_class(const tts_plan *p, int ci, int n, int src_stride, int dst_stride, const SegTables &st,
