@@ -2,9 +2,9 @@
 """bench.py -- frames/s of the 1080p -> 1080x1920 portrait scale+crop hot path on MI355X.
 
 One step = one pass of libttscale over one HBM-resident batch of synthetic yuv420p frames
-(BASELINE.json configs[1] geometry, batched: 1,200 frames = 40 s of 1080p30, 3.7 GB of source and
-3.7 GB of output per GPU, one kernel launch; `--frames 300` is the 10 s clip of configs[0]: the
-launch's ramp and tail weigh more there, 906 k frames/s against 985 k).
+(BASELINE.json configs[1] geometry, batched: 1,350 frames = 45 s of 1080p30, 4.2 GB of source and
+4.2 GB of output per GPU, one kernel launch; `--frames 300` is the 10 s clip of configs[0]: the
+launch's ramp and tail weigh more there, 906 k frames/s against 990 k).
 Multi-GPU: one process per GPU, every rank owns its own clip (clip-sharded, no data-path
 collective; torch.distributed is used for the barrier and the max-over-ranks only).
 
@@ -51,7 +51,8 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=100)
     ap.add_argument("--warmup", type=int, default=10)
-    ap.add_argument("--frames", type=int, default=1200, help="frames per GPU per step")
+    ap.add_argument("--frames", type=int, default=1350, help="frames per GPU per step (1,350 x 3.11 MB = 4.2 GB: the most that "
+                                                             "fits one set of launch-wide buffer descriptors, DESIGN.md 3)")
     ap.add_argument("--settle", type=int, default=20,
                     help="untimed launches BEFORE the warm-up steps: back-to-back launch times drift 0.33 -> 0.42 -> 0.35 ms over "
                          "the first ~30 launches of a burst while the clock governor settles (DESIGN.md 4.5); the metric is sustained rate")
