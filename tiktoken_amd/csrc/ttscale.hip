@@ -190,7 +190,7 @@ int run_batch_impl(const tts_plan *p, const void *src, size_t src_pitch, const i
         const uint8_t *s = static_cast<const uint8_t *>(src) + size_t(f0) * src_pitch;
         uint8_t *d = static_cast<uint8_t *>(dst) + size_t(f0) * dst_pitch;
         const uint64_t sspan = uint64_t(n - 1) * src_pitch + sbytes, dspan = uint64_t(n - 1) * dst_pitch + dbytes;
-        addr.wave_base = sspan > kMaxSpan || dspan > kMaxSpan;
+        addr.wave_base = sspan > kMaxSpan || dspan > kMaxSpan || p->knobs.wave_base;
         const int rc = launch_all(p, s, d, n, sstride, dstride, sspan, dspan, addr, st);
         if (rc) return rc;
     }

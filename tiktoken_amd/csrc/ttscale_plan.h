@@ -81,6 +81,7 @@ struct Knobs {
     int exp_nosrc = 0, exp_nodst = 0, exp_srcpitch0 = 0, exp_dstpitch0 = 0, exp_stride0 = 0;
     int planewise = 0;                // tts_run: always take the plane-by-plane path (test knob)
     int span_chunks = 0;              // tts_run_batch: always cut batches into launches whose whole span fits 32 bits (test knob)
+    int wave_base = 0;                // tts_run_batch: per-wave descriptors even when the batch fits one base (test knob)
     void read()
     {
         strip_n = env_int("TTS_STRIP_N", 8); strip_d = env_int("TTS_STRIP_D", 0);
@@ -92,6 +93,7 @@ struct Knobs {
 #endif
         planewise = env_int("TTS_PLANEWISE", 0);
         span_chunks = env_int("TTS_SPAN_CHUNKS", 0);
+        wave_base = env_int("TTS_WAVE_BASE", 0);
     }
 };
 
