@@ -467,9 +467,10 @@ __device__ __forceinline__ void plan_runs(const StripArgs &a, const StripClass &
     if (pm || prefix > 64u * NDMA) __builtin_trap();
 }
 
-// LW, R as in strip_kernel; G4: grouped windows (two 8-byte windows per lane, taps <= 4), else one
-// LW-byte window per column; NDMA: 1 KiB LDS-DMAs per source row (the wave's runs hold <= 64 * NDMA
-// sixteen-byte chunks).  Eight columns per lane.
+// LW: window bytes per column (4, 6, 8 for <= 4, 5-6, 7-8 horizontal taps); R: ring rows (>= vertical
+// taps); GC: columns that share one LDS window (0 = none, see the static_assert below; "G4" in the body
+// means GC != 0); NDMA: 1 KiB LDS-DMAs per source row (the wave's runs hold <= 64 * NDMA sixteen-byte
+// chunks); D: source rows in flight per wave, one LDS slot each.  Eight columns per lane.
 template <int LW, int R, int GC, int NDMA, int D>
 __global__ __launch_bounds__(kMaxLdsBlock, (GC == 4 && R == 4 && LW == 4) ? 8 : 4) void strip_lds_kernel(const uint8_t *__restrict__ src, uint8_t *__restrict__ dst,
                                                                                const uint32_t *__restrict__ tab, const StripArgs a)
