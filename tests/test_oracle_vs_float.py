@@ -80,3 +80,22 @@ def test_oracle_is_the_textbook_resampler_within_rounding(tts, oracle, vf, iw, i
         worst = max(worst, float(diff.max()))
         assert diff.mean() < 0.6, (vf, k, diff.mean())
     assert worst <= tol, (vf, worst)
+
+
+def test_range_step_is_the_textbook_mapping_within_one_level(tts, oracle):
+    """format=yuvj420p after the chain: limited -> full range.  Textbook: Y' = (Y - 16) * 255 / 219,
+    C' = (C - 128) * 255 / 224 + 128, clipped.  swscale's fixed-point constants (recalled) may round
+    differently by a level, and clip the input to the nominal range first."""
+    g = tts.parse_vf("format=yuvj420p", 16, 16)
+    frames = np.zeros((4, 16 * 16 + 2 * 64), np.uint8)
+    for f in range(4):
+        frames[f, :256] = np.arange(256)
+        frames[f, 256:320] = np.arange(64) + 64 * f
+        frames[f, 320:] = np.arange(64) + 64 * f
+    got = oracle.run_chain(g, frames)
+    y = got[0, :256].astype(np.float64)
+    c = np.concatenate([got[f, 256:320] for f in range(4)]).astype(np.float64)
+    p = np.arange(256, dtype=np.float64)
+    assert np.abs(y - np.clip((p - 16) * 255 / 219, 0, 255)).max() <= 1.0
+    assert np.abs(c - np.clip((np.clip(p, 16, 240) - 128) * 255 / 224 + 128, 0, 255)).max() <= 1.0
+    assert np.array_equal(np.concatenate([got[f, 320:] for f in range(4)]), c.astype(np.uint8))
