@@ -13,6 +13,7 @@
 
 #include <cstdint>
 #include <cstring>
+#include <map>
 #include <string>
 
 #include "../include/ttscale.h"
@@ -76,6 +77,26 @@ napi_value FrameBytes(napi_env env, napi_callback_info info)
     return out;
 }
 
+// Plans are kept between calls (a script converts many clips of a few geometries, the app one
+// thumbnail after another): building one costs about a millisecond, a frame far less.  Node runs
+// addon calls on one thread; the map is never shared.
+tts_plan *cached_plan(const std::string &vf, int32_t iw, int32_t ih, const tts_geom &g, int *rc)
+{
+    static std::map<std::string, tts_plan *> plans;
+    const std::string key = vf + "|" + std::to_string(iw) + "x" + std::to_string(ih);
+    auto it = plans.find(key);
+    if (it != plans.end()) { *rc = TTS_OK; return it->second; }
+    if (plans.size() >= 32) {                       // bounded: drop everything rather than track ages
+        for (auto &kv : plans) tts_plan_destroy(kv.second);
+        plans.clear();
+    }
+    tts_plan *plan = nullptr;
+    *rc = tts_plan_create(&g, &plan);
+    if (*rc) return nullptr;
+    plans[key] = plan;
+    return plan;
+}
+
 napi_value RunHost(napi_env env, napi_callback_info info)
 {
     napi_value argv[4];
@@ -89,13 +110,11 @@ napi_value RunHost(napi_env env, napi_callback_info info)
     const size_t sb = tts_frame_bytes(g.in_w, g.in_h), db = tts_frame_bytes(g.out_w, g.out_h);
     if (len == 0 || len % sb) return throw_status(env, "buffer is not a whole number of frames", TTS_ERR_INVALID_INPUT);
     const int n = int(len / sb);
-    tts_plan *plan = nullptr;
-    rc = tts_plan_create(&g, &plan);
+    tts_plan *plan = cached_plan(vf, iw, ih, g, &rc);
     if (rc) return throw_status(env, "plan", rc);
     napi_value out; void *dst = nullptr;
-    if (napi_create_buffer(env, db * n, &dst, &out) != napi_ok) { tts_plan_destroy(plan); return throw_status(env, "allocation", TTS_ERR_PROCESSING_FAILED); }
+    if (napi_create_buffer(env, db * n, &dst, &out) != napi_ok) return throw_status(env, "allocation", TTS_ERR_PROCESSING_FAILED);
     rc = tts_run_host(plan, src, dst, n);
-    tts_plan_destroy(plan);
     if (rc) return throw_status(env, "run", rc);
     return out;
 }
