@@ -27,6 +27,10 @@ CASES = {
     "third": ("scale=1280:720", 3840, 2160, 12441600 + 1382400),        # 4K -> 720p, 3x: 13 taps
     "stretch": ("scale=w=720:h=1280", 480, 854, 614880 + 1382400),
     "thumb": ("scale=320:568:flags=area", 1080, 1920, 3383040),
+    # area thumbnails at larger ratios: 6x (1080p -> 320x180), 4x (720p), 12x (4K)
+    "area6": ("scale=320:180:flags=area", 1920, 1080, 3110400 + 86400),
+    "area4": ("scale=320:180:flags=area", 1280, 720, 1382400 + 86400),
+    "area12": ("scale=320:180:flags=area", 3840, 2160, 12441600 + 86400),
 }
 
 
