@@ -156,7 +156,7 @@ int tts_plan_filter(const tts_plan *p, int plane_class, int axis,
 int tts_build_filter(int src, int dst, int one, int alg, int *taps, int16_t *coef, int32_t *pos);
 
 /* Which kernel the plan dispatches to for a plane class: 0 = generic, 1 = strip walk with register
- * gathers, 2 / 3 = LDS-staged strip walk with one / two LDS-DMAs per source row, 4 / 5 = column walk
+ * gathers, 2 / 3 = LDS-staged strip walk with one / more (two or four) LDS-DMAs per source row, 4 / 5 = column walk
  * (9..64 taps per axis) with one / two LDS-DMAs per source row. */
 int tts_plan_kernel_kind(const tts_plan *p, int plane_class);
 /* The same with the template arguments, for logs and tests: "strip_lds<6,6,grouped,1,1>" = window bytes,

@@ -278,7 +278,8 @@ LDS_CASES = [
     ("scale=16:16", 12, 12, 500, None),                    # 2 luma strips, 1 chroma strip per row: too many pieces -> register walk
     ("scale=320:568:flags=area", 1080, 1920, 3, 3),        # 5-tap per-column windows, 40 strips per row, 1.1 KB runs: two DMAs
     ("scale=256:144:flags=area", 960, 540, 9, 3),          # 3.75x area: source run of a wave needs two DMAs
-    ("scale=200:112:flags=area", 1400, 784, 5, 1),         # 7x area: run does not fit two DMAs -> register walk
+    ("scale=200:112:flags=area", 1400, 784, 5, 3),         # 7x area: a wave's runs take four DMAs per row
+    ("scale=320:180:flags=area", 1280, 720, 4, 3),         # 4x area, 4 taps: four DMAs
     ("scale=3413:1920,crop=1080:1920", 3840, 2160, 1, 2),  # 6-tap bicubic downscale, 8-byte windows
     ("scale=1080:1920:force_original_aspect_ratio=increase,crop=1024:1920", 1920, 1080, 2, 2),   # aligned rows: unpaced
     ("scale=1080:1920:force_original_aspect_ratio=increase,crop=1080:1920", 1920, 1080, 9, 2),   # paced, 1024-thread workgroups
@@ -355,7 +356,7 @@ def test_lds_kernel_variants(tts, oracle, vf, iw, ih, n, kind):
 
 
 @pytest.mark.parametrize("knob,val", [("TTS_PACED", "1"), ("TTS_PACED", "0"), ("TTS_LDS_BLOCK", "64"), ("TTS_LDS_BLOCK", "704"),
-                                      ("TTS_STRIP_D", "2"), ("TTS_NO_LDS", "1"), ("TTS_NO_G4", "1"), ("TTS_NO_G6", "1"), ("TTS_NO_MERGE", "1"), ("TTS_COL_NC", "1"), ("TTS_WAVE_BASE", "1")])
+                                      ("TTS_STRIP_D", "2"), ("TTS_NO_LDS", "1"), ("TTS_NO_G4", "1"), ("TTS_NO_G6", "1"), ("TTS_NO_MERGE", "1"), ("TTS_COL_NC", "1"), ("TTS_WAVE_BASE", "1"), ("TTS_NO_DMA4", "1")])
 def test_tuning_knobs_do_not_change_pixels(tts, oracle, monkeypatch, knob, val):
     import torch
     monkeypatch.setenv(knob, val)

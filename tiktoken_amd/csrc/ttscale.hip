@@ -116,7 +116,8 @@ int tts_plan_kernel_kind(const tts_plan *p, int plane_class)
     const ClassPlan &c = p->cls[plane_class];
     if (c.kind == 0) return 0;
     if (c.kind == 2) return 3 + c.col_dmas;
-    return 1 + strip_choice(c, p->knobs).lds;
+    const int lds = strip_choice(c, p->knobs).lds;
+    return lds == 0 ? 1 : lds == 1 ? 2 : 3;
 }
 
 const char *tts_plan_kernel_name(const tts_plan *p, int plane_class)

@@ -478,7 +478,7 @@ __global__ __launch_bounds__(kMaxLdsBlock, (GC == 4 && R == 4 && LW == 4) ? 8 : 
     // GC: columns that share one window (0: every column its own LW-byte window; 4 with LW = 4: 8-byte
     // windows; 4 with LW = 6, 2 with LW = 6 or 8: 12-byte windows)
     [[maybe_unused]] constexpr bool G4 = GC != 0;
-    static_assert(R % 2 == 0 && (LW == 4 || LW == 6 || LW == 8) && (NDMA == 1 || NDMA == 2), "see strip_kernel");
+    static_assert(R % 2 == 0 && (LW == 4 || LW == 6 || LW == 8) && (NDMA == 1 || NDMA == 2 || NDMA == 4), "see strip_kernel");
     static_assert(GC == 0 || (GC == 4 && (LW == 4 || LW == 6)) || (GC == 2 && (LW == 6 || LW == 8)), "window shapes on offer");
     static_assert(D >= 1 && R % D == 0, "D source rows in flight, one LDS slot each, rotating with the ring");
 #if defined(__HIP_DEVICE_COMPILE__)   // the LDS-DMA builtin exists in the device pass only

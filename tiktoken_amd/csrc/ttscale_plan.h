@@ -152,7 +152,7 @@ void build_seg_tables(const ClassPlan &c, int R, int seg_rows, std::vector<uint3
 // bytes per row touched, each rounded out to 16-byte chunks (worst case over the run's alignment);
 // the runs must fit 64 chunks per DMA and kMaxPieces runs.  `lo` holds the first byte of each of the
 // `nw` windows of a strip, `win` their width.  0 = not usable.
-int lds_dmas(const ClassPlan &c, const HTables &t, int N, const int *lo, int nw, int win)
+int lds_dmas(const ClassPlan &c, const HTables &t, int N, const int *lo, int nw, int win, bool four = false)
 {
     if ((N != 8 && N != 4 && N != 2 && N != 1) || c.ow < N || t.strips < 2 || env_int("TTS_NO_LDS", 0)) return 0;
     auto chunks = [&](int s0, int s1) {   // strips [s0, s1] of one row
@@ -171,7 +171,8 @@ int lds_dmas(const ClassPlan &c, const HTables &t, int N, const int *lo, int nw,
         if (pieces > kMaxPieces) return 0;
         worst = std::max(worst, n);
     }
-    return worst <= 64u ? 1 : worst <= 128u ? 2 : 0;
+    // (four DMAs a row: the per-column strip kernels only -- 4x..7x `area` thumbnails, whose 64 strips read 2-4 KB a row)
+    return worst <= 64u ? 1 : worst <= 128u ? 2 : (four && worst <= 256u) ? 4 : 0;
 }
 
 int build_class(const tts_geom &g, int sub, ClassPlan &c, std::vector<uint32_t> &tab)
@@ -329,7 +330,7 @@ int build_class(const tts_geom &g, int sub, ClassPlan &c, std::vector<uint32_t> 
         } else {
             for (int i = 0; i < ncols; ++i) lo[i] = int(tab[t.hoff + i]);
         }
-        t.lds_col = lds_dmas(c, t, N, lo.data(), N, c.LWlds);
+        t.lds_col = lds_dmas(c, t, N, lo.data(), N, c.LWlds, !env_int("TTS_NO_DMA4", 0));
         // Grouped 12-byte windows: GC columns share one window, read as four aligned dwords -- 8 (GC = 4) or
         // 16 (GC = 2) LDS dwords per lane and row instead of 24.  Tap j of a column whose first tap is byte d
         // of the window is picked out of the dword pair (j/4, j/4 + 1): d + j - 4 (j/4) must stay <= 7, and
@@ -431,7 +432,7 @@ strip_fn pick_strip(const StripChoice &ch, const Knobs &kn)
 #undef TTS_G2_PICK
     }
     if (ch.lds) {
-#define TTS_LDS_PICK(LW_, R_) (ch.lds == 1 ? strip_lds_kernel<LW_, R_, 0, 1, 1> : strip_lds_kernel<LW_, R_, 0, 2, 1>)
+#define TTS_LDS_PICK(LW_, R_) (ch.lds == 1 ? strip_lds_kernel<LW_, R_, 0, 1, 1> : ch.lds == 2 ? strip_lds_kernel<LW_, R_, 0, 2, 1> : strip_lds_kernel<LW_, R_, 0, 4, 1>)
         if (ch.LW == 4) return ch.R == 4 ? TTS_LDS_PICK(4, 4) : ch.R == 6 ? TTS_LDS_PICK(4, 6) : TTS_LDS_PICK(4, 8);
         if (ch.LW == 6) return ch.R == 4 ? TTS_LDS_PICK(6, 4) : ch.R == 6 ? TTS_LDS_PICK(6, 6) : TTS_LDS_PICK(6, 8);
         return ch.R == 4 ? TTS_LDS_PICK(8, 4) : ch.R == 6 ? TTS_LDS_PICK(8, 6) : TTS_LDS_PICK(8, 8);
