@@ -354,7 +354,7 @@ int build_class(const tts_geom &g, int sub, ClassPlan &c, std::vector<uint32_t> 
                     }
                 }
                 if (!ok) continue;
-                const int lds = lds_dmas(c, t, N, glo.data(), N / gc, 12);
+                const int lds = lds_dmas(c, t, N, glo.data(), N / gc, 12, gc == 2 && !env_int("TTS_NO_DMA4", 0));
                 if (!lds || (gc == 4 && lds != 1)) continue;            // (the 4-column kernels exist for one DMA only)
                 HTables::Grouped12 &gr = t.g12;
                 gr.lw = lw; gr.gc = gc; gr.lds = lds;
@@ -425,7 +425,7 @@ strip_fn pick_strip(const StripChoice &ch, const Knobs &kn)
     }
     if (ch.lds && ch.g12 == 4) return ch.R == 4 ? strip_lds_kernel<6, 4, 4, 1, 1> : ch.R == 6 ? strip_lds_kernel<6, 6, 4, 1, 1> : strip_lds_kernel<6, 8, 4, 1, 1>;
     if (ch.lds && ch.g12 == 2) {
-#define TTS_G2_PICK(LW_, R_) (ch.lds == 1 ? strip_lds_kernel<LW_, R_, 2, 1, 1> : strip_lds_kernel<LW_, R_, 2, 2, 1>)
+#define TTS_G2_PICK(LW_, R_) (ch.lds == 1 ? strip_lds_kernel<LW_, R_, 2, 1, 1> : ch.lds == 2 ? strip_lds_kernel<LW_, R_, 2, 2, 1> : strip_lds_kernel<LW_, R_, 2, 4, 1>)
         if (ch.depth == 4) return strip_lds_kernel<8, 8, 2, 2, 4>;
         if (ch.LW == 6) return ch.R == 4 ? TTS_G2_PICK(6, 4) : ch.R == 6 ? TTS_G2_PICK(6, 6) : TTS_G2_PICK(6, 8);
         return ch.R == 4 ? TTS_G2_PICK(8, 4) : ch.R == 6 ? TTS_G2_PICK(8, 6) : TTS_G2_PICK(8, 8);

@@ -30,6 +30,7 @@ CASES = {
     # area thumbnails at larger ratios: 6x (1080p -> 320x180), 4x (720p), 12x (4K)
     "area6": ("scale=320:180:flags=area", 1920, 1080, 3110400 + 86400),
     "area4": ("scale=320:180:flags=area", 1280, 720, 1382400 + 86400),
+    "bil4": ("scale=320:180:flags=bilinear", 1280, 720, 1382400 + 86400),
     "area12": ("scale=320:180:flags=area", 3840, 2160, 12441600 + 86400),
 }
 
