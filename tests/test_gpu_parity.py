@@ -107,7 +107,7 @@ def test_row_segmentation_is_invisible(tts, oracle, monkeypatch, seg):
 
 @pytest.mark.parametrize("vf,iw,ih,n,pad", [
     ("scale=284:160", 160, 90, 5, True),
-    ("scale=284:160", 160, 90, 40, False),       # more than one launch group (32 frames each), tight strides
+    ("scale=284:160", 160, 90, 130, False),      # more than one launch group (120 frames each), tight strides
     ("scale=136:96", 100, 60, 40, False),        # rows of 100 / 50 bytes: the runs of the LDS walk must stay inside each plane
     ("scale=72:40", 54, 30, 33, False),          # planes of a single short segment -> register walk in pointer mode
     ("scale=640:360:flags=area", 1283, 721, 3, False),

@@ -18,7 +18,7 @@ constexpr int kBlock = 256;
 constexpr int kMaxLdsBlock = 1024;    // largest workgroup of the LDS-staged kernel
 constexpr size_t kMaxSpan = 0xFF000000u;   // bytes one launch may address from its base pointers
 [[maybe_unused]] constexpr uint32_t kDiscard = 0xFFFFFF00u; // a lane offset the buffer range check always rejects (> kMaxSpan)
-constexpr int kMaxTableFrames = 32;   // frames addressed through the in-kernarg offset table
+constexpr int kMaxTableFrames = 120;  // frames addressed through the in-kernarg offset table (kernel arguments stay under 4 KB)
 
 typedef short short2_t __attribute__((ext_vector_type(2)));
 typedef uint32_t u32x2_t __attribute__((ext_vector_type(2)));
