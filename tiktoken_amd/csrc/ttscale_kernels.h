@@ -760,16 +760,17 @@ __device__ __forceinline__ void lds_read_dwords(uint32_t (&w)[NDW], uint32_t p)
 // NC: adjacent output columns per lane (1, 2 or 4: the per-row bookkeeping -- DMA, waits, loop control,
 // the store -- is the same for 1 byte or 4, so small ratios, where it weighs most, take the widest
 // strip their registers allow; the last strip of a row is slid left like strip_lds_kernel's).
-template <int NTP, int R, int NDMA, int NC>
+template <int NTP, int R, int NDMA, int NC, int D = 1>
 __global__ __launch_bounds__(kBlock) void column_lds_kernel(const uint8_t *__restrict__ src, uint8_t *__restrict__ dst,
                                                             const uint32_t *__restrict__ tab, const StripArgs a)
 {
     static_assert(NTP % 2 == 0 && R % 2 == 0 && (NDMA == 1 || NDMA == 2), "window is whole dwords; ring holds row pairs");
     static_assert(NC == 1 || NC == 2 || NC == 4, "one byte, short or dword store per lane and row");
+    static_assert(D >= 1 && R % D == 0, "D source rows in flight, one LDS slot each, rotating with the ring");
 #if defined(__HIP_DEVICE_COMPILE__)   // the LDS-DMA builtin exists in the device pass only
     constexpr int NDW = NTP / 2 + 1;                 // aligned dwords that hold a 2 * NTP-byte window at any byte phase
     constexpr int kSlotBytes = NDMA * 1024 + 16;
-    __shared__ __attribute__((aligned(16))) uint8_t lds[kBlock / 64][kSlotBytes];
+    __shared__ __attribute__((aligned(16))) uint8_t lds[kBlock / 64][D][kSlotBytes];
 
     uint32_t lb = xcd_remap(blockIdx.x, gridDim.x);
     const int ci = lb >= a.c[0].nblocks ? 1 : 0;
@@ -817,7 +818,7 @@ __global__ __launch_bounds__(kBlock) void column_lds_kernel(const uint8_t *__res
     uint32_t lpos[NC], psel[NC][2];
 #pragma unroll
     for (int j = 0; j < NC; ++j) {
-        const uint32_t pos = off[j] + row0_off + lbase + uint32_t(reinterpret_cast<uintptr_t>((lds_void_t *)&lds[wave][0]));
+        const uint32_t pos = off[j] + row0_off + lbase + uint32_t(reinterpret_cast<uintptr_t>((lds_void_t *)&lds[wave][0][0]));
         const uint32_t o = pos & 3u;
         lpos[j] = pos & ~3u;
         // taps 2tp, 2tp+1 (as 16-bit lanes) sit at bytes o + 2 (tp % 2), +1 of dwords tp / 2, tp / 2 + 1
@@ -841,10 +842,15 @@ __global__ __launch_bounds__(kBlock) void column_lds_kernel(const uint8_t *__res
     const u32x4_t drs = {uni(uint32_t(dbase)), uni(uint32_t(dbase >> 32) & 0xffffu), uni(dst_rec), 0x00020000u};
 
 #pragma unroll
-    for (int d = 0; d < NDMA; ++d)
-        __builtin_amdgcn_raw_ptr_buffer_load_lds(srs, (lds_void_t *)&lds[wave][d * 1024], 16, csrc[d], 0, 0, 0);
+    for (int r = 0; r < D; ++r)
+#pragma unroll
+        for (int d = 0; d < NDMA; ++d)
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(srs, (lds_void_t *)&lds[wave][r][d * 1024], 16, csrc[d],
+                                                     min(r, nrows - 1) * src_stride, 0, 0);
     int cnt_next = int(uni(emit[0]));
-    int prev_cnt = 0;                              // stores issued since the DMA of the row about to be read
+    int hist[D];                                   // stores issued in each of the last D iterations
+#pragma unroll
+    for (int r = 0; r < D; ++r) hist[r] = 0;
 
     for (int k0 = 0; k0 < nrows; k0 += R) {
 #pragma unroll
@@ -853,15 +859,19 @@ __global__ __launch_bounds__(kBlock) void column_lds_kernel(const uint8_t *__res
             if (k >= nrows) continue;                           // wave-uniform (no early exit: the loop must unroll fully)
             const int cnt = cnt_next;
             cnt_next = int(uni(emit[min(k + 1, nrows - 1)]));
-            wait_vm_plus<0>(prev_cnt);                          // row k's DMA has landed; younger stores may still fly
+            // row k's DMA is followed by the DMAs of D-1 younger rows and the stores of the last D iterations
+            int younger = 0;
+#pragma unroll
+            for (int r = 0; r < D; ++r) younger += hist[r];
+            wait_vm_plus<(D - 1) * NDMA>(younger);
             uint32_t w[NC][NDW];
 #pragma unroll
-            for (int j = 0; j < NC; ++j) lds_read_dwords<NDW>(w[j], lpos[j]);
-            // the slot is free again (its bytes sit in registers): request row k + 1 into it
+            for (int j = 0; j < NC; ++j) lds_read_dwords<NDW>(w[j], lpos[j] + uint32_t(s % D) * uint32_t(kSlotBytes));
+            // the slot is free again (its bytes sit in registers): request row k + D into it
 #pragma unroll
             for (int d = 0; d < NDMA; ++d)
-                __builtin_amdgcn_raw_ptr_buffer_load_lds(srs, (lds_void_t *)&lds[wave][d * 1024], 16, csrc[d],
-                                                         min(k + 1, nrows - 1) * src_stride, 0, 0);
+                __builtin_amdgcn_raw_ptr_buffer_load_lds(srs, (lds_void_t *)&lds[wave][s % D][d * 1024], 16, csrc[d],
+                                                         min(k + D, nrows - 1) * src_stride, 0, 0);
 #pragma unroll
             for (int j = 0; j < NC; ++j) {
                 int acc = 0;
@@ -893,7 +903,7 @@ __global__ __launch_bounds__(kBlock) void column_lds_kernel(const uint8_t *__res
                 }
                 ++y;
             }
-            prev_cnt = cnt;
+            hist[s % D] = cnt;
         }
     }
 #endif
