@@ -75,7 +75,9 @@ int tts_parse_vf(const char *vf, int iw, int ih, tts_geom *out);
  * Build the per-geometry state on the current HIP device (coefficient tables in HBM).
  * Replaces sws_getContext()/sws_init_context() inside the ffmpeg child that
  * scripts/processVideos.js:108 (`.save()`) and src/services/video.js:334 spawn.
- * The plan is immutable afterwards and may be shared between host threads.
+ * The plan is immutable afterwards and may be shared between host threads.  It belongs to the
+ * device it was made on: the run calls below return TTS_ERR_INVALID_INPUT (tts_last_error names
+ * both devices) when another device is current -- one plan per GPU in a process that drives several.
  */
 int tts_plan_create(const tts_geom *g, tts_plan **out);
 void tts_plan_destroy(tts_plan *p);

@@ -614,3 +614,18 @@ def test_strided_batch_api(tts, oracle, vf, iw, ih, ss, ds):
             assert (view[i, :, w:] == 7).all(), "wrote into the row padding"
     with pytest.raises(tts.TtsError):
         plan.run_batch_strided(torch.from_numpy(s_host).cuda(), (iw - 1, ss[1]), d_dev, ds, n)
+
+
+def test_plan_refuses_another_device(tts):
+    """A plan's tables live on the device it was made on; the run calls refuse any other current device
+    instead of reading across the fabric (needs two GPUs: skipped on a one-GPU box)."""
+    import torch
+    if torch.cuda.device_count() < 2:
+        pytest.skip("one GPU")
+    plan = tts.Plan.from_vf("scale=160:90", 320, 180)
+    with torch.cuda.device(1):
+        src = torch.zeros((1, plan.in_bytes), dtype=torch.uint8, device="cuda:1")
+        dst = torch.zeros((1, plan.out_bytes), dtype=torch.uint8, device="cuda:1")
+        with pytest.raises(tts.TtsError, match="INVALID_INPUT"):
+            plan.run_batch(src, dst)
+        torch.cuda.synchronize()

@@ -145,6 +145,19 @@ size_t tts_frame_bytes(int w, int h)
 
 namespace {
 
+// A plan's tables live in the HBM of the device that was current when it was made; run on another
+// device the kernels would read them across the fabric, or fault where peer access is off.
+int check_device(const tts_plan *p)
+{
+    int dev = -1;
+    if (hipGetDevice(&dev) != hipSuccess) { g_last_error = "hipGetDevice failed"; return TTS_ERR_PROCESSING_FAILED; }
+    if (dev != p->device) {
+        g_last_error = "plan was created on device " + std::to_string(p->device) + ", current device is " + std::to_string(dev);
+        return TTS_ERR_INVALID_INPUT;
+    }
+    return TTS_OK;
+}
+
 // Frames at a fixed pitch, Y / U / V back to back inside a frame, rows `sstride[class]` / `dstride[class]`
 // bytes apart (class 0 = luma, 1 = both chroma planes).
 int run_batch_impl(const tts_plan *p, const void *src, size_t src_pitch, const int sstride[2], void *dst, size_t dst_pitch,
@@ -160,6 +173,7 @@ int run_batch_impl(const tts_plan *p, const void *src, size_t src_pitch, const i
     const size_t dbytes = size_t(dstride[0]) * g.out_h + 2 * size_t(dstride[1]) * ceil_shift(g.out_h, 1);
     if (src_pitch < sbytes || dst_pitch < dbytes) return TTS_ERR_INVALID_INPUT;
     if (src_pitch >= (size_t(1) << 31) || dst_pitch >= (size_t(1) << 31)) return TTS_ERR_UNSUPPORTED;
+    if (const int rc = check_device(p)) return rc;
     hipStream_t st = static_cast<hipStream_t>(hip_stream);
 
     FrameAddr addr{};
@@ -232,6 +246,7 @@ int tts_run(const tts_plan *p, const tts_frame *src, const tts_frame *dst, int n
         }
         if (src[i].stride[1] != src[i].stride[2] || dst[i].stride[1] != dst[i].stride[2]) return TTS_ERR_UNSUPPORTED;
     }
+    if (const int drc = check_device(p)) return drc;
     hipStream_t st = static_cast<hipStream_t>(hip_stream);
     // Frames are grouped so that every plane of a group lies within kMaxSpan of a common base (32-bit
     // lane offsets).  `only` < 0: the three planes of a frame share the base (one launch set for the
@@ -293,6 +308,7 @@ int tts_run_host(const tts_plan *p, const void *src, void *dst, int n_frames)
     if (!p || n_frames < 0) return TTS_ERR_INVALID_INPUT;
     if (n_frames == 0) return TTS_OK;
     if (!src || !dst) return TTS_ERR_INVALID_INPUT;
+    if (const int drc = check_device(p)) return drc;
     const size_t sb = tts_frame_bytes(p->g.in_w, p->g.in_h), db = tts_frame_bytes(p->g.out_w, p->g.out_h);
     // The clip goes through in chunks over two slots (a source and a destination buffer in HBM each) on
     // two streams: chunk i + 1 is on its way up while chunk i is scaled and sent back, both directions of
