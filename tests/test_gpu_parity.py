@@ -495,7 +495,7 @@ def test_column_kernel_variants(tts, oracle, vf, iw, ih, n, kind):
     if kind is not None:
         assert plan.kernel_kind(0) == kind, "luma class runs kernel kind %d, expected %d" % (plan.kernel_kind(0), kind)
     if vf in ("scale=213:121", "scale=1280:720", "scale=720:1280"):
-        assert plan.kernel_name(0) == "column_lds<6,12,1,2>"      # 11-12 taps after trimming: 6 tap pairs, two columns per lane
+        assert plan.kernel_name(0) == "column_lds<6,12,1,2,4>"      # 11-12 taps after trimming: 6 tap pairs, two columns per lane
     for pat in ("random", "impulse"):
         src = synth.frames(pat, iw, ih, n)
         got = plan.run_batch(torch.from_numpy(src).cuda()).cpu().numpy()

@@ -126,7 +126,7 @@ const char *tts_plan_kernel_name(const tts_plan *p, int plane_class)
     if (!p || plane_class < 0 || plane_class > 1) return "";
     const ClassPlan &c = p->cls[plane_class];
     if (c.kind == 0) std::snprintf(buf, sizeof buf, "generic");
-    else if (c.kind == 2) std::snprintf(buf, sizeof buf, "column_lds<%d,%d,%d,%d>", c.NTP, c.Rc, c.col_dmas, c.col_nc);
+    else if (c.kind == 2) std::snprintf(buf, sizeof buf, "column_lds<%d,%d,%d,%d,%d>", c.NTP, c.Rc, c.col_dmas, c.col_nc, column_depth(c.NTP));
     else {
         const StripChoice ch = strip_choice(c, p->knobs);
         if (ch.lds) std::snprintf(buf, sizeof buf, "strip_lds<%d,%d,%s,%d,%d>", ch.LW, ch.R, ch.g12 == 2 ? "grouped2" : ch.g4 ? "grouped" : "percolumn", ch.lds, ch.depth);
