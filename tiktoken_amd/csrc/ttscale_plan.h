@@ -550,14 +550,14 @@ void choose_segs(const tts_plan *p, const int *cis, int ncls, int n, int N, stri
     out_idx[0] = out_idx[1] = best;
 }
 
-constexpr int column_depth(int ntp) { return ntp <= 20 ? 4 : 1; }    // source rows in flight per wave (see pick_column)
+constexpr int column_depth(int) { return 4; }    // source rows in flight per wave, every tap count (see pick_column)
 
 strip_fn pick_column(const ClassPlan &c)
 {
-    // Up to 20 tap pairs a wave has little arithmetic per source row (one or two columns per lane) against
-    // a memory latency of microseconds, so four rows are kept in flight (four LDS slots): the 1080p
-    // thumbnail chain 35 -> 41 % of peak, 4K -> 720p 46 -> 51 %; the 49-tap 4K chain is arithmetic-bound
-    // and gains nothing, so the larger windows keep one.
+    // A wave has one or two columns' arithmetic per source row against a memory latency of microseconds,
+    // so four rows are kept in flight (four LDS slots): the 1080p thumbnail chain 35 -> 39-41 % of peak,
+    // 4K -> 720p 46 -> 51 %, the 48-tap 4K thumbnail chain 48 -> 54 %.  Eight measured worse than four
+    // (1080p chain 34 %, 4K chain 51 %).
 #define TTS_COL_PICK(NTP_, NC_) (c.col_dmas == 1 ? column_lds_kernel<NTP_, 2 * NTP_, 1, NC_, column_depth(NTP_)> \
                                                   : column_lds_kernel<NTP_, 2 * NTP_, 2, NC_, column_depth(NTP_)>)
     if (c.Rc != 2 * c.NTP) return nullptr;
