@@ -468,7 +468,7 @@ def test_more_planes_than_grid_z(tts, oracle):
 # The column walk (9..64 taps per axis): (chain, iw, ih, frames, expected kernel kind of the luma class); 4 / 5 = one /
 # two LDS-DMAs per source row, 0 = generic kernel (more than 64 taps).
 COLUMN_CASES = [
-    (THUMB_REF, 1920, 1080, 9, 4),                         # src/services/video.js:329-332 on 1080p: 6x, 25 taps (14 tap pairs)
+    (THUMB_REF, 1920, 1080, 9, 4),                         # src/services/video.js:329-332 on 1080p: 6x, 25 taps (12 tap pairs after trimming)
     (THUMB_REF, 3840, 2160, 2, 4),                         # ... on 4K: 12x, 49 taps (26 tap pairs, ring of 52 rows)
     (THUMB_REF, 720, 1280, 70, 4),                         # ... on a portrait clip: 101 columns, waves wrap over planes
     (THUMB_REF + ",format=yuvj420p", 1080, 1080, 3, 4),    # ... square source, then the mjpeg range pass
@@ -496,6 +496,8 @@ def test_column_kernel_variants(tts, oracle, vf, iw, ih, n, kind):
         assert plan.kernel_kind(0) == kind, "luma class runs kernel kind %d, expected %d" % (plan.kernel_kind(0), kind)
     if vf in ("scale=213:121", "scale=1280:720", "scale=720:1280"):
         assert plan.kernel_name(0) == "column_lds<6,12,1,2,4>"      # 11-12 taps after trimming: 6 tap pairs, two columns per lane
+    if vf == THUMB_REF and (iw, ih) == (1920, 1080):
+        assert plan.kernel_name(0) == "column_lds<12,24,1,2,4>"     # 23 taps after trimming; two columns per lane up to 12 tap pairs
     for pat in ("random", "impulse"):
         src = synth.frames(pat, iw, ih, n)
         got = plan.run_batch(torch.from_numpy(src).cuda()).cpu().numpy()

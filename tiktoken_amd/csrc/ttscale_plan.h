@@ -222,10 +222,11 @@ int build_class(const tts_geom &g, int sub, ClassPlan &c, std::vector<uint32_t> 
             tab[hoff1 + i] = uint32_t(lo[i]);
             for (int k = 0; k < NTP; ++k) tab[hcoef1 + size_t(i) * NTP + k] = pack16(slot[2 * k], slot[2 * k + 1]);
         }
-        // columns per lane: two at 8 tap pairs (2160x3840 -> 720x1280: 25 -> 41 % of peak; four measured the
-        // same there and 5 % slower on 4K -> 720p, at 110 VGPRs), one above (two at 16 tap pairs made no
-        // difference to the 1080p thumbnail), if the 64-strip runs fit the LDS slot
-        int dmas = 0, nc = NTP <= 8 ? 2 : 1;
+        // columns per lane: two up to 12 tap pairs (2160x3840 -> 720x1280: 25 -> 41 % of peak; four measured the
+        // same there and 5 % slower on 4K -> 720p, at 110 VGPRs; at 12 tap pairs, with four rows in flight,
+        // two are worth 1 % on 300 frames of the 1080p thumbnail chain and 3.5 % on 1,200), one above, if the
+        // 64-strip runs fit the LDS slot
+        int dmas = 0, nc = NTP <= 12 ? 2 : 1;
         const int forced_nc = env_int("TTS_COL_NC", 0);
         if (forced_nc == 1 || forced_nc == 2) nc = std::min(nc, forced_nc);
         for (; nc >= 1 && !dmas; nc = dmas ? nc : nc / 2) {
@@ -561,7 +562,14 @@ strip_fn pick_column(const ClassPlan &c)
 #define TTS_COL_PICK(NTP_, NC_) (c.col_dmas == 1 ? column_lds_kernel<NTP_, 2 * NTP_, 1, NC_, column_depth(NTP_)> \
                                                   : column_lds_kernel<NTP_, 2 * NTP_, 2, NC_, column_depth(NTP_)>)
     if (c.Rc != 2 * c.NTP) return nullptr;
-    if (c.col_nc == 2) return c.NTP == 6 ? TTS_COL_PICK(6, 2) : c.NTP == 8 ? TTS_COL_PICK(8, 2) : nullptr;
+    if (c.col_nc == 2)
+        switch (c.NTP) {
+        case 6: return TTS_COL_PICK(6, 2);
+        case 8: return TTS_COL_PICK(8, 2);
+        case 10: return TTS_COL_PICK(10, 2);
+        case 12: return TTS_COL_PICK(12, 2);
+        default: return nullptr;
+        }
     switch (c.NTP) {
     case 6: return TTS_COL_PICK(6, 1);
     case 8: return TTS_COL_PICK(8, 1);
