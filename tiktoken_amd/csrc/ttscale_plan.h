@@ -82,6 +82,7 @@ struct Knobs {
     int planewise = 0;                // tts_run: always take the plane-by-plane path (test knob)
     int span_chunks = 0;              // tts_run_batch: always cut batches into launches whose whole span fits 32 bits (test knob)
     int wave_base = 0;                // tts_run_batch: per-wave descriptors even when the batch fits one base (test knob)
+    int col_fill = 0;                 // column walk: workgroups per resident slot (in tenths) a segment length must leave; 0 = by tap count
     void read()
     {
         strip_n = env_int("TTS_STRIP_N", 8); strip_d = env_int("TTS_STRIP_D", 0);
@@ -94,6 +95,7 @@ struct Knobs {
         planewise = env_int("TTS_PLANEWISE", 0);
         span_chunks = env_int("TTS_SPAN_CHUNKS", 0);
         wave_base = env_int("TTS_WAVE_BASE", 0);
+        col_fill = std::max(0, env_int("TTS_COL_FILL", 0));
     }
 };
 
@@ -611,11 +613,16 @@ void fill_column_class(const tts_plan *p, int ci, int n, int src_stride, int dst
 
 // Row-segment length of a column-walk launch: the longest segment on offer that leaves >= 1.5
 // workgroups per resident slot (every segment start re-reads taps - 1 source rows: 24 of 120 at
-// 16-row segments of the 1080p thumbnail), else the shortest; at least `min_segs` segments.
+// 16-row segments of the 1080p thumbnail) -- >= 3 up to 8 tap pairs, where a start costs little
+// (4K -> 720p 50.7 -> 54.7 % of peak at 300 frames, 2160x3840 -> 720x1280 48.1 -> 52.8 %) -- else the
+// shortest; at least `min_segs` segments, and two wherever there is a choice: whole-plane segments
+// measured 15-20 % slower than halves at any fill (4K -> 720p, 1,200 frames: 43.8 vs 55.3 %; the 4K
+// thumbnail chain, 900 frames: 46.9 vs 56.3 %; the 1080p one, 1,200 frames: 40.1 vs 50.1 %).
 size_t choose_column_segs(const tts_plan *p, const int *cis, int ncls, int n, int planes_each[2], strip_fn fn, int min_segs)
 {
     const size_t nopt = p->cls[cis[0]].segs.size();
     const double slots = double(p->n_cus) * blocks_per_cu(fn, kBlock, 0);
+    const double fill = p->knobs.col_fill ? 0.1 * p->knobs.col_fill : p->cls[cis[0]].NTP <= 8 ? 3.0 : 1.5;
     size_t best = 0;
     for (size_t i = 0; i < nopt; ++i) {
         double blocks = 0;
@@ -623,7 +630,7 @@ size_t choose_column_segs(const tts_plan *p, const int *cis, int ncls, int n, in
             const ClassPlan &c = p->cls[cis[k]];
             blocks += double((int64_t(n) * planes_each[k] * ((c.ow + c.col_nc - 1) / c.col_nc) + kBlock - 1) / kBlock) * c.segs[i].nseg;
         }
-        if (i == 0 || blocks >= 1.5 * slots) best = i;
+        if (i == 0 || (blocks >= fill * slots && p->cls[cis[0]].segs[i].nseg >= 2)) best = i;
     }
     for (bool ok = false; !ok && best > 0; ) {
         ok = true;
