@@ -164,7 +164,8 @@ int tts_plan_kernel_kind(const tts_plan *p, int plane_class);
 /* The same with the template arguments, for logs and tests: "strip_lds<6,6,grouped,1,1>" = window bytes,
  * ring rows, grouped (one window per 4 columns) / grouped2 (per 2) or percolumn windows, LDS-DMAs per row,
  * rows in flight; "column_lds<6,12,1,2,4>" = tap pairs, ring rows, LDS-DMAs per row, columns per lane,
- * rows in flight; "strip<...>" the register walk, "generic".
+ * rows in flight (above 8 tap pairs small launches take one column per lane; the name is the large-launch
+ * variant); "strip<...>" the register walk, "generic".
  * Valid until the calling thread's next call. */
 const char *tts_plan_kernel_name(const tts_plan *p, int plane_class);
 

@@ -357,12 +357,12 @@ def test_lds_kernel_variants(tts, oracle, vf, iw, ih, n, kind):
 
 @pytest.mark.parametrize("knob,val", [("TTS_PACED", "1"), ("TTS_PACED", "0"), ("TTS_LDS_BLOCK", "64"), ("TTS_LDS_BLOCK", "704"),
                                       ("TTS_STRIP_D", "2"), ("TTS_NO_LDS", "1"), ("TTS_NO_G4", "1"), ("TTS_NO_G6", "1"), ("TTS_NO_MERGE", "1"), ("TTS_COL_NC", "1"), ("TTS_WAVE_BASE", "1"), ("TTS_NO_DMA4", "1"),
-                                      ("TTS_COL_FILL", "1"), ("TTS_COL_FILL", "80")])
+                                      ("TTS_COL_FILL", "1"), ("TTS_COL_FILL", "80"), ("TTS_COL_NC_LAUNCH", "1"), ("TTS_COL_NC_LAUNCH", "2")])
 def test_tuning_knobs_do_not_change_pixels(tts, oracle, monkeypatch, knob, val):
     import torch
     monkeypatch.setenv(knob, val)
     for vf, iw, ih in (("scale=355:267", 200, 150), ("scale=120:90:flags=area", 200, 150), ("scale=136:96", 100, 60),
-                       ("scale=176:132", 200, 150), ("scale=67:49", 200, 150)):
+                       ("scale=176:132", 200, 150), ("scale=67:49", 200, 150), ("scale=40:30", 200, 150)):
         plan = tts.Plan.from_vf(vf, iw, ih)
         src = synth.frames("random", iw, ih, 21)
         got = plan.run_batch(torch.from_numpy(src).cuda()).cpu().numpy()

@@ -43,7 +43,8 @@ struct ClassPlan {
     int LWlds = 0;                     // window width of the LDS-staged kernel's per-column mode (6 when 5-6 taps)
     // kind 2: column walk (9..64 taps): one output column per lane
     int NTP = 0, Rc = 0, col_dmas = 0; // tap pairs per column, ring depth, LDS-DMAs per source row
-    int col_nc = 1;                    // output columns per lane (1, 2, 4)
+    int col_nc = 1;                    // output columns per lane (1, 2), the most a launch may take
+    int col_dmas1 = 0;                 // LDS-DMAs per source row at one column per lane (what small launches take above 8 tap pairs)
     uint32_t hoff1 = 0, hcoef1 = 0;    // window start per column, taps per column [ow][NTP]
     HTables ht[2];                     // horizontal tables for N = 8 and N = 16 columns per lane
     std::vector<SegTables> segs;
@@ -82,6 +83,7 @@ struct Knobs {
     int planewise = 0;                // tts_run: always take the plane-by-plane path (test knob)
     int span_chunks = 0;              // tts_run_batch: always cut batches into launches whose whole span fits 32 bits (test knob)
     int wave_base = 0;                // tts_run_batch: per-wave descriptors even when the batch fits one base (test knob)
+    int col_nc_launch = 0;            // column walk above 8 tap pairs: 1 / 2 columns per lane whatever the launch's size (0 = by size)
     int col_fill = 0;                 // column walk: workgroups per resident slot (in tenths) a segment length must leave; 0 = by tap count
     void read()
     {
@@ -96,6 +98,7 @@ struct Knobs {
         span_chunks = env_int("TTS_SPAN_CHUNKS", 0);
         wave_base = env_int("TTS_WAVE_BASE", 0);
         col_fill = std::max(0, env_int("TTS_COL_FILL", 0));
+        col_nc_launch = env_int("TTS_COL_NC_LAUNCH", 0);
     }
 };
 
@@ -225,9 +228,8 @@ int build_class(const tts_geom &g, int sub, ClassPlan &c, std::vector<uint32_t> 
             for (int k = 0; k < NTP; ++k) tab[hcoef1 + size_t(i) * NTP + k] = pack16(slot[2 * k], slot[2 * k + 1]);
         }
         // columns per lane: two up to 12 tap pairs (2160x3840 -> 720x1280: 25 -> 41 % of peak; four measured the
-        // same there and 5 % slower on 4K -> 720p, at 110 VGPRs; at 12 tap pairs, with four rows in flight,
-        // two are worth 1 % on 300 frames of the 1080p thumbnail chain and 3.5 % on 1,200), one above, if the
-        // 64-strip runs fit the LDS slot
+        // same there and 5 % slower on 4K -> 720p, at 110 VGPRs; at 10-12 tap pairs, with four rows in flight,
+        // two pay on large launches only and launch_all decides), one above, if the 64-strip runs fit the LDS slot
         int dmas = 0, nc = NTP <= 12 ? 2 : 1;
         const int forced_nc = env_int("TTS_COL_NC", 0);
         if (forced_nc == 1 || forced_nc == 2) nc = std::min(nc, forced_nc);
@@ -241,6 +243,8 @@ int build_class(const tts_geom &g, int sub, ClassPlan &c, std::vector<uint32_t> 
         }
         if (!dmas) return TTS_OK;
         c.kind = 2; c.NTP = NTP; c.Rc = Rc; c.col_dmas = dmas; c.col_nc = nc; c.hoff1 = hoff1; c.hcoef1 = hcoef1;
+        c.col_dmas1 = dmas;
+        if (nc == 2) { t.strips = c.ow; c.col_dmas1 = lds_dmas(c, t, 1, lo.data(), 1, 2 * NTP); }
         // Segment lengths on offer: the luma plane cut into 1..32 EQUAL parts (outputs here are small --
         // a ragged last segment would be most of the tail), the same list for both classes, ascending.
         std::vector<int> opts;
@@ -555,16 +559,18 @@ void choose_segs(const tts_plan *p, const int *cis, int ncls, int n, int N, stri
 
 constexpr int column_depth(int) { return 4; }    // source rows in flight per wave, every tap count (see pick_column)
 
-strip_fn pick_column(const ClassPlan &c)
+struct ColMode { int nc, dmas; };                  // columns per lane and LDS-DMAs per row of one launch (per class)
+
+strip_fn pick_column(const ClassPlan &c, const ColMode m)
 {
     // A wave has one or two columns' arithmetic per source row against a memory latency of microseconds,
     // so four rows are kept in flight (four LDS slots): the 1080p thumbnail chain 35 -> 39-41 % of peak,
     // 4K -> 720p 46 -> 51 %, the 48-tap 4K thumbnail chain 48 -> 54 %.  Eight measured worse than four
     // (1080p chain 34 %, 4K chain 51 %).
-#define TTS_COL_PICK(NTP_, NC_) (c.col_dmas == 1 ? column_lds_kernel<NTP_, 2 * NTP_, 1, NC_, column_depth(NTP_)> \
+#define TTS_COL_PICK(NTP_, NC_) (m.dmas == 1 ? column_lds_kernel<NTP_, 2 * NTP_, 1, NC_, column_depth(NTP_)> \
                                                   : column_lds_kernel<NTP_, 2 * NTP_, 2, NC_, column_depth(NTP_)>)
     if (c.Rc != 2 * c.NTP) return nullptr;
-    if (c.col_nc == 2)
+    if (m.nc == 2)
         switch (c.NTP) {
         case 6: return TTS_COL_PICK(6, 2);
         case 8: return TTS_COL_PICK(8, 2);
@@ -592,7 +598,7 @@ strip_fn pick_column(const ClassPlan &c)
 #undef TTS_COL_PICK
 }
 
-void fill_column_class(const tts_plan *p, int ci, int n, int src_stride, int dst_stride, const SegTables &st,
+void fill_column_class(const tts_plan *p, int ci, const ColMode m, int n, int src_stride, int dst_stride, const SegTables &st,
                        int planes, int plane0, StripClass &sc)
 {
     const ClassPlan &c = p->cls[ci];
@@ -600,7 +606,7 @@ void fill_column_class(const tts_plan *p, int ci, int n, int src_stride, int dst
     sc.hoff = c.hoff1; sc.hcoef = c.hcoef1;
     sc.seginfo = st.seginfo; sc.emit = st.emit; sc.vcoef = st.vcoef;
     sc.maxrows = st.maxrows; sc.nseg = st.nseg; sc.seg_rows = st.seg_rows;
-    sc.strips = (c.ow + c.col_nc - 1) / c.col_nc;      // col_nc columns per lane
+    sc.strips = (c.ow + m.nc - 1) / m.nc;              // nc columns per lane
     sc.planes = planes; sc.plane0 = plane0;
     sc.n_items = n * planes * sc.strips;
     sc.ow = c.ow; sc.oh = c.oh; sc.src_stride = src_stride; sc.dst_stride = dst_stride;
@@ -618,7 +624,7 @@ void fill_column_class(const tts_plan *p, int ci, int n, int src_stride, int dst
 // shortest; at least `min_segs` segments, and two wherever there is a choice: whole-plane segments
 // measured 15-20 % slower than halves at any fill (4K -> 720p, 1,200 frames: 43.8 vs 55.3 %; the 4K
 // thumbnail chain, 900 frames: 46.9 vs 56.3 %; the 1080p one, 1,200 frames: 40.1 vs 50.1 %).
-size_t choose_column_segs(const tts_plan *p, const int *cis, int ncls, int n, int planes_each[2], strip_fn fn, int min_segs)
+size_t choose_column_segs(const tts_plan *p, const int *cis, const ColMode *cm, int ncls, int n, int planes_each[2], strip_fn fn, int min_segs)
 {
     const size_t nopt = p->cls[cis[0]].segs.size();
     const double slots = double(p->n_cus) * blocks_per_cu(fn, kBlock, 0);
@@ -628,7 +634,7 @@ size_t choose_column_segs(const tts_plan *p, const int *cis, int ncls, int n, in
         double blocks = 0;
         for (int k = 0; k < ncls; ++k) {
             const ClassPlan &c = p->cls[cis[k]];
-            blocks += double((int64_t(n) * planes_each[k] * ((c.ow + c.col_nc - 1) / c.col_nc) + kBlock - 1) / kBlock) * c.segs[i].nseg;
+            blocks += double((int64_t(n) * planes_each[k] * ((c.ow + cm[cis[k]].nc - 1) / cm[cis[k]].nc) + kBlock - 1) / kBlock) * c.segs[i].nseg;
         }
         if (i == 0 || (blocks >= fill * slots && p->cls[cis[0]].segs[i].nseg >= 2)) best = i;
     }
@@ -744,23 +750,48 @@ int launch_all(const tts_plan *p, const uint8_t *src, uint8_t *dst, int n, const
             if (src_span < 4096u || (addr.use_table && (c.segs[0].nseg < 2 || c.segs[0].spans_plane || c.src_w < 48 || c.src_h < 32))) to_generic[ci] = true;
             else col_cls[nc++] = ci;
         }
-        const bool cmerged = nc == 2 && !p->knobs.no_merge && pick_column(p->cls[0]) == pick_column(p->cls[1]);
+        const int min_segs = addr.use_table ? 2 : 1;
+        ColMode cm[2] = {{p->cls[0].col_nc, p->cls[0].col_dmas}, {p->cls[1].col_nc, p->cls[1].col_dmas}};
+        auto cmerged_now = [&] { return nc == 2 && !p->knobs.no_merge && pick_column(p->cls[0], cm[0]) == pick_column(p->cls[1], cm[1]); };
+        // Above 8 tap pairs two columns per lane pay only on large launches (1080p thumbnail chain: +2 % at
+        // 300 frames, +8.5 % at 600, but -10 % at 120 and -5 % at 30): half as many workgroups want shorter
+        // row segments to fill the chip, and every segment start re-reads taps - 1 rows.  So such a launch
+        // takes two only where that still leaves segments of an eighth of the plane or longer.
+        int decided = -1;                                  // one answer for both classes, so that they stay one launch
         for (int k = 0; k < nc; ++k) {
             const int ci = col_cls[k];
-            strip_fn fn = pick_column(p->cls[ci]);
+            const ClassPlan &c = p->cls[ci];
+            if (c.col_nc != 2 || c.NTP <= 8 || !c.col_dmas1 || p->knobs.col_nc_launch == 2) continue;
+            bool two = decided > 0;
+            if (decided < 0 && p->knobs.col_nc_launch != 1) {
+                strip_fn fn2 = pick_column(c, cm[ci]);
+                if (fn2) {
+                    const bool m2 = cmerged_now();
+                    int planes_each[2] = {m2 ? nplanes(0) : nplanes(ci), m2 ? nplanes(1) : 0};
+                    const size_t si = m2 ? choose_column_segs(p, col_cls, cm, 2, n, planes_each, fn2, min_segs)
+                                         : choose_column_segs(p, &ci, cm, 1, n, planes_each, fn2, min_segs);
+                    two = c.segs[si].nseg <= 8;
+                }
+            }
+            decided = two;
+            if (!two) cm[ci] = {1, c.col_dmas1};
+        }
+        const bool cmerged = cmerged_now();
+        for (int k = 0; k < nc; ++k) {
+            const int ci = col_cls[k];
+            strip_fn fn = pick_column(p->cls[ci], cm[ci]);
             if (!fn) return TTS_ERR_UNSUPPORTED;
             StripArgs a{};
             a.src_span = src_span; a.dst_span = dst_span; a.addr = addr;
-            const int min_segs = addr.use_table ? 2 : 1;
             if (cmerged) {
                 int planes_each[2] = {nplanes(0), nplanes(1)};
-                const size_t si = choose_column_segs(p, col_cls, 2, n, planes_each, fn, min_segs);
+                const size_t si = choose_column_segs(p, col_cls, cm, 2, n, planes_each, fn, min_segs);
                 for (int j = 0; j < 2; ++j)
-                    fill_column_class(p, j, n, src_stride[j], dst_stride[j], p->cls[j].segs[si], nplanes(j), plane0(j), a.c[j]);
+                    fill_column_class(p, j, cm[j], n, src_stride[j], dst_stride[j], p->cls[j].segs[si], nplanes(j), plane0(j), a.c[j]);
             } else {
                 int planes_each[2] = {nplanes(ci), 0};
-                const size_t si = choose_column_segs(p, &ci, 1, n, planes_each, fn, min_segs);
-                fill_column_class(p, ci, n, src_stride[ci], dst_stride[ci], p->cls[ci].segs[si], nplanes(ci), plane0(ci), a.c[0]);
+                const size_t si = choose_column_segs(p, &ci, cm, 1, n, planes_each, fn, min_segs);
+                fill_column_class(p, ci, cm[ci], n, src_stride[ci], dst_stride[ci], p->cls[ci].segs[si], nplanes(ci), plane0(ci), a.c[0]);
                 a.c[1] = a.c[0]; a.c[1].nblocks = 0;
             }
             const uint32_t blocks = a.c[0].nblocks + (cmerged ? a.c[1].nblocks : 0);
