@@ -32,6 +32,17 @@ enum { TTS_MEM_DEVICE = 0, TTS_MEM_HOST = 1 };
  * ffmpeg auto-inserts between a yuv420p chain and an encoder wanting yuvj420p does -- the mjpeg
  * thumbnail of src/services/video.js:329-334 (`-q:v 2 out.jpg`).  SURVEY.md S7 / 8f-1. */
 enum { TTS_RANGE_KEEP = 0, TTS_RANGE_TO_FULL = 1, TTS_RANGE_TO_LIMITED = 2 };
+/* Pixel format of the frames a chain hands out: `format=rgb24 | bgr24 | rgba | bgra` ending it makes the
+ * chain's swscale pass write packed RGB (BT.601, limited-range source, swscale's table-driven C path:
+ * libswscale/yuv2rgb.c + output.c yuv2rgb_X_c_template; two neighbouring pixels share one chroma sample,
+ * as without full_chroma_int).  The stage right after the thumbnail filters of
+ * src/services/video.js:329-334 and the colour conversion BASELINE.json's north_star names.
+ * Frames of a packed format are ONE plane of out_w * bpp bytes a row (bpp 3 or 4; alpha = 255). */
+enum { TTS_FMT_YUV420P = 0, TTS_FMT_RGB24 = 1, TTS_FMT_BGR24 = 2, TTS_FMT_RGBA = 3, TTS_FMT_BGRA = 4 };
+/* Where the conversion sits, as libavfilter's format negotiation places it: inside the chain's `scale`
+ * (everything after it -- crop, pad -- then works on RGB pixels: no chroma-grid rounding, pad colour in
+ * RGB), or, in a chain without one, in a pass of its own at the very end (after pad, borders included). */
+enum { TTS_RGB_NONE = 0, TTS_RGB_AT_SCALE = 1, TTS_RGB_AT_END = 2 };
 
 /*
  * Resolved geometry of one filter chain, in luma pixels of a yuv420p frame:
@@ -48,9 +59,12 @@ typedef struct tts_geom {
     int32_t out_w, out_h;                     /* final frame size */
     int32_t fill_y, fill_u, fill_v;           /* pad colour */
     int32_t out_range;                        /* TTS_RANGE_*: `format=yuvj420p` / `format=yuv420p` ending the chain */
+    int32_t out_fmt;                          /* TTS_FMT_*: what the chain hands out (0 = yuv420p) */
+    int32_t rgb_stage;                        /* TTS_RGB_*: where the yuv -> RGB conversion sits (0 when out_fmt is yuv420p) */
+    int32_t fill_rgb;                         /* pad colour as 0xRRGGBB, used when the pad stage works on RGB pixels */
 } tts_geom;
 
-/* One yuv420p frame: Y, U, V plane pointers and byte strides. */
+/* One frame: Y, U, V plane pointers and byte strides (yuv420p), or plane[0] / stride[0] alone (packed RGB). */
 typedef struct tts_frame {
     void   *plane[3];
     int32_t stride[3];
@@ -67,7 +81,8 @@ typedef struct tts_plan tts_plan;
  *   src/services/video.js:329-332    "scale=320x180:force_original_aspect_ratio=decrease,
  *                                     pad=320x180:-1:-1:color=black,format=yuv420p"
  *   web/src/tests/video/portrait.test.js:78,95-96,146  "scale=W:H", "min(720,...", decrease
- * Accepted filters: scale (bicubic | area | bilinear), crop, pad, format=yuv420p | yuvj420p, setsar.
+ * Accepted filters: scale (bicubic | area | bilinear), crop, pad, setsar,
+ * format=yuv420p | yuvj420p | rgb24 | bgr24 | rgba | bgra.
  */
 int tts_parse_vf(const char *vf, int iw, int ih, tts_geom *out);
 
@@ -82,6 +97,10 @@ int tts_parse_vf(const char *vf, int iw, int ih, tts_geom *out);
 int tts_plan_create(const tts_geom *g, tts_plan **out);
 void tts_plan_destroy(tts_plan *p);
 int tts_plan_geom(const tts_plan *p, tts_geom *out);
+int tts_plan_device(const tts_plan *p);        /* index of the HIP device the plan belongs to (negative status if p is NULL) */
+/* Bytes of one packed frame going in (which = 0: I420 of in_w x in_h) or coming out (which = 1: I420 of
+ * out_w x out_h, or out_w * out_h * bpp for a packed-RGB chain): the frame pitches tts_run_batch expects. */
+size_t tts_plan_frame_bytes(const tts_plan *p, int which);
 
 /*
  * Run n_frames frames through the plan, asynchronously on hip_stream (a hipStream_t,
@@ -95,7 +114,8 @@ int tts_run(const tts_plan *p, const tts_frame *src, const tts_frame *dst, int n
 /*
  * Same, for a batch laid out as consecutive packed I420 frames (Y, U, V back to back,
  * strides == widths) at a fixed byte pitch between frames -- what a raw-video demuxer
- * (`-f rawvideo -pix_fmt yuv420p`) hands over.  Device pointers.
+ * (`-f rawvideo -pix_fmt yuv420p`) hands over.  Device pointers.  A packed-RGB chain writes
+ * consecutive frames of out_w * out_h * bpp bytes (`-f rawvideo -pix_fmt rgb24`).
  */
 int tts_run_batch(const tts_plan *p, const void *src, size_t src_frame_pitch,
                   void *dst, size_t dst_frame_pitch, int n_frames, void *hip_stream);
@@ -103,7 +123,8 @@ int tts_run_batch(const tts_plan *p, const void *src, size_t src_frame_pitch,
 /*
  * The same with padded rows, as decoders and encoders hand frames over (AVFrame.linesize[]): inside
  * a frame Y, U, V still follow each other, rows `*_stride_y` (luma) and `*_stride_c` (both chroma
- * planes) bytes apart, each at least the plane's width.  Padding bytes are never written.  (Packed
+ * planes) bytes apart, each at least the plane's width (packed RGB out: dst_stride_y = bytes between
+ * RGB rows, dst_stride_c ignored).  Padding bytes are never written.  (Packed
  * output rows are the fastest to write: 1080-column rows at a stride of 1088 measured 17 % slower
  * than at 1080 -- the 8-byte holes leave a partly written 64-byte sector at every row's end.)
  */

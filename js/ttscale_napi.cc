@@ -56,7 +56,8 @@ napi_value ParseVf(napi_env env, napi_callback_info info)
     napi_create_object(env, &obj);
     const char *names[] = {"in_w", "in_h", "pre_x", "pre_y", "pre_w", "pre_h", "do_scale", "alg", "sc_w", "sc_h",
                            "crop_x", "crop_y", "crop_w", "crop_h", "do_pad", "pad_x", "pad_y", "out_w", "out_h",
-                           "fill_y", "fill_u", "fill_v", "out_range"};
+                           "fill_y", "fill_u", "fill_v", "out_range", "out_fmt", "rgb_stage", "fill_rgb"};
+    static_assert(sizeof(tts_geom) == sizeof(names) / sizeof(names[0]) * sizeof(int32_t), "names[] lists every field of tts_geom, in order");
     const int32_t *vals = &g.in_w;
     for (size_t i = 0; i < sizeof(names) / sizeof(names[0]); ++i) {
         napi_value v;
@@ -107,11 +108,12 @@ napi_value RunHost(napi_env env, napi_callback_info info)
     tts_geom g;
     int rc = tts_parse_vf(vf.c_str(), iw, ih, &g);
     if (rc) return throw_status(env, "filter chain", rc);
-    const size_t sb = tts_frame_bytes(g.in_w, g.in_h), db = tts_frame_bytes(g.out_w, g.out_h);
+    const size_t sb = tts_frame_bytes(g.in_w, g.in_h);
     if (len == 0 || len % sb) return throw_status(env, "buffer is not a whole number of frames", TTS_ERR_INVALID_INPUT);
     const int n = int(len / sb);
     tts_plan *plan = cached_plan(vf, iw, ih, g, &rc);
     if (rc) return throw_status(env, "plan", rc);
+    const size_t db = tts_plan_frame_bytes(plan, 1);      // packed I420, or out_w * out_h * bpp behind format=rgb24 & co.
     napi_value out; void *dst = nullptr;
     if (napi_create_buffer(env, db * n, &dst, &out) != napi_ok) return throw_status(env, "allocation", TTS_ERR_PROCESSING_FAILED);
     rc = tts_run_host(plan, src, dst, n);

@@ -23,7 +23,7 @@ class Chain(ctypes.Structure):
     _fields_ = [(n, ctypes.c_int) for n in (
         "in_w", "in_h", "pre_x", "pre_y", "pre_w", "pre_h", "do_scale", "alg", "sc_w", "sc_h",
         "crop_x", "crop_y", "crop_w", "crop_h", "do_pad", "pad_x", "pad_y", "out_w", "out_h",
-        "fill_y", "fill_u", "fill_v", "out_range")]
+        "fill_y", "fill_u", "fill_v", "out_range", "out_fmt", "rgb_stage", "fill_rgb")]
 
 
 _lib = None
@@ -48,6 +48,9 @@ def lib():
         L.tto_crop_offset.argtypes = [ctypes.c_int, ctypes.c_int, ctypes.c_double, ctypes.c_int]
         L.tto_run_chain.argtypes = [ctypes.POINTER(Chain)] + [ctypes.c_void_p] * 3 + [ctypes.c_int] * 3 + \
                                    [ctypes.c_void_p] * 3 + [ctypes.c_int] * 3
+        L.tto_run_chain_rgb.argtypes = [ctypes.POINTER(Chain)] + [ctypes.c_void_p] * 3 + [ctypes.c_int] * 3 + \
+                                       [ctypes.c_void_p, ctypes.c_int]
+        L.tto_sws_yuv420_to_rgb.argtypes = [ctypes.c_void_p] * 3 + [ctypes.c_int] * 5 + [ctypes.c_void_p] + [ctypes.c_int] * 5
         _lib = L
     return _lib
 
@@ -91,13 +94,33 @@ def frame_bytes(w, h):
     return w * h + 2 * ((w + 1) // 2) * ((h + 1) // 2)
 
 
+class Unsupported(Exception):
+    """swscale takes a path here that the oracle does not restate (see tto_sws_yuv420_to_rgb)."""
+
+
+def out_frame_bytes(c):
+    """Bytes of one output frame of a chain: packed I420, or out_w * out_h * bpp for packed RGB."""
+    if c.out_fmt:
+        return c.out_w * c.out_h * (4 if c.out_fmt >= 3 else 3)
+    return frame_bytes(c.out_w, c.out_h)
+
+
 def run_chain(geom, frames):
-    """frames: uint8 [n, frame_bytes(in)] packed I420 -> [n, frame_bytes(out)]."""
+    """frames: uint8 [n, frame_bytes(in)] packed I420 -> [n, out_frame_bytes] (packed I420 or packed RGB)."""
     c = chain_from(geom)
     frames = np.ascontiguousarray(frames, np.uint8).reshape(-1, frame_bytes(c.in_w, c.in_h))
-    out = np.empty((frames.shape[0], frame_bytes(c.out_w, c.out_h)), np.uint8)
+    out = np.empty((frames.shape[0], out_frame_bytes(c)), np.uint8)
     iw, ih, ow, oh = c.in_w, c.in_h, c.out_w, c.out_h
     icw, ich, ocw, och = (iw + 1) // 2, (ih + 1) // 2, (ow + 1) // 2, (oh + 1) // 2
+    if c.out_fmt:
+        bpp = 4 if c.out_fmt >= 3 else 3
+        for i in range(frames.shape[0]):
+            s, d = frames[i].ctypes.data, out[i].ctypes.data
+            rc = lib().tto_run_chain_rgb(ctypes.byref(c), s, s + iw * ih, s + iw * ih + icw * ich, iw, icw, icw, d, ow * bpp)
+            if rc == -2:
+                raise Unsupported("swscale path not restated for this geometry")
+            assert rc == 0, rc
+        return out
     for i in range(frames.shape[0]):
         s, d = frames[i].ctypes.data, out[i].ctypes.data
         rc = lib().tto_run_chain(ctypes.byref(c), s, s + iw * ih, s + iw * ih + icw * ich, iw, icw, icw,

@@ -15,6 +15,8 @@
  *   libswscale/utils.c   initFilter(), sws_init_context()   (SURVEY.md S1-S3,S6)
  *   libswscale/swscale.c hScale8To15_c()                    
  *   libswscale/output.c  yuv2planeX_8_c(), yuv2plane1_8_c()
+ *   libswscale/yuv2rgb.c ff_yuv2rgb_c_init_tables(), yuv2rgb_c_24_rgb & co.;
+ *   libswscale/output.c  yuv2rgb_X_c_template(), yuv2rgb_write()   (packed RGB out)
  * and libavfilter's vf_scale / vf_crop / vf_pad geometry.
  *
  * PARITY UNPINNED: no golden vector, known-answer test or runnable FFmpeg
@@ -272,9 +274,11 @@ int tto_scale_dims(int iw, int ih, int w, int h, int foar, int fdb, int *ow, int
     if (w < 0) w = (int)(tto_rescale(h, iw, (int64_t)ih * factor_w) * factor_w);
     if (h < 0) h = (int)(tto_rescale(w, ih, (int64_t)iw * factor_h) * factor_h);
     if (foar) {
-        int tmp_w = (int)tto_rescale(h, iw, ih);
-        int tmp_h = (int)tto_rescale(w, ih, iw);
+        int tmp_w, tmp_h;
         if (fdb < 1) fdb = 1;
+        /* "Including force_divisible_by here rounds to the nearest multiple of it." */
+        tmp_w = (int)tto_rescale(h, iw, (int64_t)ih * fdb) * fdb;
+        tmp_h = (int)tto_rescale(w, ih, (int64_t)iw * fdb) * fdb;
         if (foar == 1) {
             w = tmp_w < w ? tmp_w : w;
             h = tmp_h < h ? tmp_h : h;
@@ -375,4 +379,211 @@ int tto_run_chain(const tto_chain *c,
         }
     }
     return 0;
+}
+
+/* ------------------------------------------------------------------------------------------------
+ * Packed RGB output.  RECALLED, UNVERIFIED like the rest of this file -- and the least
+ * certain part of it: the constants of ff_yuv2rgb_c_init_tables() below (yoffs 326 / 384, the 384 << 16
+ * table origin) are as remembered from FFmpeg 4.x-6.x and imply limited-range luma 1.8 levels darker than
+ * the textbook BT.601 matrix (tests/test_oracle_vs_float.py states the bound).  A diff against a real
+ * `ffmpeg -pix_fmt rgb24` (tests/test_vs_ffmpeg.py) is what settles it.
+ * ------------------------------------------------------------------------------------------------ */
+#define TTO_RGB_HEADROOM      512   /* YUVRGB_TABLE_HEADROOM */
+#define TTO_RGB_LUMA_HEADROOM 512   /* YUVRGB_TABLE_LUMA_HEADROOM */
+#define TTO_RGB_PLANE (1024 + 2 * TTO_RGB_LUMA_HEADROOM)
+#define TTO_RGB_CHROMA (256 + 2 * TTO_RGB_HEADROOM)
+
+typedef struct tto_yuv2rgb {
+    uint8_t ytab[TTO_RGB_PLANE];            /* c->yuvTable, 24 bpp case: one clipped ramp */
+    int rV[TTO_RGB_CHROMA], gU[TTO_RGB_CHROMA], bU[TTO_RGB_CHROMA];   /* c->table_rV ...: swscale keeps POINTERS into yuvTable, here offsets */
+    int gV[TTO_RGB_CHROMA];                 /* c->table_gV: an int offset in swscale as well */
+} tto_yuv2rgb;
+
+/* yuv2rgb.c fill_table(): table[i] = y_table - (inc >> 9) + ((clip_u8(i - HEADROOM) * inc) >> 16) */
+static void tto_fill_table(int *table, int64_t inc, int y_off)
+{
+    y_off -= (int)(inc >> 9);
+    for (int i = 0; i < TTO_RGB_CHROMA; i++) {
+        int64_t cb = (int64_t)tto_clip_u8(i - TTO_RGB_HEADROOM) * inc;
+        table[i] = y_off + (int)(cb >> 16);
+    }
+}
+/* yuv2rgb.c fill_gv_table() */
+static void tto_fill_gv_table(int *table, int64_t inc)
+{
+    const int off = -(int)(inc >> 9);
+    for (int i = 0; i < TTO_RGB_CHROMA; i++) {
+        int64_t cb = (int64_t)tto_clip_u8(i - TTO_RGB_HEADROOM) * inc;
+        table[i] = off + (int)(cb >> 16);
+    }
+}
+
+/* yuv2rgb.c ff_yuv2rgb_c_init_tables(c, ff_yuv2rgb_coeffs[SWS_CS_DEFAULT = ITU601], fullRange = 0,
+ * brightness 0, contrast = saturation = 1 << 16), bpp 24 (the 32 bpp tables hold the same bytes shifted) */
+static void tto_yuv2rgb_init(tto_yuv2rgb *t)
+{
+    const int yoffs = 326 + TTO_RGB_LUMA_HEADROOM;            /* fullRange ? 384 : 326 */
+    int64_t crv = 104597, cbu = 132201, cgu = -25675, cgv = -53279;   /* ITU-R BT.601 */
+    int64_t cy = 1 << 16, oy = 0, yb;
+    cy = (cy * 255) / 219;                                     /* !fullRange */
+    oy = 16 << 16;
+    /* contrast, saturation = 1.0 and brightness = 0 leave cy, c?? and oy as they are */
+    crv = ((crv * (1 << 16)) + 0x8000) / cy;                   /* "scale coefficients by cy" */
+    cbu = ((cbu * (1 << 16)) + 0x8000) / cy;
+    cgu = ((cgu * (1 << 16)) + 0x8000) / cy;
+    cgv = ((cgv * (1 << 16)) + 0x8000) / cy;
+    yb = -(384 << 16) - TTO_RGB_LUMA_HEADROOM * cy - oy;
+    for (int i = 0; i < TTO_RGB_PLANE; i++) {
+        t->ytab[i] = tto_clip_u8((int)((yb + 0x8000) >> 16));
+        yb += cy;
+    }
+    tto_fill_table(t->rV, crv, yoffs);
+    tto_fill_table(t->gU, cgu, yoffs);
+    tto_fill_table(t->bU, cbu, yoffs);
+    tto_fill_gv_table(t->gV, cgv);
+}
+
+/* output.c yuv2rgb_write() for RGB24 / BGR24 / RGBA / BGRA: r[Y], g[Y], b[Y] with r = table_rV[V], ... */
+static int tto_rgb_put(const tto_yuv2rgb *t, uint8_t *d, int fmt, int Y, int U, int V)
+{
+    const int r = t->rV[V + TTO_RGB_HEADROOM] + Y;
+    const int g = t->gU[U + TTO_RGB_HEADROOM] + t->gV[V + TTO_RGB_HEADROOM] + Y;
+    const int b = t->bU[U + TTO_RGB_HEADROOM] + Y;
+    if (r < 0 || g < 0 || b < 0 || r >= TTO_RGB_PLANE || g >= TTO_RGB_PLANE || b >= TTO_RGB_PLANE) return -1;  /* swscale would read outside yuvTable */
+    const int swap = fmt == TTO_FMT_BGR24 || fmt == TTO_FMT_BGRA;
+    d[0] = t->ytab[swap ? b : r];
+    d[1] = t->ytab[g];
+    d[2] = t->ytab[swap ? r : b];
+    if (fmt == TTO_FMT_RGBA || fmt == TTO_FMT_BGRA) d[3] = 255;
+    return 0;
+}
+
+static void tto_hscale_plane(const uint8_t *src, int sstride, int sh, const tto_filter *hf, int16_t *tmp)
+{
+    for (int y = 0; y < sh; y++) {
+        const uint8_t *s = src + (size_t)y * sstride;
+        int16_t *t = tmp + (size_t)y * hf->dst;
+        for (int x = 0; x < hf->dst; x++) {
+            int val = 0, p = hf->pos[x];
+            for (int j = 0; j < hf->size; j++) val += (int)s[p + j] * hf->coef[hf->size * x + j];
+            val >>= 7;
+            t[x] = (int16_t)(val < (1 << 15) - 1 ? val : (1 << 15) - 1);
+        }
+    }
+}
+
+int tto_sws_yuv420_to_rgb(const uint8_t *sy, const uint8_t *su, const uint8_t *sv, int sys, int sus, int svs,
+                          int sw, int sh, uint8_t *dst, int dstride, int dw, int dh, int alg, int fmt)
+{
+    const int bpp = (fmt == TTO_FMT_RGBA || fmt == TTO_FMT_BGRA) ? 4 : 3;
+    tto_yuv2rgb *t;
+    int rc = 0;
+    if (fmt < TTO_FMT_RGB24 || fmt > TTO_FMT_BGRA || sw < 1 || sh < 1 || dw < 1 || dh < 1) return -1;
+    t = (tto_yuv2rgb *)malloc(sizeof(*t));
+    tto_yuv2rgb_init(t);
+
+    if (sw == dw && sh == dh && !(dh & 1)) {
+        /* swscale_unscaled.c ff_get_unscaled_swscale(): yuv420p -> RGB, no accurate_rnd, even height ->
+         * ff_yuv2rgb_get_func_ptr(): yuv2rgb_c_24_rgb & co.  Two luma rows share chroma row y >> 1, two
+         * pixels chroma column x >> 1; the 8-bit samples index the tables directly.  (Its 8 / 4 / 2-pixel
+         * loops never write the last column of an odd width: not restated.) */
+        if (dw & 1) { free(t); return -2; }
+        for (int y = 0; y < dh && !rc; y++)
+            for (int x = 0; x < dw && !rc; x++)
+                rc = tto_rgb_put(t, dst + (size_t)y * dstride + (size_t)x * bpp, fmt, sy[(size_t)y * sys + x],
+                                 su[(size_t)(y >> 1) * sus + (x >> 1)], sv[(size_t)(y >> 1) * svs + (x >> 1)]);
+        free(t);
+        return rc;
+    }
+
+    /* sws_init_context(): RGB out without full_chroma_int -> chrDstHSubSample = 1, chrDstVSubSample = 0:
+     * chroma is scaled to ceil(dw / 2) columns and to dh rows (every position 128: centre-aligned) */
+    {
+        const int csw = (sw + 1) >> 1, csh = (sh + 1) >> 1, cdw = (dw + 1) >> 1;
+        tto_filter lh, lv, ch, cv;
+        int16_t *ty, *tu, *tv;
+        if (tto_filter_init(&lh, sw, dw, 1 << 14, alg) || tto_filter_init(&lv, sh, dh, 1 << 12, alg) ||
+            tto_filter_init(&ch, csw, cdw, 1 << 14, alg) || tto_filter_init(&cv, csh, dh, 1 << 12, alg)) { free(t); return -1; }
+        /* vscale.c packed_vscale(): yuv2packed1 when the luma filter has 1 tap and chroma 1-2, yuv2packed2
+         * when both have 2; everything else yuv2packedX, which is what follows */
+        if (lv.size <= 2 && cv.size <= 2) rc = -2;
+        ty = (int16_t *)malloc((size_t)dw * sh * sizeof(int16_t));
+        tu = (int16_t *)malloc((size_t)cdw * csh * sizeof(int16_t));
+        tv = (int16_t *)malloc((size_t)cdw * csh * sizeof(int16_t));
+        if (!rc) {
+            tto_hscale_plane(sy, sys, sh, &lh, ty);
+            tto_hscale_plane(su, sus, csh, &ch, tu);
+            tto_hscale_plane(sv, svs, csh, &ch, tv);
+        }
+        for (int y = 0; y < dh && !rc; y++) {
+            /* output.c yuv2rgb_X_c_template() */
+            const int16_t *lf = lv.coef + (size_t)lv.size * y, *cf = cv.coef + (size_t)cv.size * y;
+            const int lp = lv.pos[y], cp = cv.pos[y];
+            for (int i = 0; i < ((dw + 1) >> 1) && !rc; i++) {
+                int Y1 = 1 << 18, Y2 = 1 << 18, U = 1 << 18, V = 1 << 18;
+                const int has2 = i * 2 + 1 < dw;             /* (swscale computes and writes it into the row's padding) */
+                for (int j = 0; j < lv.size; j++) {
+                    Y1 += ty[(size_t)(lp + j) * dw + i * 2] * lf[j];
+                    if (has2) Y2 += ty[(size_t)(lp + j) * dw + i * 2 + 1] * lf[j];
+                }
+                for (int j = 0; j < cv.size; j++) {
+                    U += tu[(size_t)(cp + j) * cdw + i] * cf[j];
+                    V += tv[(size_t)(cp + j) * cdw + i] * cf[j];
+                }
+                Y1 >>= 19; Y2 >>= 19; U >>= 19; V >>= 19;
+                if (U < -TTO_RGB_HEADROOM || U >= 256 + TTO_RGB_HEADROOM || V < -TTO_RGB_HEADROOM || V >= 256 + TTO_RGB_HEADROOM) { rc = -1; break; }
+                rc = tto_rgb_put(t, dst + (size_t)y * dstride + (size_t)(i * 2) * bpp, fmt, Y1, U, V);
+                if (has2 && !rc) rc = tto_rgb_put(t, dst + (size_t)y * dstride + (size_t)(i * 2 + 1) * bpp, fmt, Y2, U, V);
+            }
+        }
+        free(ty); free(tu); free(tv);
+        tto_filter_free(&lh); tto_filter_free(&lv); tto_filter_free(&ch); tto_filter_free(&cv);
+    }
+    free(t);
+    return rc;
+}
+
+int tto_run_chain_rgb(const tto_chain *c, const uint8_t *sy, const uint8_t *su, const uint8_t *sv,
+                      int sys, int sus, int svs, uint8_t *dst, int dstride)
+{
+    const int bpp = (c->out_fmt == TTO_FMT_RGBA || c->out_fmt == TTO_FMT_BGRA) ? 4 : 3;
+    int rc;
+    if (c->rgb_stage == 2) {
+        /* no scale in the chain: crop / pad run on yuv420p (tto_run_chain), then libavfilter inserts a
+         * conversion-only swscale pass in front of `format`, borders included */
+        tto_chain y = *c;
+        const int ow = c->out_w, oh = c->out_h, cw = (ow + 1) >> 1, chh = (oh + 1) >> 1;
+        uint8_t *buf = (uint8_t *)malloc((size_t)ow * oh + 2 * (size_t)cw * chh);
+        uint8_t *py = buf, *pu = buf + (size_t)ow * oh, *pv = pu + (size_t)cw * chh;
+        y.out_fmt = 0; y.rgb_stage = 0; y.out_range = 0;
+        rc = tto_run_chain(&y, sy, su, sv, sys, sus, svs, py, pu, pv, ow, cw, cw);
+        if (!rc) rc = tto_sws_yuv420_to_rgb(py, pu, pv, ow, cw, cw, ow, oh, dst, dstride, ow, oh, c->alg, c->out_fmt);
+        free(buf);
+        return rc;
+    }
+    if (c->rgb_stage != 1) return -1;
+    {
+        /* the chain's scale writes RGB (sc_w x sc_h, from the pre-cropped source); vf_crop and vf_pad then
+         * work on RGB pixels: offsets and sizes are not rounded to a chroma grid */
+        const uint8_t *py = sy + (size_t)c->pre_y * sys + c->pre_x;
+        const uint8_t *pu = su + (size_t)(c->pre_y >> 1) * sus + (c->pre_x >> 1);
+        const uint8_t *pv = sv + (size_t)(c->pre_y >> 1) * svs + (c->pre_x >> 1);
+        const size_t sstride = (size_t)c->sc_w * bpp;
+        uint8_t *scaled = (uint8_t *)malloc(sstride * c->sc_h);
+        rc = tto_sws_yuv420_to_rgb(py, pu, pv, sys, sus, svs, c->pre_w, c->pre_h, scaled, (int)sstride, c->sc_w, c->sc_h, c->alg, c->out_fmt);
+        if (!rc) {
+            const uint8_t *q = scaled + (size_t)c->crop_y * sstride + (size_t)c->crop_x * bpp;
+            if (c->do_pad) {
+                const int swap = c->out_fmt == TTO_FMT_BGR24 || c->out_fmt == TTO_FMT_BGRA;
+                uint8_t px[4] = { (uint8_t)(c->fill_rgb >> 16), (uint8_t)(c->fill_rgb >> 8), (uint8_t)c->fill_rgb, 255 };
+                if (swap) { uint8_t t0 = px[0]; px[0] = px[2]; px[2] = t0; }
+                for (int y = 0; y < c->out_h; y++)
+                    for (int x = 0; x < c->out_w; x++) memcpy(dst + (size_t)y * dstride + (size_t)x * bpp, px, (size_t)bpp);
+                dst += (size_t)c->pad_y * dstride + (size_t)c->pad_x * bpp;
+            }
+            for (int y = 0; y < c->crop_h; y++) memcpy(dst + (size_t)y * dstride, q + (size_t)y * sstride, (size_t)c->crop_w * bpp);
+        }
+        free(scaled);
+    }
+    return rc;
 }

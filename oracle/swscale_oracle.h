@@ -45,7 +45,12 @@ typedef struct tto_chain {
     int do_pad, pad_x, pad_y, out_w, out_h; /* pad canvas */
     int fill_y, fill_u, fill_v;
     int out_range;                    /* 0 keep, 1 limited->full, 2 full->limited: a second, unscaled swscale pass */
+    int out_fmt;                      /* TTO_FMT_*: packed RGB written by the chain's swscale pass */
+    int rgb_stage;                    /* 0 none, 1 inside the chain's scale (crop / pad then work on RGB), 2 a pass of its own at the end */
+    int fill_rgb;                     /* pad colour 0xRRGGBB for pads that work on RGB */
 } tto_chain;
+
+enum { TTO_FMT_YUV420P = 0, TTO_FMT_RGB24 = 1, TTO_FMT_BGR24 = 2, TTO_FMT_RGBA = 3, TTO_FMT_BGRA = 4 };
 
 /* vf_scale output-size rule; foar: 0 disable, 1 decrease, 2 increase */
 int tto_scale_dims(int iw, int ih, int w, int h, int foar, int fdb, int *ow, int *oh);
@@ -58,6 +63,18 @@ int tto_run_chain(const tto_chain *c,
                   int sys, int sus, int svs,
                   uint8_t *dy, uint8_t *du, uint8_t *dv,
                   int dys, int dus, int dvs);
+
+/* One swscale context yuv420p (sw x sh) -> packed RGB (dw x dh), C path, default flags (no
+ * full_chroma_int, no accurate_rnd): libswscale/yuv2rgb.c tables + output.c yuv2rgb_X_c_template, or the
+ * unscaled converter yuv2rgb_c_24_rgb & co. when the sizes match and dh is even.
+ * Returns 0, -1 on bad arguments, -2 where swscale takes a path that is not restated here (the 1- / 2-tap
+ * packed writers yuv2rgb_1 / yuv2rgb_2; the unscaled converter on an odd width). */
+int tto_sws_yuv420_to_rgb(const uint8_t *sy, const uint8_t *su, const uint8_t *sv, int sys, int sus, int svs,
+                          int sw, int sh, uint8_t *dst, int dstride, int dw, int dh, int alg, int fmt);
+
+/* a chain that ends in packed RGB (c->out_fmt != 0): dst holds out_h rows of out_w * bpp bytes */
+int tto_run_chain_rgb(const tto_chain *c, const uint8_t *sy, const uint8_t *su, const uint8_t *sv,
+                      int sys, int sus, int svs, uint8_t *dst, int dstride);
 
 #ifdef __cplusplus
 }

@@ -57,6 +57,24 @@ PARSE_CASES = [
     ("scale=320x180:force_original_aspect_ratio=decrease,pad=320x180:-1:-1:color=black,format=yuv420p,format=yuvj420p", 720, 1280,
      dict(sc_w=101, sc_h=180, do_pad=1, pad_x=108, out_range=1)),
     ("format=pix_fmts=yuvj420p", 64, 48, dict(do_scale=0, out_range=1)),
+    # ff_scale_adjust_dimensions: the aspect-derived size is rounded to the NEAREST multiple of force_divisible_by
+    # first (101.25 -> 102), then min'ed and rounded down
+    ("scale=320:180:force_original_aspect_ratio=decrease:force_divisible_by=2", 720, 1280, dict(sc_w=102, sc_h=180)),
+    ("scale=320:180:force_original_aspect_ratio=decrease:force_divisible_by=4", 720, 1280, dict(sc_w=100, sc_h=180)),
+    ("scale=1080:1920:force_original_aspect_ratio=increase:force_divisible_by=2", 1920, 1080, dict(sc_w=3414, sc_h=1920)),
+    # packed RGB ending the chain: the chain's scale writes it, and crop / pad behind it work on
+    # RGB pixels -- no chroma grid: the 101-wide picture sits at x = 109, not 108
+    ("scale=320x180:force_original_aspect_ratio=decrease,pad=320x180:-1:-1:color=black,format=rgb24", 720, 1280,
+     dict(sc_w=101, sc_h=180, do_pad=1, pad_x=109, pad_y=0, out_w=320, out_h=180, out_fmt=1, rgb_stage=1, fill_rgb=0)),
+    ("scale=1080:1920:force_original_aspect_ratio=increase,crop=1080:1920,format=rgb24", 1920, 1080,
+     dict(sc_w=3413, crop_x=1166, out_fmt=1, rgb_stage=1)),
+    ("scale=1080:1920:force_original_aspect_ratio=increase,crop=1081:1919,format=bgra", 1920, 1080,   # odd sizes survive on RGB
+     dict(crop_x=1166, crop_y=0, crop_w=1081, crop_h=1919, out_fmt=4, rgb_stage=1)),
+    # a format=yuv420p between the scale and the RGB format pins that link: the conversion is a pass of its own at the end
+    ("scale=320x180:force_original_aspect_ratio=decrease,pad=320x180:-1:-1:color=black,format=yuv420p,format=rgb24", 720, 1280,
+     dict(pad_x=108, out_fmt=1, rgb_stage=2)),
+    ("format=rgb24", 64, 48, dict(do_scale=0, out_fmt=1, rgb_stage=2)),
+    ("crop=32:20,pad=64:48:-1:-1:color=white,format=pix_fmts=bgr24", 64, 48, dict(pre_w=32, pad_x=16, pad_y=14, out_fmt=2, rgb_stage=2, fill_rgb=0xffffff)),
 ]
 
 
@@ -69,7 +87,8 @@ def test_parse_vf(tts, vf, iw, ih, want):
 
 @pytest.mark.parametrize("vf,name", [
     ("hflip", "INVALID_FORMAT"), ("scale=abc:def", "INVALID_FORMAT"), ("scale=10:10:flags=lanczos", "UNSUPPORTED"),
-    ("format=rgb24", "UNSUPPORTED"), ("crop=4000:10", "INVALID_INPUT"), ("pad=10:10", "INVALID_INPUT"),
+    ("format=gray", "UNSUPPORTED"), ("format=rgb24,crop=10:10", "UNSUPPORTED"), ("format=yuvj420p,format=rgb24", "UNSUPPORTED"),
+    ("crop=4000:10", "INVALID_INPUT"), ("pad=10:10", "INVALID_INPUT"),
     ("scale=64:64,scale=32:32", "UNSUPPORTED"), ("scale=100:100:unknown=1", "INVALID_FORMAT"),
 ])
 def test_parse_errors_carry_the_web_spec_names(tts, vf, name):
@@ -86,6 +105,9 @@ def test_parser_agrees_with_oracle_geometry(tts, oracle):
         word = {1: "decrease", 2: "increase"}[foar]
         g = tts.parse_vf("scale=%d:%d:force_original_aspect_ratio=%s" % (w, h, word), iw, ih)
         assert (g.sc_w, g.sc_h) == oracle.scale_dims(iw, ih, w, h, foar)
+        for fdb in (2, 3, 4, 16):
+            g = tts.parse_vf("scale=%d:%d:force_original_aspect_ratio=%s:force_divisible_by=%d" % (w, h, word, fdb), iw, ih)
+            assert (g.sc_w, g.sc_h) == oracle.scale_dims(iw, ih, w, h, foar, fdb)
     for inn, out in [(3413, 1080), (1920, 1080), (101, 100), (3413, 1082)]:
         g = tts.parse_vf("crop=%d:2" % out, inn, 4)          # a crop with no scale before it is a source crop
         assert g.pre_x == oracle.crop_offset(inn, out)

@@ -12,7 +12,7 @@ class Geom(ctypes.Structure):
     _fields_ = [(n, ctypes.c_int32) for n in (
         "in_w", "in_h", "pre_x", "pre_y", "pre_w", "pre_h", "do_scale", "alg", "sc_w", "sc_h",
         "crop_x", "crop_y", "crop_w", "crop_h", "do_pad", "pad_x", "pad_y", "out_w", "out_h",
-        "fill_y", "fill_u", "fill_v", "out_range")]
+        "fill_y", "fill_u", "fill_v", "out_range", "out_fmt", "rgb_stage", "fill_rgb")]
 
     def as_dict(self):
         return {n: getattr(self, n) for n, _ in self._fields_}
@@ -30,6 +30,8 @@ SYMBOLS = {
     "tts_plan_create": (ctypes.c_int, [ctypes.POINTER(Geom), ctypes.POINTER(ctypes.c_void_p)]),
     "tts_plan_destroy": (None, [ctypes.c_void_p]),
     "tts_plan_geom": (ctypes.c_int, [ctypes.c_void_p, ctypes.POINTER(Geom)]),
+    "tts_plan_device": (ctypes.c_int, [ctypes.c_void_p]),
+    "tts_plan_frame_bytes": (ctypes.c_size_t, [ctypes.c_void_p, ctypes.c_int]),
     "tts_run": (ctypes.c_int, [ctypes.c_void_p, ctypes.POINTER(Frame), ctypes.POINTER(Frame), ctypes.c_int, ctypes.c_void_p]),
     "tts_run_batch": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_size_t, ctypes.c_void_p,
                                      ctypes.c_size_t, ctypes.c_int, ctypes.c_void_p]),

@@ -8,7 +8,7 @@ LIB = os.path.join(HERE, "libttscale.so")
 
 def build(force: bool = False) -> str:
     csrc = os.path.join(HERE, "csrc")
-    cmd = ["make", "-C", csrc] + (["-B"] if force else [])
+    cmd = ["make", "-j4", "-C", csrc] + (["-B"] if force else [])
     subprocess.run(cmd, check=True, stdout=subprocess.PIPE, stderr=subprocess.STDOUT)
     if not os.path.exists(LIB):
         raise RuntimeError("libttscale.so was not produced by %s" % " ".join(cmd))

@@ -186,8 +186,11 @@ bool scale_output_size(int iw, int ih, int w, int h, int foar, int fdb, int &ow,
     if (w < 0) w = int(rescale(h, iw, i64(ih) * fw) * fw);
     if (h < 0) h = int(rescale(w, ih, i64(iw) * fh) * fh);
     if (foar) {
-        const int tw = int(rescale(h, iw, ih)), th = int(rescale(w, ih, iw));
+        // libavfilter scale_eval.c ff_scale_adjust_dimensions(): the aspect-derived sizes are first rounded to
+        // the NEAREST multiple of force_divisible_by, then min / max'ed against the requested ones, then
+        // rounded down (decrease) or up (increase): 720x1280, 320:180, decrease, fdb 2 -> 102x180.
         fdb = std::max(fdb, 1);
+        const int tw = int(rescale(h, iw, i64(ih) * fdb)) * fdb, th = int(rescale(w, ih, i64(iw) * fdb)) * fdb;
         if (foar == 1) {
             w = std::min(tw, w) / fdb * fdb;
             h = std::min(th, h) / fdb * fdb;
@@ -201,18 +204,18 @@ bool scale_output_size(int iw, int ih, int w, int h, int foar, int fdb, int &ow,
     return true;
 }
 
-int crop_origin(int in, int out, double value, bool has_value)
+int crop_origin(int in, int out, double value, bool has_value, int sub)
 {
     const double v = has_value ? value : (in - out) / 2.0;
     int x = int(std::lrint(v));                 // round half to even, as lrint does
     x = std::max(x, 0);
     if (x + out > in) x = in - out;
-    return x & ~1;                              // 4:2:0 chroma grid
+    return x & ~(sub - 1);                      // the link's chroma grid: 2 on yuv420p, 1 (none) on RGB
 }
 
 int check_geom(const tts_geom &g)
 {
-    auto even = [](int v) { return (v & 1) == 0; };
+    bool (*even)(int) = [](int v) { return (v & 1) == 0; };
     if (g.in_w < 1 || g.in_h < 1 || g.in_w > 16384 || g.in_h > 16384) return TTS_ERR_INVALID_INPUT;
     if (g.pre_w < 1 || g.pre_h < 1 || g.pre_x < 0 || g.pre_y < 0 ||
         g.pre_x + g.pre_w > g.in_w || g.pre_y + g.pre_h > g.in_h) return TTS_ERR_INVALID_INPUT;
@@ -222,6 +225,12 @@ int check_geom(const tts_geom &g)
     if (!g.do_scale && (g.sc_w != g.pre_w || g.sc_h != g.pre_h)) return TTS_ERR_INVALID_INPUT;
     if (g.alg < TTS_ALG_BICUBIC || g.alg > TTS_ALG_BILINEAR) return TTS_ERR_INVALID_INPUT;
     if (g.out_range < TTS_RANGE_KEEP || g.out_range > TTS_RANGE_TO_LIMITED) return TTS_ERR_INVALID_INPUT;
+    if (g.out_fmt < TTS_FMT_YUV420P || g.out_fmt > TTS_FMT_BGRA) return TTS_ERR_INVALID_INPUT;
+    if ((g.out_fmt == TTS_FMT_YUV420P) != (g.rgb_stage == TTS_RGB_NONE) || g.rgb_stage < 0 || g.rgb_stage > TTS_RGB_AT_END) return TTS_ERR_INVALID_INPUT;
+    if (g.out_fmt != TTS_FMT_YUV420P && g.out_range != TTS_RANGE_KEEP) return TTS_ERR_UNSUPPORTED;
+    if (g.fill_rgb & ~0xffffff) return TTS_ERR_INVALID_INPUT;
+    // crop and pad behind an RGB-writing scale work on RGB pixels: no chroma grid
+    if (g.rgb_stage == TTS_RGB_AT_SCALE) even = [](int) { return true; };
     if (g.crop_w < 1 || g.crop_h < 1 || g.crop_x < 0 || g.crop_y < 0 ||
         g.crop_x + g.crop_w > g.sc_w || g.crop_y + g.crop_h > g.sc_h) return TTS_ERR_INVALID_INPUT;
     const bool has_crop = g.crop_x || g.crop_y || g.crop_w != g.sc_w || g.crop_h != g.sc_h;

@@ -21,7 +21,7 @@ bool build_axis_filter(int src, int dst, int one, int alg, AxisFilter &out);
 
 // Geometry helpers.
 bool scale_output_size(int iw, int ih, int w, int h, int foar, int fdb, int &ow, int &oh);
-int  crop_origin(int in, int out, double value, bool has_value);
+int  crop_origin(int in, int out, double value, bool has_value, int sub = 2);   // sub: chroma grid of the link (2 yuv420p, 1 RGB)
 
 // Validate a resolved geometry; returns TTS_OK or an error.
 int  check_geom(const tts_geom &g);

@@ -22,12 +22,18 @@
 #include <new>
 #include <utility>
 #include <string>
+#include <tuple>
 #include <vector>
 
 #include "filter.h"
+#include "ttscale_rgb.h"
 
 #include "ttscale_kernels.h"
 #include "ttscale_plan.h"
+
+namespace tts {
+void set_last_error(const std::string &msg) { g_last_error = msg; }
+}  // namespace tts
 
 // ------------------------------------------------------------------------------------
 // C ABI
@@ -62,10 +68,16 @@ int tts_plan_create(const tts_geom *g, tts_plan **out)
     int cus = 0;
     if (hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) == hipSuccess && cus > 0) p->n_cus = cus;
     std::vector<uint32_t> tab;
+    if (g->out_fmt != TTS_FMT_YUV420P) {
+        rc = tts::rgb_plan_create(*g, p->n_cus, &p->rgb);      // (sets the error text itself)
+        if (rc) { tts_plan_destroy(p); return rc; }
+        *out = p;
+        return TTS_OK;
+    }
     for (int ci = 0; ci < 2 && rc == TTS_OK; ++ci) rc = build_class(*g, ci, p->cls[ci], tab);
     if (rc == TTS_OK && !upload(p->d_tab, tab)) rc = TTS_ERR_INITIALIZATION_FAILED;
     if (rc) {
-        if (rc == TTS_ERR_INITIALIZATION_FAILED) g_last_error = std::string("table upload: ") + hipGetErrorString(hipGetLastError());
+        if (rc == TTS_ERR_INITIALIZATION_FAILED) g_last_error = "table upload failed (hipMalloc / hipMemcpy)";
         tts_plan_destroy(p);
         return rc;
     }
@@ -78,6 +90,7 @@ void tts_plan_destroy(tts_plan *p)
     if (!p) return;
     free_class(p->cls[0]); free_class(p->cls[1]);
     (void)hipFree(p->d_tab);
+    tts::rgb_plan_destroy(p->rgb);
     delete p;
 }
 
@@ -88,9 +101,20 @@ int tts_plan_geom(const tts_plan *p, tts_geom *out)
     return TTS_OK;
 }
 
+int tts_plan_device(const tts_plan *p) { return p ? p->device : TTS_ERR_INVALID_INPUT; }
+
+size_t tts_plan_frame_bytes(const tts_plan *p, int which)
+{
+    if (!p) return 0;
+    if (which == 0) return tts_frame_bytes(p->g.in_w, p->g.in_h);
+    if (p->g.out_fmt == TTS_FMT_YUV420P) return tts_frame_bytes(p->g.out_w, p->g.out_h);
+    return size_t(p->g.out_w) * p->g.out_h * (p->g.out_fmt >= TTS_FMT_RGBA ? 4 : 3);
+}
+
 int tts_plan_filter(const tts_plan *p, int plane_class, int axis, int *taps, int *n_out, int16_t *coef, int32_t *pos)
 {
     if (!p || plane_class < 0 || plane_class > 1 || axis < 0 || axis > 1) return TTS_ERR_INVALID_INPUT;
+    if (p->rgb) return TTS_ERR_UNSUPPORTED;           // (the RGB path keeps four tables: luma and chroma of a dst_w x dst_h context)
     const tts::AxisFilter &f = axis == 0 ? p->cls[plane_class].h : p->cls[plane_class].v;
     if (taps) *taps = f.size;
     if (n_out) *n_out = f.dst;
@@ -113,6 +137,7 @@ int tts_build_filter(int src, int dst, int one, int alg, int *taps, int16_t *coe
 int tts_plan_kernel_kind(const tts_plan *p, int plane_class)
 {
     if (!p || plane_class < 0 || plane_class > 1) return TTS_ERR_INVALID_INPUT;
+    if (p->rgb) return 6;
     const ClassPlan &c = p->cls[plane_class];
     if (c.kind == 0) return 0;
     if (c.kind == 2) return 3 + c.col_dmas;
@@ -124,6 +149,7 @@ const char *tts_plan_kernel_name(const tts_plan *p, int plane_class)
 {
     static thread_local char buf[96];
     if (!p || plane_class < 0 || plane_class > 1) return "";
+    if (p->rgb) return tts::rgb_plan_kernel_name(p->rgb);
     const ClassPlan &c = p->cls[plane_class];
     if (c.kind == 0) std::snprintf(buf, sizeof buf, "generic");
     else if (c.kind == 2) std::snprintf(buf, sizeof buf, "column_lds<%d,%d,%d,%d,%d>", c.NTP, c.Rc, c.col_dmas, c.col_nc, column_depth(c.NTP));
@@ -167,14 +193,31 @@ int run_batch_impl(const tts_plan *p, const void *src, size_t src_pitch, const i
     if (n_frames == 0) return TTS_OK;
     if (!src || !dst) return TTS_ERR_INVALID_INPUT;
     const tts_geom &g = p->g;
+    const int bpp = g.out_fmt == TTS_FMT_YUV420P ? 0 : g.out_fmt >= TTS_FMT_RGBA ? 4 : 3;   // packed RGB out: one plane
     for (int ci = 0; ci < 2; ++ci)
-        if (sstride[ci] < ceil_shift(g.in_w, ci) || dstride[ci] < ceil_shift(g.out_w, ci)) return TTS_ERR_INVALID_INPUT;
+        if (sstride[ci] < ceil_shift(g.in_w, ci) || (!bpp && dstride[ci] < ceil_shift(g.out_w, ci))) return TTS_ERR_INVALID_INPUT;
+    if (bpp && dstride[0] < g.out_w * bpp) return TTS_ERR_INVALID_INPUT;
     const size_t sbytes = size_t(sstride[0]) * g.in_h + 2 * size_t(sstride[1]) * ceil_shift(g.in_h, 1);
-    const size_t dbytes = size_t(dstride[0]) * g.out_h + 2 * size_t(dstride[1]) * ceil_shift(g.out_h, 1);
+    const size_t dbytes = bpp ? size_t(dstride[0]) * g.out_h : size_t(dstride[0]) * g.out_h + 2 * size_t(dstride[1]) * ceil_shift(g.out_h, 1);
     if (src_pitch < sbytes || dst_pitch < dbytes) return TTS_ERR_INVALID_INPUT;
     if (src_pitch >= (size_t(1) << 31) || dst_pitch >= (size_t(1) << 31)) return TTS_ERR_UNSUPPORTED;
     if (const int rc = check_device(p)) return rc;
     hipStream_t st = static_cast<hipStream_t>(hip_stream);
+    if (p->rgb) {
+        // The RGB kernels cover the whole canvas (borders included) and address every frame from its own base
+        // (per workgroup or per wave), so one launch set takes the batch whatever its span.
+        if (sbytes > kMaxSpan || dbytes > kMaxSpan) return TTS_ERR_UNSUPPORTED;
+        FrameAddr addr{};
+        addr.src_pitch = uint32_t(src_pitch); addr.dst_pitch = uint32_t(dst_pitch); addr.wave_base = 1;
+        uint32_t splane = 0;
+        for (int k = 0; k < 3; ++k) {
+            const int ci = k ? 1 : 0;
+            addr.src_plane[k] = splane + uint32_t(g.pre_y >> ci) * sstride[ci] + uint32_t(g.pre_x >> ci);
+            splane += uint32_t(sstride[ci]) * ceil_shift(g.in_h, ci);
+        }
+        return launch_all(p, static_cast<const uint8_t *>(src), static_cast<uint8_t *>(dst), n_frames, sstride, dstride,
+                          uint64_t(n_frames - 1) * src_pitch + sbytes, uint64_t(n_frames - 1) * dst_pitch + dbytes, addr, st);
+    }
 
     FrameAddr addr{};
     addr.src_pitch = uint32_t(src_pitch); addr.dst_pitch = uint32_t(dst_pitch);
@@ -220,7 +263,8 @@ int tts_run_batch(const tts_plan *p, const void *src, size_t src_pitch, void *ds
                   int n_frames, void *hip_stream)
 {
     if (!p) return TTS_ERR_INVALID_INPUT;
-    const int sstride[2] = {p->g.in_w, ceil_shift(p->g.in_w, 1)}, dstride[2] = {p->g.out_w, ceil_shift(p->g.out_w, 1)};
+    const int bpp = p->g.out_fmt == TTS_FMT_YUV420P ? 1 : p->g.out_fmt >= TTS_FMT_RGBA ? 4 : 3;
+    const int sstride[2] = {p->g.in_w, ceil_shift(p->g.in_w, 1)}, dstride[2] = {p->g.out_w * bpp, ceil_shift(p->g.out_w, 1)};
     return run_batch_impl(p, src, src_pitch, sstride, dst, dst_pitch, dstride, n_frames, hip_stream);
 }
 
@@ -237,14 +281,17 @@ int tts_run(const tts_plan *p, const tts_frame *src, const tts_frame *dst, int n
     if (n_frames == 0) return TTS_OK;
     if (!src || !dst) return TTS_ERR_INVALID_INPUT;
     const tts_geom &g = p->g;
+    const int bpp = g.out_fmt == TTS_FMT_YUV420P ? 0 : g.out_fmt >= TTS_FMT_RGBA ? 4 : 3;
+    const int ndp = bpp ? 1 : 3;                       // destination planes: packed RGB frames have one
     for (int i = 0; i < n_frames; ++i) {
         if (src[i].mem != TTS_MEM_DEVICE || dst[i].mem != TTS_MEM_DEVICE) return TTS_ERR_INVALID_INPUT;
         if (src[i].width != g.in_w || src[i].height != g.in_h || dst[i].width != g.out_w || dst[i].height != g.out_h) return TTS_ERR_INVALID_INPUT;
         for (int k = 0; k < 3; ++k) {
-            if (!src[i].plane[k] || !dst[i].plane[k]) return TTS_ERR_INVALID_INPUT;
-            if (src[i].stride[k] < ceil_shift(g.in_w, k ? 1 : 0) || dst[i].stride[k] < ceil_shift(g.out_w, k ? 1 : 0)) return TTS_ERR_INVALID_INPUT;
+            if (!src[i].plane[k] || (k < ndp && !dst[i].plane[k])) return TTS_ERR_INVALID_INPUT;
+            if (src[i].stride[k] < ceil_shift(g.in_w, k ? 1 : 0)) return TTS_ERR_INVALID_INPUT;
+            if (k < ndp && dst[i].stride[k] < (bpp ? g.out_w * bpp : ceil_shift(g.out_w, k ? 1 : 0))) return TTS_ERR_INVALID_INPUT;
         }
-        if (src[i].stride[1] != src[i].stride[2] || dst[i].stride[1] != dst[i].stride[2]) return TTS_ERR_UNSUPPORTED;
+        if (src[i].stride[1] != src[i].stride[2] || (!bpp && dst[i].stride[1] != dst[i].stride[2])) return TTS_ERR_UNSUPPORTED;
     }
     if (const int drc = check_device(p)) return drc;
     hipStream_t st = static_cast<hipStream_t>(hip_stream);
@@ -261,13 +308,15 @@ int tts_run(const tts_plan *p, const tts_frame *src, const tts_frame *dst, int n
             while (f0 + n < first + count && n < kMaxTableFrames) {
                 const tts_frame &s = src[f0 + n], &d = dst[f0 + n];
                 if (n && (s.stride[0] != src[f0].stride[0] || s.stride[1] != src[f0].stride[1] ||
-                          d.stride[0] != dst[f0].stride[0] || d.stride[1] != dst[f0].stride[1])) break;
+                          d.stride[0] != dst[f0].stride[0] || (!bpp && d.stride[1] != dst[f0].stride[1]))) break;
                 uintptr_t a = smin, b = smax, c2 = dmin, e = dmax;
                 for (int k = k0; k < k1; ++k) {
                     const int ci = k ? 1 : 0;
                     const size_t sext = size_t(s.stride[k]) * (ceil_shift(g.in_h, ci) - 1) + ceil_shift(g.in_w, ci);
-                    const size_t dext = size_t(d.stride[k]) * (ceil_shift(g.out_h, ci) - 1) + ceil_shift(g.out_w, ci);
                     a = std::min(a, uintptr_t(s.plane[k])); b = std::max(b, uintptr_t(s.plane[k]) + sext);
+                    if (k >= ndp) continue;
+                    const size_t dext = bpp ? size_t(d.stride[0]) * (g.out_h - 1) + size_t(g.out_w) * bpp
+                                            : size_t(d.stride[k]) * (ceil_shift(g.out_h, ci) - 1) + ceil_shift(g.out_w, ci);
                     c2 = std::min(c2, uintptr_t(d.plane[k])); e = std::max(e, uintptr_t(d.plane[k]) + dext);
                 }
                 if (b - a > kMaxSpan || e - c2 > kMaxSpan) break;
@@ -283,9 +332,11 @@ int tts_run(const tts_plan *p, const tts_frame *src, const tts_frame *dst, int n
                 for (int k = k0; k < k1; ++k) {
                     const int ci = k ? 1 : 0;
                     const ClassPlan &c = p->cls[ci];
-                    const size_t so = size_t(uintptr_t(src[f0 + i].plane[k]) - smin), dof = size_t(uintptr_t(dst[f0 + i].plane[k]) - dmin);
+                    const size_t so = size_t(uintptr_t(src[f0 + i].plane[k]) - smin);
                     addr.src_tab[k][i] = uint32_t(so) + uint32_t(g.pre_y >> ci) * sstride[ci] + uint32_t(g.pre_x >> ci);
-                    addr.dst_tab[k][i] = uint32_t(dof) + uint32_t(c.pad_y) * dstride[ci] + uint32_t(c.pad_x);
+                    if (k >= ndp) continue;
+                    const size_t dof = size_t(uintptr_t(dst[f0 + i].plane[k]) - dmin);
+                    addr.dst_tab[k][i] = bpp ? uint32_t(dof) : uint32_t(dof) + uint32_t(c.pad_y) * dstride[ci] + uint32_t(c.pad_x);
                 }
             const int rc = launch_all(p, reinterpret_cast<const uint8_t *>(smin), reinterpret_cast<uint8_t *>(dmin), n,
                                       sstride, dstride, uint32_t(smax - smin), uint32_t(dmax - dmin), addr, st, only);
@@ -294,8 +345,8 @@ int tts_run(const tts_plan *p, const tts_frame *src, const tts_frame *dst, int n
         }
         return TTS_OK;
     };
-    int rc = p->knobs.planewise ? TTS_ERR_UNSUPPORTED : run_groups(0, n_frames, -1);
-    if (rc == TTS_ERR_UNSUPPORTED) {
+    int rc = p->knobs.planewise && !bpp ? TTS_ERR_UNSUPPORTED : run_groups(0, n_frames, -1);
+    if (rc == TTS_ERR_UNSUPPORTED && !bpp) {
         // some frame's planes are spread over more than kMaxSpan: go plane by plane (a repeat of the
         // frames already done above is harmless -- same inputs, same outputs)
         for (int k = 0; k < 3 && (rc == TTS_ERR_UNSUPPORTED || rc == TTS_OK); ++k) rc = run_groups(0, n_frames, k);
@@ -309,7 +360,7 @@ int tts_run_host(const tts_plan *p, const void *src, void *dst, int n_frames)
     if (n_frames == 0) return TTS_OK;
     if (!src || !dst) return TTS_ERR_INVALID_INPUT;
     if (const int drc = check_device(p)) return drc;
-    const size_t sb = tts_frame_bytes(p->g.in_w, p->g.in_h), db = tts_frame_bytes(p->g.out_w, p->g.out_h);
+    const size_t sb = tts_plan_frame_bytes(p, 0), db = tts_plan_frame_bytes(p, 1);
     // The clip goes through in chunks over two slots (a source and a destination buffer in HBM each) on
     // two streams: chunk i + 1 is on its way up while chunk i is scaled and sent back, both directions of
     // the link busy, device memory bounded whatever the clip's length.  Buffers the caller has pinned
@@ -317,7 +368,7 @@ int tts_run_host(const tts_plan *p, const void *src, void *dst, int n_frames)
     // 31.6 GB/s each way at once, against 8,900 without the overlap; pageable ones are staged by the
     // runtime and run at host-memory speed (2,400 - 3,600 frames/s; registering them here for the call
     // cost more than it saved, so that is left to the caller).
-    const size_t chunk_bytes = size_t(std::max(1, env_int("TTS_HOST_CHUNK_MB", 128))) << 20;
+    const size_t chunk_bytes = size_t(p->knobs.host_chunk_mb) << 20;
     const int per = int(std::max<size_t>(1, std::min<size_t>(size_t(n_frames), chunk_bytes / (sb + db))));
     const int nchunks = (n_frames + per - 1) / per;
     const int slots = std::min(2, nchunks);

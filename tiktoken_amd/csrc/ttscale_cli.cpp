@@ -47,7 +47,7 @@ int main(int argc, char **argv)
     rc = tts_plan_create(&g, &plan);
     if (rc) return fail("plan", rc);
 
-    const size_t sb = tts_frame_bytes(g.in_w, g.in_h), db = tts_frame_bytes(g.out_w, g.out_h);
+    const size_t sb = tts_plan_frame_bytes(plan, 0), db = tts_plan_frame_bytes(plan, 1);   // (packed RGB behind format=rgb24 & co.)
     FILE *fi = std::fopen(in.c_str(), "rb"), *fo = std::fopen(out.c_str(), "wb");
     if (!fi || !fo) { std::fprintf(stderr, "ttscale: cannot open %s\n", fi ? out.c_str() : in.c_str()); return 1; }
     const int batch = 64;

@@ -1,0 +1,110 @@
+// ttscale_device.h -- what the translation units of libttscale share on the device side: launch-wide
+// constants, the frame address table that rides in the kernel arguments, and the small gfx950 helpers
+// (packed dot products, wave-uniform reads, the XCD remap, output stores issued from inline asm).
+// Included by ttscale_kernels.h (the planar scaler, ttscale.hip) and by ttscale_rgb.hip (packed RGB).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <cstddef>
+#include <cstdint>
+
+namespace tts {
+
+constexpr int kBlock = 256;
+constexpr int kMaxLdsBlock = 1024;    // largest workgroup of the LDS-staged kernel
+constexpr size_t kMaxSpan = 0xFF000000u;   // bytes one launch may address from its base pointers
+constexpr uint32_t kDiscard = 0xFFFFFF00u; // a lane offset the buffer range check always rejects (> kMaxSpan)
+constexpr int kMaxTableFrames = 120;  // frames addressed through the in-kernarg offset table (kernel arguments stay under 4 KB)
+
+// Where the planes of frame f live, relative to the base pointers of the launch.  (Named namespace: the
+// struct crosses from ttscale.hip to ttscale_rgb.hip.)  A packed-RGB destination has one plane, [0].
+struct FrameAddr {
+    uint32_t src_pitch, dst_pitch;            // packed mode: bytes between frames
+    uint32_t src_plane[3], dst_plane[3];      // packed mode: plane origin inside a frame
+    int32_t  use_table;                        // table mode: explicit per-frame offsets
+    int32_t  wave_base;                        // packed mode: spans pass kMaxSpan, waves address from their own first frame
+    uint32_t src_tab[3][kMaxTableFrames];
+    uint32_t dst_tab[3][kMaxTableFrames];
+};
+
+}  // namespace tts
+
+namespace {
+
+using tts::FrameAddr;
+using tts::kBlock;
+using tts::kMaxLdsBlock;
+using tts::kMaxSpan;
+using tts::kDiscard;
+using tts::kMaxTableFrames;
+
+typedef short short2_t __attribute__((ext_vector_type(2)));
+typedef uint32_t u32x2_t __attribute__((ext_vector_type(2)));
+typedef uint32_t u32x4_t __attribute__((ext_vector_type(4)));
+
+// clamp = true selects the VOP3P form (v_dot2_i32_i16 d, a, b, c) whose accumulator input is a
+// free operand; the sums here never reach the int32 range, so the clamp never acts.
+__device__ __forceinline__ int dot2(uint32_t a, uint32_t b, int c)
+{
+    return __builtin_amdgcn_sdot2(__builtin_bit_cast(short2_t, a), __builtin_bit_cast(short2_t, b), c, true);
+}
+
+__device__ __forceinline__ uint32_t uni(uint32_t v) { return uint32_t(__builtin_amdgcn_readfirstlane(int(v))); }
+
+// Blocks are dealt round-robin over the 8 XCDs; give each XCD a contiguous run of
+// logical blocks so neighbouring strips and row segments share one L2.
+__device__ __forceinline__ uint32_t xcd_remap(uint32_t b, uint32_t n)
+{
+    const uint32_t q = n >> 3, r = n & 7, x = b & 7, k = b >> 3;
+    return (x < r ? x * (q + 1) : r * (q + 1) + (x - r) * q) + k;
+}
+
+// 15-bit intermediate of swscale's horizontal pass: truncating >>7, clip to 32767
+__device__ __forceinline__ uint32_t hfinish(int acc)
+{
+    acc >>= 7;
+    return uint32_t(acc < 32767 ? acc : 32767);
+}
+
+// four vertical sums -> four clipped bytes (val >> 19, clip to 0..255)
+__device__ __forceinline__ uint32_t pack4(int v0, int v1, int v2, int v3)
+{
+    // high halves of each pair, then >>3 on the packed int16s == >>19 on the int32s
+    const uint32_t h01 = __builtin_amdgcn_perm(uint32_t(v1), uint32_t(v0), 0x07060302);
+    const uint32_t h23 = __builtin_amdgcn_perm(uint32_t(v3), uint32_t(v2), 0x07060302);
+    const short2_t s01 = __builtin_bit_cast(short2_t, h01) >> short2_t{3, 3};
+    const short2_t s23 = __builtin_bit_cast(short2_t, h23) >> short2_t{3, 3};
+    uint32_t b01, b23;
+    asm("v_sat_pk_u8_i16 %0, %1" : "=v"(b01) : "v"(s01));
+    asm("v_sat_pk_u8_i16 %0, %1" : "=v"(b23) : "v"(s23));
+    return b01 | (b23 << 16);
+}
+
+// Output stores are issued from inline asm.  hipcc's s_waitcnt pass counts the vector-memory
+// operations it can see; with stores visible inside the variable-trip emission loop it can no
+// longer count and falls back to vmcnt(0) before every use of a prefetched row, which drains the
+// rows still in flight AND every store acknowledgement once per source row.  Stores it cannot see
+// leave it counting the row loads alone, vmcnt((D-1)*loads), which (the counter retires in issue
+// order) is never too weak: the hidden stores only make the wait retire a few more operations.
+__device__ __forceinline__ void store_b128(u32x4_t v, u32x4_t rs, uint32_t off, int soff)
+{
+    asm volatile("buffer_store_dwordx4 %0, %1, %2, %3 offen" :: "v"(v), "v"(off), "s"(rs), "s"(soff));
+}
+__device__ __forceinline__ void store_b64(u32x2_t v, u32x4_t rs, uint32_t off, int soff)
+{
+    asm volatile("buffer_store_dwordx2 %0, %1, %2, %3 offen" :: "v"(v), "v"(off), "s"(rs), "s"(soff));
+}
+__device__ __forceinline__ void store_b8(uint32_t v, u32x4_t rs, uint32_t off, int soff)
+{
+    asm volatile("buffer_store_byte %0, %1, %2, %3 offen" :: "v"(v), "v"(off), "s"(rs), "s"(soff));
+}
+[[maybe_unused]] __device__ __forceinline__ void store_b16(uint32_t v, u32x4_t rs, uint32_t off, int soff)
+{
+    asm volatile("buffer_store_short %0, %1, %2, %3 offen" :: "v"(v), "v"(off), "s"(rs), "s"(soff));
+}
+[[maybe_unused]] __device__ __forceinline__ void store_b32(uint32_t v, u32x4_t rs, uint32_t off, int soff)
+{
+    asm volatile("buffer_store_dword %0, %1, %2, %3 offen" :: "v"(v), "v"(off), "s"(rs), "s"(soff));
+}
+
+
+}  // namespace

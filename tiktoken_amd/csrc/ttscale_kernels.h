@@ -8,31 +8,8 @@
 //   generic_kernel     any tap count, one lane per output sample
 //   fill_kernel, range_kernel   pad colour; limited <-> full range table
 #pragma once
+#include "ttscale_device.h"
 namespace {
-
-// ------------------------------------------------------------------------------------
-// device side
-// ------------------------------------------------------------------------------------
-
-constexpr int kBlock = 256;
-constexpr int kMaxLdsBlock = 1024;    // largest workgroup of the LDS-staged kernel
-constexpr size_t kMaxSpan = 0xFF000000u;   // bytes one launch may address from its base pointers
-[[maybe_unused]] constexpr uint32_t kDiscard = 0xFFFFFF00u; // a lane offset the buffer range check always rejects (> kMaxSpan)
-constexpr int kMaxTableFrames = 120;  // frames addressed through the in-kernarg offset table (kernel arguments stay under 4 KB)
-
-typedef short short2_t __attribute__((ext_vector_type(2)));
-typedef uint32_t u32x2_t __attribute__((ext_vector_type(2)));
-typedef uint32_t u32x4_t __attribute__((ext_vector_type(4)));
-
-// Where the planes of frame f live, relative to the base pointers of the launch.
-struct FrameAddr {
-    uint32_t src_pitch, dst_pitch;            // packed mode: bytes between frames
-    uint32_t src_plane[3], dst_plane[3];      // packed mode: plane origin inside a frame
-    int32_t  use_table;                        // table mode: explicit per-frame offsets
-    int32_t  wave_base;                        // packed mode: spans pass kMaxSpan, waves address from their own first frame
-    uint32_t src_tab[3][kMaxTableFrames];
-    uint32_t dst_tab[3][kMaxTableFrames];
-};
 
 // One plane class (0 = luma, 1 = both chroma planes) of a strip launch.
 struct StripClass {
@@ -53,15 +30,6 @@ struct StripArgs {
     uint64_t src_span, dst_span;   // bytes reachable from the base pointers (buffer range check)
     FrameAddr addr;
 };
-
-// clamp = true selects the VOP3P form (v_dot2_i32_i16 d, a, b, c) whose accumulator input is a
-// free operand; the sums here never reach the int32 range, so the clamp never acts.
-__device__ __forceinline__ int dot2(uint32_t a, uint32_t b, int c)
-{
-    return __builtin_amdgcn_sdot2(__builtin_bit_cast(short2_t, a), __builtin_bit_cast(short2_t, b), c, true);
-}
-
-__device__ __forceinline__ uint32_t uni(uint32_t v) { return uint32_t(__builtin_amdgcn_readfirstlane(int(v))); }
 
 // Where this lane's plane lies.  Lane offsets are 32-bit, a launch is not: in packed mode every wave
 // addresses from ITS first frame (lanes are ordered by frame, so that is lane 0's; the host checks that
@@ -88,62 +56,6 @@ __device__ __forceinline__ void frame_offsets(const StripArgs &a, int plane, int
         soff = (uint32_t(frame) - f0) * a.addr.src_pitch + a.addr.src_plane[plane];
         doff = (uint32_t(frame) - f0) * a.addr.dst_pitch + a.addr.dst_plane[plane];
     }
-}
-
-// Blocks are dealt round-robin over the 8 XCDs; give each XCD a contiguous run of
-// logical blocks so neighbouring strips and row segments share one L2.
-__device__ __forceinline__ uint32_t xcd_remap(uint32_t b, uint32_t n)
-{
-    const uint32_t q = n >> 3, r = n & 7, x = b & 7, k = b >> 3;
-    return (x < r ? x * (q + 1) : r * (q + 1) + (x - r) * q) + k;
-}
-
-// 15-bit intermediate of swscale's horizontal pass: truncating >>7, clip to 32767
-__device__ __forceinline__ uint32_t hfinish(int acc)
-{
-    acc >>= 7;
-    return uint32_t(acc < 32767 ? acc : 32767);
-}
-
-// four vertical sums -> four clipped bytes (val >> 19, clip to 0..255)
-__device__ __forceinline__ uint32_t pack4(int v0, int v1, int v2, int v3)
-{
-    // high halves of each pair, then >>3 on the packed int16s == >>19 on the int32s
-    const uint32_t h01 = __builtin_amdgcn_perm(uint32_t(v1), uint32_t(v0), 0x07060302);
-    const uint32_t h23 = __builtin_amdgcn_perm(uint32_t(v3), uint32_t(v2), 0x07060302);
-    const short2_t s01 = __builtin_bit_cast(short2_t, h01) >> short2_t{3, 3};
-    const short2_t s23 = __builtin_bit_cast(short2_t, h23) >> short2_t{3, 3};
-    uint32_t b01, b23;
-    asm("v_sat_pk_u8_i16 %0, %1" : "=v"(b01) : "v"(s01));
-    asm("v_sat_pk_u8_i16 %0, %1" : "=v"(b23) : "v"(s23));
-    return b01 | (b23 << 16);
-}
-
-// Output stores are issued from inline asm.  hipcc's s_waitcnt pass counts the vector-memory
-// operations it can see; with stores visible inside the variable-trip emission loop it can no
-// longer count and falls back to vmcnt(0) before every use of a prefetched row, which drains the
-// rows still in flight AND every store acknowledgement once per source row.  Stores it cannot see
-// leave it counting the row loads alone, vmcnt((D-1)*loads), which (the counter retires in issue
-// order) is never too weak: the hidden stores only make the wait retire a few more operations.
-__device__ __forceinline__ void store_b128(u32x4_t v, u32x4_t rs, uint32_t off, int soff)
-{
-    asm volatile("buffer_store_dwordx4 %0, %1, %2, %3 offen" :: "v"(v), "v"(off), "s"(rs), "s"(soff));
-}
-__device__ __forceinline__ void store_b64(u32x2_t v, u32x4_t rs, uint32_t off, int soff)
-{
-    asm volatile("buffer_store_dwordx2 %0, %1, %2, %3 offen" :: "v"(v), "v"(off), "s"(rs), "s"(soff));
-}
-__device__ __forceinline__ void store_b8(uint32_t v, u32x4_t rs, uint32_t off, int soff)
-{
-    asm volatile("buffer_store_byte %0, %1, %2, %3 offen" :: "v"(v), "v"(off), "s"(rs), "s"(soff));
-}
-[[maybe_unused]] __device__ __forceinline__ void store_b16(uint32_t v, u32x4_t rs, uint32_t off, int soff)
-{
-    asm volatile("buffer_store_short %0, %1, %2, %3 offen" :: "v"(v), "v"(off), "s"(rs), "s"(soff));
-}
-[[maybe_unused]] __device__ __forceinline__ void store_b32(uint32_t v, u32x4_t rs, uint32_t off, int soff)
-{
-    asm volatile("buffer_store_dword %0, %1, %2, %3 offen" :: "v"(v), "v"(off), "s"(rs), "s"(soff));
 }
 
 // How a lane fetches the source bytes of its N columns from one source row:
@@ -723,37 +635,53 @@ __global__ __launch_bounds__(kMaxLdsBlock, (GC == 4 && R == 4 && LW == 4) ? 8 : 
 // int16 pairs; an output row is R/2 v_dot2 against the wave-uniform vertical taps and one byte
 // store per lane (a wave stores 64 contiguous bytes).  Every source byte is read once per row
 // segment; the generic kernel re-reads each one taps^2 / ratio^2 times.
-// NDW aligned dwords starting at LDS address p, any NDW: ds_read2_b32 pairs (+ one ds_read_b32), ONE wait,
-// then every register is passed through an empty asm so that no use can be scheduled before the wait
-// (volatile asm statements keep their order; the compiler knows nothing of the reads themselves, so it adds
-// no waits of its own -- see the window readers above).
-template <int I> __device__ __forceinline__ void lds_rd2(u32x2_t &t, uint32_t p)
-{
-    asm volatile("ds_read2_b32 %0, %1 offset0:%2 offset1:%3" : "=v"(t) : "v"(p), "n"(I), "n"(I + 1) : "memory");
-}
-template <int I> __device__ __forceinline__ void lds_rd1(uint32_t &t, uint32_t p)
-{
-    asm volatile("ds_read_b32 %0, %1 offset:%2" : "=v"(t) : "v"(p), "n"(4 * I) : "memory");
-}
-__device__ __forceinline__ void lds_landed(u32x2_t &t) { asm volatile("" : "+v"(t)); }
-__device__ __forceinline__ void lds_landed(uint32_t &t) { asm volatile("" : "+v"(t)); }
-template <int NDW, int... I>
-__device__ __forceinline__ void lds_read_dwords_impl(uint32_t (&w)[NDW], uint32_t p, std::integer_sequence<int, I...>)
-{
-    u32x2_t t[NDW / 2];
-    uint32_t last = 0;
-    (lds_rd2<2 * I>(t[I], p), ...);
-    if constexpr (NDW % 2 != 0) lds_rd1<NDW - 1>(last, p);
-    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-    (lds_landed(t[I]), ...);
-    if constexpr (NDW % 2 != 0) lds_landed(last);
-    ((w[2 * I] = t[I].x, w[2 * I + 1] = t[I].y), ...);
-    if constexpr (NDW % 2 != 0) w[NDW - 1] = last;
-}
+// NDW aligned dwords starting at LDS address p (NDW = 4..17: windows of 6..32 tap pairs at any byte phase):
+// ds_read2_b32 pairs (+ one ds_read_b32) and their lgkmcnt wait in ONE asm statement, like the strip readers
+// above: as far as the compiler can tell no output register exists before its data has landed, so it cannot
+// place a copy or a spill of one between a read and the wait.  (The compiler knows nothing of the reads
+// themselves, so it adds no waits of its own.)  The statement is spelt once per pair count by macros.
+#define TTS_RDP(k, a, b) "ds_read2_b32 %" #k ", %[p] offset0:" #a " offset1:" #b "\n\t"
+#define TTS_RD_2 TTS_RDP(0, 0, 1) TTS_RDP(1, 2, 3)
+#define TTS_RD_3 TTS_RD_2 TTS_RDP(2, 4, 5)
+#define TTS_RD_4 TTS_RD_3 TTS_RDP(3, 6, 7)
+#define TTS_RD_5 TTS_RD_4 TTS_RDP(4, 8, 9)
+#define TTS_RD_6 TTS_RD_5 TTS_RDP(5, 10, 11)
+#define TTS_RD_7 TTS_RD_6 TTS_RDP(6, 12, 13)
+#define TTS_RD_8 TTS_RD_7 TTS_RDP(7, 14, 15)
+#define TTS_RO_2 "=&v"(t[0]), "=&v"(t[1])
+#define TTS_RO_3 TTS_RO_2, "=&v"(t[2])
+#define TTS_RO_4 TTS_RO_3, "=&v"(t[3])
+#define TTS_RO_5 TTS_RO_4, "=&v"(t[4])
+#define TTS_RO_6 TTS_RO_5, "=&v"(t[5])
+#define TTS_RO_7 TTS_RO_6, "=&v"(t[6])
+#define TTS_RO_8 TTS_RO_7, "=&v"(t[7])
+// NP pairs, then (odd NDW) the last dword at byte offset 8 * NP as operand %NP
+#define TTS_RD_EVEN(NP) asm volatile(TTS_RD_##NP "s_waitcnt lgkmcnt(0)" : TTS_RO_##NP : [p] "v"(p) : "memory")
+#define TTS_RD_ODD(NP, LASTOP, LASTOFF) \
+    asm volatile(TTS_RD_##NP "ds_read_b32 %" #LASTOP ", %[p] offset:" #LASTOFF "\n\ts_waitcnt lgkmcnt(0)" : TTS_RO_##NP, "=&v"(last) : [p] "v"(p) : "memory")
 template <int NDW>
 __device__ __forceinline__ void lds_read_dwords(uint32_t (&w)[NDW], uint32_t p)
 {
-    lds_read_dwords_impl<NDW>(w, p, std::make_integer_sequence<int, NDW / 2>{});
+    static_assert(NDW >= 4 && NDW <= 17, "one asm statement per dword count on offer");
+    u32x2_t t[NDW / 2];
+    [[maybe_unused]] uint32_t last = 0;
+    if constexpr (NDW == 4) TTS_RD_EVEN(2);
+    else if constexpr (NDW == 5) TTS_RD_ODD(2, 2, 16);
+    else if constexpr (NDW == 6) TTS_RD_EVEN(3);
+    else if constexpr (NDW == 7) TTS_RD_ODD(3, 3, 24);
+    else if constexpr (NDW == 8) TTS_RD_EVEN(4);
+    else if constexpr (NDW == 9) TTS_RD_ODD(4, 4, 32);
+    else if constexpr (NDW == 10) TTS_RD_EVEN(5);
+    else if constexpr (NDW == 11) TTS_RD_ODD(5, 5, 40);
+    else if constexpr (NDW == 12) TTS_RD_EVEN(6);
+    else if constexpr (NDW == 13) TTS_RD_ODD(6, 6, 48);
+    else if constexpr (NDW == 14) TTS_RD_EVEN(7);
+    else if constexpr (NDW == 15) TTS_RD_ODD(7, 7, 56);
+    else if constexpr (NDW == 16) TTS_RD_EVEN(8);
+    else TTS_RD_ODD(8, 8, 64);
+#pragma unroll
+    for (int i = 0; i < NDW / 2; ++i) { w[2 * i] = t[i].x; w[2 * i + 1] = t[i].y; }
+    if constexpr (NDW % 2 != 0) w[NDW - 1] = last;
 }
 
 // NTP: tap pairs per column (window = 2 * NTP bytes); R: ring depth >= vertical taps; NDMA as above;

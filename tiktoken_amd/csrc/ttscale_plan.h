@@ -70,6 +70,22 @@ int env_int(const char *name, int dflt)
     return e && *e ? std::atoi(e) : dflt;
 }
 
+// One kernel launch whose OWN status is returned: hipLaunchKernel reports the failure of this launch, so a
+// stale error left by the host application's earlier HIP calls is neither blamed on this library nor
+// cleared from under the application (hipGetLastError would do both).
+template <class... P, class... A>
+int launch_checked(const char *what, void (*fn)(P...), dim3 grid, dim3 block, size_t lds, hipStream_t st, A &&...args)
+{
+    std::tuple<P...> held(std::forward<A>(args)...);
+    void *ptrs[sizeof...(P)];
+    size_t i = 0;
+    std::apply([&](auto &...v) { ((ptrs[i++] = const_cast<void *>(static_cast<const void *>(&v))), ...); }, held);
+    const hipError_t e = hipLaunchKernel(reinterpret_cast<const void *>(fn), grid, block, ptrs, lds, st);
+    if (e == hipSuccess) return TTS_OK;
+    g_last_error = std::string(what) + ": " + hipGetErrorString(e);
+    return TTS_ERR_PROCESSING_FAILED;
+}
+
 }  // namespace
 
 // Tuning knobs (environment), read ONCE when a plan is created so that tts_run* never calls getenv.
@@ -85,6 +101,7 @@ struct Knobs {
     int wave_base = 0;                // tts_run_batch: per-wave descriptors even when the batch fits one base (test knob)
     int col_nc_launch = 0;            // column walk above 8 tap pairs: 1 / 2 columns per lane whatever the launch's size (0 = by size)
     int col_fill = 0;                 // column walk: workgroups per resident slot (in tenths) a segment length must leave; 0 = by tap count
+    int host_chunk_mb = 128;          // tts_run_host: bytes (source + output) of one pipelined chunk
     void read()
     {
         strip_n = env_int("TTS_STRIP_N", 8); strip_d = env_int("TTS_STRIP_D", 0);
@@ -99,6 +116,7 @@ struct Knobs {
         wave_base = env_int("TTS_WAVE_BASE", 0);
         col_fill = std::max(0, env_int("TTS_COL_FILL", 0));
         col_nc_launch = env_int("TTS_COL_NC_LAUNCH", 0);
+        host_chunk_mb = std::max(1, env_int("TTS_HOST_CHUNK_MB", 128));
     }
 };
 
@@ -107,6 +125,7 @@ struct tts_plan {
     Knobs knobs;
     ClassPlan cls[2];
     uint32_t *d_tab = nullptr;        // strip tables of both classes
+    tts::RgbPlan *rgb = nullptr;      // packed-RGB output (g.out_fmt != yuv420p): the plan of ttscale_rgb.hip; cls[] stay empty
     int device = 0;
     int n_cus = 256;
 };
@@ -654,9 +673,14 @@ int launch_all(const tts_plan *p, const uint8_t *src, uint8_t *dst, int n, const
                int only_plane = -1)
 {
     // the plain kernels index frames by grid.z (at most 65535 planes a launch)
+    if (p->rgb) {
+        if (only_plane >= 0) { g_last_error = "packed RGB output needs the planes of a frame within 4 GiB of each other"; return TTS_ERR_UNSUPPORTED; }
+        return tts::rgb_launch(p->rgb, src, dst, n, src_stride, dst_stride[0], src_span, dst_span, addr, st);
+    }
+    int lrc = TTS_OK;                                  // first failed launch, if any
     auto z_launches = [&](int planes, auto &&launch) {
         const int per = 65535 / planes;
-        for (int f0 = 0; f0 < n; f0 += per) launch(f0, std::min(per, n - f0));
+        for (int f0 = 0; f0 < n && !lrc; f0 += per) lrc = launch(f0, std::min(per, n - f0));
     };
     auto active  = [&](int ci) { return only_plane < 0 || ci == (only_plane ? 1 : 0); };
     auto nplanes = [&](int ci) { return only_plane < 0 ? (ci ? 2 : 1) : 1; };
@@ -675,8 +699,9 @@ int launch_all(const tts_plan *p, const uint8_t *src, uint8_t *dst, int n, const
             z_launches(f.planes, [&](int f0, int nf) {
                 f.frame0 = f0;
                 dim3 grid((c.canvas_w + 255) / 256, (c.canvas_h + 3) / 4, nf * f.planes);
-                hipLaunchKernelGGL(fill_kernel, grid, dim3(kBlock), 0, st, f);
+                return launch_checked("fill_kernel", fill_kernel, grid, dim3(kBlock), 0, st, f);
             });
+            if (lrc) return lrc;
         }
     }
 
@@ -735,7 +760,7 @@ int launch_all(const tts_plan *p, const uint8_t *src, uint8_t *dst, int n, const
             a.c[1] = a.c[0]; a.c[1].nblocks = 0;
         }
         const uint32_t blocks = a.c[0].nblocks + (merged ? a.c[1].nblocks : 0);
-        hipLaunchKernelGGL(fn, dim3(blocks), dim3(bs.threads), bs.lds_bytes, st, src, dst, p->d_tab, a);
+        if (const int rc = launch_checked("strip kernel", fn, dim3(blocks), dim3(bs.threads), bs.lds_bytes, st, src, dst, p->d_tab, a)) return rc;
         if (merged) break;
     }
 
@@ -795,7 +820,7 @@ int launch_all(const tts_plan *p, const uint8_t *src, uint8_t *dst, int n, const
                 a.c[1] = a.c[0]; a.c[1].nblocks = 0;
             }
             const uint32_t blocks = a.c[0].nblocks + (cmerged ? a.c[1].nblocks : 0);
-            hipLaunchKernelGGL(fn, dim3(blocks), dim3(kBlock), 0, st, src, dst, p->d_tab, a);
+            if (const int rc = launch_checked("column kernel", fn, dim3(blocks), dim3(kBlock), 0, st, src, dst, p->d_tab, a)) return rc;
             if (cmerged) break;
         }
     }
@@ -814,8 +839,9 @@ int launch_all(const tts_plan *p, const uint8_t *src, uint8_t *dst, int n, const
         z_launches(a.planes, [&](int f0, int nf) {
             a.frame0 = f0;
             dim3 grid((c.ow + 63) / 64, (c.oh + 3) / 4, nf * a.planes);
-            hipLaunchKernelGGL(generic_kernel, grid, dim3(kBlock), 0, st, a);
+            return launch_checked("generic_kernel", generic_kernel, grid, dim3(kBlock), 0, st, a);
         });
+        if (lrc) return lrc;
     }
     if (p->g.out_range != TTS_RANGE_KEEP) {
         for (int ci = 0; ci < 2; ++ci) {
@@ -830,11 +856,12 @@ int launch_all(const tts_plan *p, const uint8_t *src, uint8_t *dst, int n, const
             z_launches(r.planes, [&](int f0, int nf) {
                 r.frame0 = f0;
                 dim3 grid((c.canvas_w + 255) / 256, (c.canvas_h + 3) / 4, nf * r.planes);
-                hipLaunchKernelGGL(range_kernel, grid, dim3(kBlock), 0, st, r);
+                return launch_checked("range_kernel", range_kernel, grid, dim3(kBlock), 0, st, r);
             });
+            if (lrc) return lrc;
         }
     }
-    return hipGetLastError() == hipSuccess ? TTS_OK : TTS_ERR_PROCESSING_FAILED;
+    return TTS_OK;
 }
 
 }  // namespace

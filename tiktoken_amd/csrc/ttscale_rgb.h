@@ -1,0 +1,28 @@
+// ttscale_rgb.h -- what ttscale.hip (the C ABI, the planar scaler) and ttscale_rgb.hip (the packed-RGB
+// output paths: SURVEY.md 8f-1) know of each other.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <cstdint>
+#include <string>
+
+#include "../../include/ttscale.h"
+#include "ttscale_device.h"
+
+namespace tts {
+
+// the calling thread's tts_last_error() text (defined in ttscale.hip)
+void set_last_error(const std::string &msg);
+
+struct RgbPlan;        // tables of one geometry whose output is packed RGB, on the current device
+
+// TTS_OK, or why this geometry cannot go out as packed RGB (message through set_last_error)
+int  rgb_plan_create(const tts_geom &g, int n_cus, RgbPlan **out);
+void rgb_plan_destroy(RgbPlan *p);
+const char *rgb_plan_kernel_name(const RgbPlan *p);
+
+// One launch set: frames [0, n) addressed by `addr` relative to (src, dst); src_stride = luma / chroma row
+// pitch of the yuv420p source, dst_stride = bytes between RGB rows.  Asynchronous on st.
+int rgb_launch(const RgbPlan *p, const uint8_t *src, uint8_t *dst, int n, const int src_stride[2], int dst_stride,
+               uint64_t src_span, uint64_t dst_span, const FrameAddr &addr, hipStream_t st);
+
+}  // namespace tts

@@ -1,0 +1,389 @@
+// ttscale_rgb.hip -- packed-RGB output of libttscale: the yuv420p -> rgb24 / bgr24 /
+// rgba / bgra conversion swscale performs INSIDE its scaling pass, fused here into the scaler's vertical
+// pass so that no yuv intermediate ever reaches HBM and every output row is written once, as RGB.
+//
+// The reference's chains end in yuv420p / mjpeg (src/services/video.js:329-334); BASELINE.json's north_star
+// lists the colour conversion as part of the path, so `format=rgb24` (bgr24, rgba, bgra) ending a chain
+// selects what libswscale's C path computes for such a context (default flags: no full_chroma_int, no
+// accurate_rnd):
+//   * chroma is scaled to ceil(dst_w / 2) columns and dst_h rows (two neighbouring pixels share a chroma
+//     sample; vertically chroma is interpolated to every output row), luma to dst_w x dst_h, both through
+//     hScale8To15 (15-bit intermediate, truncating >> 7);
+//   * output.c yuv2rgb_X_c_template(): Y1, Y2, U, V = (1 << 18 + sum of taps x intermediates) >> 19, NOT
+//     clipped, index libswscale/yuv2rgb.c's tables: r = table_rV[V], g = table_gU[U] + table_gV[V],
+//     b = table_bU[U], pixel = r[Y], g[Y], b[Y];
+//   * the tables (ff_yuv2rgb_c_init_tables, ITU-R BT.601, limited range) are one clipped ramp
+//     y_table[i] = clip_u8((i * cy - (384 << 16) - (16 << 16) + 0x8000) >> 16), entered at 326 + Y + the
+//     chroma's offset ((clip_u8(C) * inc) >> 16) - (inc >> 9) -- so a pixel is a closed form,
+//         clip_u8(((Y + off) * cy + K) >> 16),   K = 326 cy - (400 << 16) + 0x8000,
+//     which is what the kernels evaluate (the oracle keeps swscale's tables; the two must agree);
+//   * same size in and out with an even height: the unscaled converter (yuv2rgb_c_24_rgb & co.), which
+//     indexes the same tables with the 8-bit samples, chroma row y >> 1 for both luma rows.
+// Constants recalled from FFmpeg 4.x-6.x, UNVERIFIED like the rest.
+//
+// Kernels: rgb_strip_kernel (every axis <= 4 taps: the portrait upscales), rgb_generic_kernel (any taps),
+// rgb_unscaled_kernel.  All three cover the whole canvas: pad borders are written by the same launch.
+#include "ttscale_rgb.h"
+
+#include <algorithm>
+#include <cstdio>
+#include <cstring>
+#include <new>
+#include <tuple>
+#include <vector>
+
+#include "filter.h"
+
+namespace tts {
+
+// BT.601 limited-range tables of ff_yuv2rgb_c_init_tables() as the closed form above
+struct RgbCoef {
+    int32_t cy, crv, cbu, cgu, cgv;     // cy = 65536 * 255 / 219; the chroma increments "scaled by cy"
+    int32_t k;                          // 326 cy - (400 << 16) + 0x8000
+    int32_t off_r, off_g, off_b;        // -(crv >> 9), -(cgu >> 9) - (cgv >> 9), -(cbu >> 9)
+};
+
+static RgbCoef rgb_coef()
+{
+    RgbCoef c;
+    const int64_t cy = (int64_t(1) << 16) * 255 / 219;
+    auto scaled = [&](int64_t v) { return int32_t((v * (1 << 16) + 0x8000) / cy); };   // C division: truncates toward zero
+    c.cy = int32_t(cy);
+    c.crv = scaled(104597); c.cbu = scaled(132201); c.cgu = scaled(-25675); c.cgv = scaled(-53279);
+    c.k = int32_t(326 * cy - (int64_t(400) << 16) + 0x8000);
+    c.off_r = -(c.crv >> 9); c.off_b = -(c.cbu >> 9); c.off_g = -(c.cgu >> 9) - (c.cgv >> 9);
+    return c;
+}
+
+// one pixel, host and device: Y is the (unclipped) vertical-pass value, U and V likewise
+__host__ __device__ inline void rgb_pixel(const RgbCoef &c, int Y, int U, int V, int &r, int &g, int &b)
+{
+    U = U < 0 ? 0 : U > 255 ? 255 : U;          // fill_table(): av_clip_uint8(i - YUVRGB_TABLE_HEADROOM)
+    V = V < 0 ? 0 : V > 255 ? 255 : V;
+    const int tr = Y + ((V * c.crv) >> 16) + c.off_r;
+    const int tg = Y + ((U * c.cgu) >> 16) + ((V * c.cgv) >> 16) + c.off_g;      // (>> of a negative product: floor, as in C on int64)
+    const int tb = Y + ((U * c.cbu) >> 16) + c.off_b;
+    r = (tr * c.cy + c.k) >> 16; g = (tg * c.cy + c.k) >> 16; b = (tb * c.cy + c.k) >> 16;
+    r = r < 0 ? 0 : r > 255 ? 255 : r; g = g < 0 ? 0 : g > 255 ? 255 : g; b = b < 0 ? 0 : b > 255 ? 255 : b;
+}
+
+}  // namespace tts
+
+namespace {
+
+using tts::RgbCoef;
+
+// What every RGB kernel needs to know of the chain: the canvas, where the picture sits in it, which part of
+// the context's output (the virtual scaled image) the picture is, the border colour, the frame addresses.
+struct RgbFrameArgs {
+    const uint8_t *src;
+    uint8_t       *dst;
+    int32_t canvas_w, canvas_h;        // output frame
+    int32_t px, py, pw, ph;            // picture rectangle inside the canvas
+    int32_t ox, oy;                    // its origin in the context's output (crop offset behind the scale)
+    int32_t src_stride_y, src_stride_c, dst_stride;
+    int32_t bpp, swap;                 // 3 / 4 bytes a pixel; swap: B first
+    int32_t border[3];                 // border pixel, r g b
+    // The pad ran on yuv420p, ahead of the conversion (TTS_RGB_AT_END): luma and chroma planes were padded
+    // separately, on their own grids -- an odd picture height leaves a luma border row over a picture chroma
+    // row -- so a canvas pixel takes Y from the luma rectangle and U, V from the chroma rectangle.
+    int32_t yuv_pad;
+    int32_t cpx, cpy, cpw, cph;        // yuv_pad: picture rectangle of the chroma planes
+    int32_t fill[3];                   // yuv_pad: pad colour y, u, v
+    int32_t frame0;                    // first frame of this launch (grid.z holds at most 65535 frames)
+    RgbCoef coef;
+    FrameAddr addr;
+};
+
+// base pointers of the frame a workgroup works on (grid.z = frame): 64-bit, per workgroup
+__device__ __forceinline__ void rgb_frame_bases(const RgbFrameArgs &a, int frame, const uint8_t *(&sp)[3], uint8_t *&dp)
+{
+    if (a.addr.use_table) {
+        for (int k = 0; k < 3; ++k) sp[k] = a.src + a.addr.src_tab[k][frame];
+        dp = a.dst + a.addr.dst_tab[0][frame];
+    } else {
+        for (int k = 0; k < 3; ++k) sp[k] = a.src + size_t(frame) * a.addr.src_pitch + a.addr.src_plane[k];
+        dp = a.dst + size_t(frame) * a.addr.dst_pitch;
+    }
+}
+
+__device__ __forceinline__ void rgb_store_pixel(uint8_t *d, int bpp, int swap, int r, int g, int b)
+{
+    d[0] = uint8_t(swap ? b : r); d[1] = uint8_t(g); d[2] = uint8_t(swap ? r : b);
+    if (bpp == 4) d[3] = 255;
+}
+
+// ---- same size in and out, even height: swscale's unscaled converter --------------------------------
+// Four adjacent pixels a lane (two chroma samples), 12 or 16 bytes stored as dwords where the row allows.
+__global__ __launch_bounds__(kBlock) void rgb_unscaled_kernel(const RgbFrameArgs a)
+{
+    const int x0 = (int(blockIdx.x) * 64 + int(threadIdx.x & 63)) * 4;
+    const int y  = int(blockIdx.y) * 4 + int(threadIdx.x >> 6);
+    if (x0 >= a.canvas_w || y >= a.canvas_h) return;
+    const uint8_t *sp[3];
+    uint8_t *dp;
+    rgb_frame_bases(a, a.frame0 + int(blockIdx.z), sp, dp);
+    uint8_t px[16];
+    const int n = min(4, a.canvas_w - x0);
+    const bool in_rows = y >= a.py && y < a.py + a.ph;
+    for (int i = 0; i < n; ++i) {
+        const int x = x0 + i;
+        int r = a.border[0], g = a.border[1], b = a.border[2];
+        const bool in_luma = in_rows && x >= a.px && x < a.px + a.pw;
+        if (a.yuv_pad) {
+            int Y = a.fill[0], U = a.fill[1], V = a.fill[2];
+            if (in_luma) Y = sp[0][size_t(a.oy + y - a.py) * a.src_stride_y + (a.ox + x - a.px)];
+            const int cx = x >> 1, cy = y >> 1;
+            if (cy >= a.cpy && cy < a.cpy + a.cph && cx >= a.cpx && cx < a.cpx + a.cpw) {
+                const size_t o = size_t((a.oy >> 1) + cy - a.cpy) * a.src_stride_c + ((a.ox >> 1) + cx - a.cpx);
+                U = sp[1][o]; V = sp[2][o];
+            }
+            tts::rgb_pixel(a.coef, Y, U, V, r, g, b);
+        } else if (in_luma) {
+            const int sx = a.ox + x - a.px, sy = a.oy + y - a.py;
+            const int Y = sp[0][size_t(sy) * a.src_stride_y + sx];
+            const int U = sp[1][size_t(sy >> 1) * a.src_stride_c + (sx >> 1)];
+            const int V = sp[2][size_t(sy >> 1) * a.src_stride_c + (sx >> 1)];
+            tts::rgb_pixel(a.coef, Y, U, V, r, g, b);
+        }
+        rgb_store_pixel(px + i * a.bpp, a.bpp, a.swap, r, g, b);
+    }
+    uint8_t *d = dp + size_t(y) * a.dst_stride + size_t(x0) * a.bpp;
+    const int nb = n * a.bpp;
+    if (n == 4 && (reinterpret_cast<uintptr_t>(d) & 3) == 0) {
+        uint32_t w[4];
+        for (int i = 0; i < 4; ++i) w[i] = uint32_t(px[4 * i]) | uint32_t(px[4 * i + 1]) << 8 | uint32_t(px[4 * i + 2]) << 16 | uint32_t(px[4 * i + 3]) << 24;
+        for (int i = 0; i < nb / 4; ++i) reinterpret_cast<uint32_t *>(d)[i] = w[i];
+    } else {
+        for (int i = 0; i < nb; ++i) d[i] = px[i];
+    }
+}
+
+// ---- any tap counts: one lane per output pixel --------------------------------------------------------
+struct RgbGenericArgs {
+    RgbFrameArgs f;
+    const int32_t *lhpos, *lvpos, *chpos, *cvpos;     // luma / chroma, horizontal / vertical: first tap
+    const int16_t *lhtaps, *lvtaps, *chtaps, *cvtaps;
+    int32_t lht, lvt, cht, cvt;                        // taps per sample
+    // two_stage: the chain's scale wrote yuv420p (a `format=yuv420p` pins its output) and a conversion pass
+    // follows at the end.  Same kernel, other arithmetic: every plane is scaled as yuv420p scales it (chroma
+    // to ceil(w / 2) x ceil(h / 2)), clipped to 8 bits, padded with the yuv fill on the chroma grid, and the
+    // finished canvas goes through the unscaled converter (chroma sample x >> 1, y >> 1).
+    int32_t two_stage;
+    int32_t cox, coy;                                  // two_stage: origin of the chroma picture rectangle (f.cp*) in the scaled chroma plane
+};
+
+__device__ __forceinline__ int rgb_hv(const uint8_t *plane, int stride, const int32_t *hpos, const int16_t *htaps, int ht,
+                                      const int32_t *vpos, const int16_t *vtaps, int vt, int vx, int vy)
+{
+    const int hp = hpos[vx], vp = vpos[vy];
+    const int16_t *hc = htaps + size_t(vx) * ht, *vc = vtaps + size_t(vy) * vt;
+    int val = 1 << 18;
+    for (int j = 0; j < vt; ++j) {
+        const uint8_t *row = plane + size_t(vp + j) * size_t(stride) + hp;
+        int acc = 0;
+        for (int k = 0; k < ht; ++k) acc += int(row[k]) * int(hc[k]);
+        acc >>= 7;
+        acc = acc < 32767 ? acc : 32767;
+        val += acc * int(vc[j]);
+    }
+    return val >> 19;
+}
+
+__global__ __launch_bounds__(kBlock) void rgb_generic_kernel(const RgbGenericArgs a)
+{
+    const RgbFrameArgs &f = a.f;
+    const int x = int(blockIdx.x) * 64 + int(threadIdx.x & 63);
+    const int y = int(blockIdx.y) * 4 + int(threadIdx.x >> 6);
+    if (x >= f.canvas_w || y >= f.canvas_h) return;
+    const uint8_t *sp[3];
+    uint8_t *dp;
+    rgb_frame_bases(f, f.frame0 + int(blockIdx.z), sp, dp);
+    int r = f.border[0], g = f.border[1], b = f.border[2];
+    if (a.two_stage) {
+        auto clip8 = [](int v) { return v < 0 ? 0 : v > 255 ? 255 : v; };
+        int Y = f.fill[0], U = f.fill[1], V = f.fill[2];
+        if (y >= f.py && y < f.py + f.ph && x >= f.px && x < f.px + f.pw)
+            Y = clip8(rgb_hv(sp[0], f.src_stride_y, a.lhpos, a.lhtaps, a.lht, a.lvpos, a.lvtaps, a.lvt, f.ox + x - f.px, f.oy + y - f.py));
+        const int cx = x >> 1, cy = y >> 1;
+        if (cy >= f.cpy && cy < f.cpy + f.cph && cx >= f.cpx && cx < f.cpx + f.cpw) {
+            U = clip8(rgb_hv(sp[1], f.src_stride_c, a.chpos, a.chtaps, a.cht, a.cvpos, a.cvtaps, a.cvt, a.cox + cx - f.cpx, a.coy + cy - f.cpy));
+            V = clip8(rgb_hv(sp[2], f.src_stride_c, a.chpos, a.chtaps, a.cht, a.cvpos, a.cvtaps, a.cvt, a.cox + cx - f.cpx, a.coy + cy - f.cpy));
+        }
+        tts::rgb_pixel(f.coef, Y, U, V, r, g, b);
+    } else if (y >= f.py && y < f.py + f.ph && x >= f.px && x < f.px + f.pw) {
+        const int vx = f.ox + x - f.px, vy = f.oy + y - f.py;
+        const int Y = rgb_hv(sp[0], f.src_stride_y, a.lhpos, a.lhtaps, a.lht, a.lvpos, a.lvtaps, a.lvt, vx, vy);
+        const int U = rgb_hv(sp[1], f.src_stride_c, a.chpos, a.chtaps, a.cht, a.cvpos, a.cvtaps, a.cvt, vx >> 1, vy);
+        const int V = rgb_hv(sp[2], f.src_stride_c, a.chpos, a.chtaps, a.cht, a.cvpos, a.cvtaps, a.cvt, vx >> 1, vy);
+        tts::rgb_pixel(f.coef, Y, U, V, r, g, b);
+    }
+    rgb_store_pixel(dp + size_t(y) * f.dst_stride + size_t(x) * f.bpp, f.bpp, f.swap, r, g, b);
+}
+
+template <class T>
+bool upload_vec(T *&dptr, const std::vector<T> &host)
+{
+    if (hipMalloc(reinterpret_cast<void **>(&dptr), std::max<size_t>(host.size(), 1) * sizeof(T)) != hipSuccess) return false;
+    return hipMemcpy(dptr, host.data(), host.size() * sizeof(T), hipMemcpyHostToDevice) == hipSuccess;
+}
+
+template <class... P, class... A>
+int launch_rgb(const char *what, void (*fn)(P...), dim3 grid, dim3 block, size_t lds, hipStream_t st, A &&...args)
+{
+    std::tuple<P...> held(std::forward<A>(args)...);
+    void *ptrs[sizeof...(P)];
+    size_t i = 0;
+    std::apply([&](auto &...v) { ((ptrs[i++] = const_cast<void *>(static_cast<const void *>(&v))), ...); }, held);
+    const hipError_t e = hipLaunchKernel(reinterpret_cast<const void *>(fn), grid, block, ptrs, lds, st);
+    if (e == hipSuccess) return TTS_OK;
+    tts::set_last_error(std::string(what) + ": " + hipGetErrorString(e));
+    return TTS_ERR_PROCESSING_FAILED;
+}
+
+}  // namespace
+
+namespace tts {
+
+struct RgbPlan {
+    tts_geom g{};
+    int n_cus = 256;
+    int bpp = 3, swap = 0;
+    enum Mode { kUnscaled, kGeneric } mode = kGeneric;
+    bool two_stage = false;            // kGeneric: yuv420p scale, then the unscaled converter over the finished canvas
+    int cpx = 0, cpy = 0, cpw = 0, cph = 0, cox = 0, coy = 0;
+    AxisFilter lh, lv, ch, cv;
+    int32_t *d_pos[4] = {nullptr, nullptr, nullptr, nullptr};      // lh, lv, ch, cv
+    int16_t *d_taps[4] = {nullptr, nullptr, nullptr, nullptr};
+    int px = 0, py = 0, pw = 0, ph = 0, ox = 0, oy = 0;
+    int border[3] = {0, 0, 0};
+    RgbCoef coef{};
+    char name[96] = "";
+};
+
+int rgb_plan_create(const tts_geom &g, int n_cus, RgbPlan **out)
+{
+    *out = nullptr;
+    if (g.out_fmt < TTS_FMT_RGB24 || g.out_fmt > TTS_FMT_BGRA || (g.rgb_stage != TTS_RGB_AT_SCALE && g.rgb_stage != TTS_RGB_AT_END)) {
+        set_last_error("not a packed-RGB geometry");
+        return TTS_ERR_INVALID_INPUT;
+    }
+    RgbPlan *p = new (std::nothrow) RgbPlan();
+    if (!p) return TTS_ERR_INITIALIZATION_FAILED;
+    p->g = g; p->n_cus = n_cus;
+    p->bpp = g.out_fmt >= TTS_FMT_RGBA ? 4 : 3;
+    p->swap = g.out_fmt == TTS_FMT_BGR24 || g.out_fmt == TTS_FMT_BGRA;
+    p->coef = rgb_coef();
+    p->px = g.do_pad ? g.pad_x : 0; p->py = g.do_pad ? g.pad_y : 0;
+    p->pw = g.crop_w; p->ph = g.crop_h; p->ox = g.crop_x; p->oy = g.crop_y;
+
+    // the swscale context that writes the RGB: source size, destination size
+    int ctx_sw, ctx_sh, ctx_dw, ctx_dh;
+    if (g.rgb_stage == TTS_RGB_AT_SCALE) {
+        ctx_sw = g.pre_w; ctx_sh = g.pre_h; ctx_dw = g.sc_w; ctx_dh = g.sc_h;
+        p->border[0] = (g.fill_rgb >> 16) & 255; p->border[1] = (g.fill_rgb >> 8) & 255; p->border[2] = g.fill_rgb & 255;
+    } else {
+        // conversion pass at the end of a chain without scale: its source is the finished yuv420p canvas
+        // (crop = an offset into the source; pad = fill colour around it, on the chroma grid; an odd picture
+        // width loses its last column to the fill, see vf_pad in the oracle)
+        ctx_sw = ctx_dw = g.out_w; ctx_sh = ctx_dh = g.out_h;
+        if (g.do_pad) p->pw = g.crop_w & ~1;
+        p->cpx = p->px >> 1; p->cpy = p->py >> 1; p->cpw = (p->pw + 1) >> 1; p->cph = (g.crop_h + 1) >> 1;
+        rgb_pixel(p->coef, g.fill_y, g.fill_u, g.fill_v, p->border[0], p->border[1], p->border[2]);
+    }
+    int rc = TTS_OK;
+    auto cs = [](int v) { return (v + 1) >> 1; };
+    if (g.rgb_stage == TTS_RGB_AT_END && g.do_scale) {
+        // scale (+ crop, pad) on yuv420p first, then the conversion pass over the finished canvas.  The
+        // unscaled converter is a function of one pixel's Y and of chroma sample (x >> 1, y >> 1), so both
+        // passes fit one kernel; a canvas of odd height would take swscale's generic path instead, which
+        // interpolates the SCALED chroma rows: that needs the intermediate frame in memory.
+        if ((g.out_w | g.out_h) & 1) {
+            set_last_error("yuv420p scale followed by an RGB conversion pass over a canvas of odd width or height is not supported");
+            rc = TTS_ERR_UNSUPPORTED;
+        }
+        if (!rc && (!build_axis_filter(g.pre_w, g.sc_w, 1 << 14, g.alg, p->lh) || !build_axis_filter(g.pre_h, g.sc_h, 1 << 12, g.alg, p->lv) ||
+                    !build_axis_filter(cs(g.pre_w), cs(g.sc_w), 1 << 14, g.alg, p->ch) || !build_axis_filter(cs(g.pre_h), cs(g.sc_h), 1 << 12, g.alg, p->cv))) {
+            set_last_error("filter tables"); rc = TTS_ERR_INVALID_INPUT;
+        }
+        p->two_stage = true;
+        p->cox = g.crop_x >> 1; p->coy = g.crop_y >> 1;
+        const AxisFilter *f[4] = {&p->lh, &p->lv, &p->ch, &p->cv};
+        for (int i = 0; i < 4 && !rc; ++i)
+            if (!upload_vec(p->d_pos[i], f[i]->pos) || !upload_vec(p->d_taps[i], f[i]->taps)) { set_last_error("table upload failed (hipMalloc / hipMemcpy)"); rc = TTS_ERR_INITIALIZATION_FAILED; }
+        std::snprintf(p->name, sizeof p->name, "rgb_generic<%d,%d,%d,%d>+unscaled", p->lh.size, p->lv.size, p->ch.size, p->cv.size);
+    } else if (ctx_sw == ctx_dw && ctx_sh == ctx_dh && !(ctx_dh & 1)) {
+        p->mode = RgbPlan::kUnscaled;
+        if (ctx_dw & 1) { set_last_error("swscale's unscaled yuv420p -> RGB converter never writes the last column of an odd width: not supported"); rc = TTS_ERR_UNSUPPORTED; }
+        std::snprintf(p->name, sizeof p->name, "rgb_unscaled");
+    } else {
+        if (g.rgb_stage == TTS_RGB_AT_END && (g.do_pad || g.crop_w != g.sc_w || g.crop_h != g.sc_h)) {
+            // (cannot happen: crop and pad make the height even, which selects the unscaled converter)
+            set_last_error("conversion pass over a cropped or padded canvas of odd height"); rc = TTS_ERR_UNSUPPORTED;
+        }
+        const int csw = (ctx_sw + 1) >> 1, csh = (ctx_sh + 1) >> 1, cdw = (ctx_dw + 1) >> 1;
+        if (!rc && (!build_axis_filter(ctx_sw, ctx_dw, 1 << 14, g.alg, p->lh) || !build_axis_filter(ctx_sh, ctx_dh, 1 << 12, g.alg, p->lv) ||
+                    !build_axis_filter(csw, cdw, 1 << 14, g.alg, p->ch) || !build_axis_filter(csh, ctx_dh, 1 << 12, g.alg, p->cv))) {
+            set_last_error("filter tables"); rc = TTS_ERR_INVALID_INPUT;
+        }
+        // vscale.c packed_vscale(): 1- and 2-tap vertical filters go to yuv2packed1 / yuv2packed2, whose
+        // arithmetic differs (no 19-bit sum); only yuv2packedX is restated
+        if (!rc && p->lv.size <= 2 && p->cv.size <= 2) {
+            set_last_error("vertical filters of 1-2 taps on both luma and chroma (swscale's yuv2packed1/2 writers) are not supported for RGB output");
+            rc = TTS_ERR_UNSUPPORTED;
+        }
+        const AxisFilter *f[4] = {&p->lh, &p->lv, &p->ch, &p->cv};
+        for (int i = 0; i < 4 && !rc; ++i)
+            if (!upload_vec(p->d_pos[i], f[i]->pos) || !upload_vec(p->d_taps[i], f[i]->taps)) { set_last_error("table upload failed (hipMalloc / hipMemcpy)"); rc = TTS_ERR_INITIALIZATION_FAILED; }
+        std::snprintf(p->name, sizeof p->name, "rgb_generic<%d,%d,%d,%d>", p->lh.size, p->lv.size, p->ch.size, p->cv.size);
+    }
+    if (rc) { rgb_plan_destroy(p); return rc; }
+    *out = p;
+    return TTS_OK;
+}
+
+void rgb_plan_destroy(RgbPlan *p)
+{
+    if (!p) return;
+    for (int i = 0; i < 4; ++i) { (void)hipFree(p->d_pos[i]); (void)hipFree(p->d_taps[i]); }
+    delete p;
+}
+
+const char *rgb_plan_kernel_name(const RgbPlan *p) { return p ? p->name : ""; }
+
+int rgb_launch(const RgbPlan *p, const uint8_t *src, uint8_t *dst, int n, const int src_stride[2], int dst_stride,
+               uint64_t src_span, uint64_t dst_span, const FrameAddr &addr, hipStream_t st)
+{
+    (void)src_span; (void)dst_span;
+    RgbFrameArgs f{};
+    f.src = src; f.dst = dst;
+    f.canvas_w = p->g.out_w; f.canvas_h = p->g.out_h;
+    f.px = p->px; f.py = p->py; f.pw = p->pw; f.ph = p->ph; f.ox = p->ox; f.oy = p->oy;
+    f.src_stride_y = src_stride[0]; f.src_stride_c = src_stride[1]; f.dst_stride = dst_stride;
+    f.bpp = p->bpp; f.swap = p->swap;
+    for (int i = 0; i < 3; ++i) f.border[i] = p->border[i];
+    f.coef = p->coef; f.addr = addr;
+    f.yuv_pad = p->g.rgb_stage == TTS_RGB_AT_END;
+    f.cpx = p->cpx; f.cpy = p->cpy; f.cpw = p->cpw; f.cph = p->cph;
+    f.fill[0] = p->g.fill_y; f.fill[1] = p->g.fill_u; f.fill[2] = p->g.fill_v;
+    int rc = TTS_OK;
+    for (int f0 = 0; f0 < n && !rc; f0 += 65535) {          // grid.z
+        const int nf = std::min(65535, n - f0);
+        f.frame0 = f0;
+        if (p->mode == RgbPlan::kUnscaled) {
+            rc = launch_rgb("rgb_unscaled_kernel", rgb_unscaled_kernel, dim3((f.canvas_w + 255) / 256, (f.canvas_h + 3) / 4, nf), dim3(kBlock), 0, st, f);
+        } else {
+            RgbGenericArgs a{};
+            a.f = f;
+            a.lhpos = p->d_pos[0]; a.lvpos = p->d_pos[1]; a.chpos = p->d_pos[2]; a.cvpos = p->d_pos[3];
+            a.lhtaps = p->d_taps[0]; a.lvtaps = p->d_taps[1]; a.chtaps = p->d_taps[2]; a.cvtaps = p->d_taps[3];
+            a.lht = p->lh.size; a.lvt = p->lv.size; a.cht = p->ch.size; a.cvt = p->cv.size;
+            a.two_stage = p->two_stage;
+            a.cox = p->cox; a.coy = p->coy;
+            rc = launch_rgb("rgb_generic_kernel", rgb_generic_kernel, dim3((f.canvas_w + 63) / 64, (f.canvas_h + 3) / 4, nf), dim3(kBlock), 0, st, a);
+        }
+    }
+    return rc;
+}
+
+}  // namespace tts

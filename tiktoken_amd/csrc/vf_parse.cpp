@@ -199,6 +199,23 @@ void rgb_to_yuv(int r, int g, int b, tts_geom &o)
                  fix(0.08131 * 224.0 / 255.0) * b + 511) >> 10) + 128;
 }
 
+int parse_pix_fmt(const std::string &f)
+{
+    if (f == "yuv420p" || f == "yuvj420p") return TTS_FMT_YUV420P;
+    if (f == "rgb24") return TTS_FMT_RGB24;
+    if (f == "bgr24") return TTS_FMT_BGR24;
+    if (f == "rgba") return TTS_FMT_RGBA;
+    if (f == "bgra") return TTS_FMT_BGRA;
+    return -1;
+}
+
+std::string format_arg(const std::string &args)
+{
+    std::string f = trim(args);
+    if (f.rfind("pix_fmts=", 0) == 0) f = f.substr(9);
+    return f;
+}
+
 bool parse_color(std::string c, tts_geom &o)
 {
     size_t at = c.find('@');
@@ -218,6 +235,7 @@ bool parse_color(std::string c, tts_geom &o)
         rgb = unsigned(std::stoul(c, nullptr, 16));
     }
     rgb_to_yuv((rgb >> 16) & 255, (rgb >> 8) & 255, rgb & 255, o);
+    o.fill_rgb = int32_t(rgb);
     return true;
 }
 
@@ -253,6 +271,36 @@ int parse_vf(const char *vf, int iw, int ih, tts_geom &g, std::string &err)
     int cw = iw, ch = ih;                   // size of the picture at the current point of the chain
     int cx = 0, cy = 0;                     // accumulated crop origin at the current stage
 
+    // A packed-RGB format ending the chain: libavfilter's format negotiation makes the chain's `scale` (the
+    // one filter that can change the pixel format) write it, unless a `format=yuv...` between the two pins
+    // that link to yuv, or the chain has no scale; then a conversion pass of its own is inserted in front of
+    // the `format` filter, i.e. at the very end.  First pass over the chain: find that out, because every
+    // filter between the conversion and the end then works on RGB pixels (no chroma grid to round to).
+    try {
+        bool seen_scale = false, yuv_pinned = false, full_range = false;
+        for (const std::string &raw : split(vf, ',')) {
+            const std::string f = trim(raw);
+            if (f.empty()) continue;
+            const size_t eq = f.find('=');
+            const std::string name = trim(f.substr(0, eq));
+            if (g.out_fmt != TTS_FMT_YUV420P && name != "setsar") { err = "an RGB format must end the chain"; return TTS_ERR_UNSUPPORTED; }
+            if (name == "scale") { seen_scale = true; yuv_pinned = false; }
+            if (name != "format") continue;
+            const std::string pf = format_arg(eq == std::string::npos ? "" : f.substr(eq + 1));
+            const int fmt = parse_pix_fmt(pf);
+            if (fmt < 0) { err = "format: only yuv420p, yuvj420p, rgb24, bgr24, rgba, bgra are supported"; return TTS_ERR_UNSUPPORTED; }
+            if (fmt == TTS_FMT_YUV420P) { yuv_pinned = true; full_range = pf == "yuvj420p"; continue; }
+            if (full_range) { err = "RGB from a full-range (yuvj420p) link is not supported"; return TTS_ERR_UNSUPPORTED; }
+            g.out_fmt = fmt;
+            g.rgb_stage = seen_scale && !yuv_pinned ? TTS_RGB_AT_SCALE : TTS_RGB_AT_END;
+        }
+    } catch (const std::exception &e) {
+        err = e.what();
+        return TTS_ERR_INVALID_FORMAT;
+    }
+    // chroma subsampling of the link a filter sits on: 2 on yuv420p, 1 once the pixels are RGB
+    auto grid = [&]() { return g.rgb_stage == TTS_RGB_AT_SCALE && stage != kBeforeScale ? 1 : 2; };
+
     try {
         for (const std::string &raw : split(vf, ',')) {
             const std::string f = trim(raw);
@@ -263,12 +311,10 @@ int parse_vf(const char *vf, int iw, int ih, tts_geom &g, std::string &err)
 
             if (name == "format" || name == "setsar") {
                 if (name == "format") {
-                    std::string f = trim(args);
-                    if (f.rfind("pix_fmts=", 0) == 0) f = f.substr(9);
+                    const std::string pf = format_arg(args);
                     // yuvj420p = the same planes in full range: the range step of a second, unscaled swscale pass
-                    if (f == "yuvj420p") g.out_range = TTS_RANGE_TO_FULL;
-                    else if (f == "yuv420p") g.out_range = TTS_RANGE_KEEP;
-                    else { err = "only format=yuv420p / yuvj420p is supported"; return TTS_ERR_UNSUPPORTED; }
+                    if (pf == "yuvj420p") g.out_range = TTS_RANGE_TO_FULL;
+                    else if (pf == "yuv420p") g.out_range = TTS_RANGE_KEEP;
                 }
                 continue;
             }
@@ -325,8 +371,9 @@ int parse_vf(const char *vf, int iw, int ih, tts_geom &g, std::string &err)
                 Options o = parse_options(args, {"w", "h", "x", "y", "keep_aspect", "exact"},
                     {{"out_w", "w"}, {"out_h", "h"}});
                 if (o.get("exact", "0") != "0" || o.get("keep_aspect", "0") != "0") { err = "crop: exact/keep_aspect unsupported"; return TTS_ERR_UNSUPPORTED; }
+                const int sub = grid();                 // vf_crop rounds sizes and offsets to the link's chroma grid
                 Vars v = {{"in_w", cw}, {"iw", cw}, {"in_h", ch}, {"ih", ch}, {"a", double(cw) / ch},
-                          {"sar", 1}, {"dar", double(cw) / ch}, {"hsub", 2}, {"vsub", 2}, {"n", 0}, {"t", 0},
+                          {"sar", 1}, {"dar", double(cw) / ch}, {"hsub", sub}, {"vsub", sub}, {"n", 0}, {"t", 0},
                           {"x", 0}, {"y", 0}};
                 v["out_w"] = v["ow"] = cw; v["out_h"] = v["oh"] = ch;
                 int w = int(eval(o.get("w", "iw"), v));
@@ -334,7 +381,7 @@ int parse_vf(const char *vf, int iw, int ih, tts_geom &g, std::string &err)
                 int h = int(eval(o.get("h", "ih"), v));
                 v["out_h"] = v["oh"] = h;
                 w = int(eval(o.get("w", "iw"), v));
-                w &= ~1; h &= ~1;
+                w &= ~(sub - 1); h &= ~(sub - 1);
                 if (w <= 0 || h <= 0 || w > cw || h > ch) { err = "crop: invalid too big or non positive size"; return TTS_ERR_INVALID_INPUT; }
                 v["out_w"] = v["ow"] = w; v["out_h"] = v["oh"] = h;
                 double xv = 0, yv = 0;
@@ -344,7 +391,7 @@ int parse_vf(const char *vf, int iw, int ih, tts_geom &g, std::string &err)
                 if (hy) yv = eval(o.get("y", "0"), v);
                 v["y"] = hy ? yv : (ch - h) / 2.0;
                 if (hx) xv = eval(o.get("x", "0"), v);   // x may be written in terms of y
-                const int x = crop_origin(cw, w, xv, hx), y = crop_origin(ch, h, yv, hy);
+                const int x = crop_origin(cw, w, xv, hx, sub), y = crop_origin(ch, h, yv, hy, sub);
                 cx += x; cy += y; cw = w; ch = h;
                 if (stage == kBeforeScale) { g.pre_x = cx; g.pre_y = cy; g.pre_w = cw; g.pre_h = ch; }
             } else if (name == "pad") {
@@ -374,7 +421,7 @@ int parse_vf(const char *vf, int iw, int ih, tts_geom &g, std::string &err)
                 if (w < cw || h < ch) { err = "pad: padded size smaller than input"; return TTS_ERR_INVALID_INPUT; }
                 if (x < 0 || x + cw > w) x = (w - cw) / 2;
                 if (y < 0 || y + ch > h) y = (h - ch) / 2;
-                w &= ~1; h &= ~1; x &= ~1; y &= ~1;                 // round down to the chroma grid
+                if (grid() == 2) { w &= ~1; h &= ~1; x &= ~1; y &= ~1; }   // round down to the chroma grid (none on RGB)
                 if (!parse_color(o.get("color", "black"), g)) { err = "pad: unsupported colour"; return TTS_ERR_INVALID_FORMAT; }
                 if (stage == kBeforeScale) { g.pre_x = cx; g.pre_y = cy; g.pre_w = cw; g.pre_h = ch; g.sc_w = cw; g.sc_h = ch; cx = cy = 0; }
                 g.crop_x = cx; g.crop_y = cy; g.crop_w = cw; g.crop_h = ch;

@@ -100,11 +100,17 @@ class Plan:
 
     @property
     def in_bytes(self):
-        return frame_bytes(*self.in_size)
+        return int(_lib.lib().tts_plan_frame_bytes(self._h, 0))
 
     @property
     def out_bytes(self):
-        return frame_bytes(*self.out_size)
+        """Bytes of one output frame: packed I420, or out_w * out_h * bpp when the chain ends in packed RGB."""
+        return int(_lib.lib().tts_plan_frame_bytes(self._h, 1))
+
+    @property
+    def out_bpp(self):
+        """Bytes per pixel of a packed-RGB output (0 for planar yuv420p)."""
+        return {0: 0, 1: 3, 2: 3, 3: 4, 4: 4}[self.geom.out_fmt]
 
     def kernel_kind(self, plane_class):
         return _lib.lib().tts_plan_kernel_kind(self._h, plane_class)
@@ -122,19 +128,34 @@ class Plan:
                                          coef.ctypes.data_as(ctypes.c_void_p), pos.ctypes.data_as(ctypes.c_void_p)))
         return coef, pos
 
+    @property
+    def device(self):
+        """Index of the GPU the plan's tables live on (the device that was current when it was made)."""
+        return _lib.lib().tts_plan_device(self._h)
+
+    def _check_tensor(self, t, what):
+        """A frame buffer must be a contiguous uint8 tensor on the plan's own GPU: the kernels are launched
+        on that tensor's stream with the plan's tables, so a tensor on another device would mean a launch
+        with foreign pointers instead of a clean INVALID_INPUT."""
+        import torch
+        if not (t.is_cuda and t.dtype == torch.uint8 and t.is_contiguous()):
+            raise TtsError(-1, "%s must be a contiguous uint8 CUDA tensor" % what)
+        if t.device.index != self.device:
+            raise TtsError(-1, "%s is on cuda:%d, the plan was made on cuda:%d" % (what, t.device.index, self.device))
+
     def run_batch(self, src, dst=None, stream=None):
         """src: uint8 cuda tensor [n, in_bytes] (or flat); returns dst [n, out_bytes].
         Asynchronous on `stream` (default: torch's current stream)."""
         import torch
-        if not (src.is_cuda and src.dtype == torch.uint8 and src.is_contiguous()):
-            raise TtsError(-1, "src must be a contiguous uint8 CUDA tensor")
+        self._check_tensor(src, "src")
         if src.numel() % self.in_bytes:
             raise TtsError(-1, "src size is not a multiple of the packed frame size")
         n = src.numel() // self.in_bytes
         if dst is None:
             dst = torch.empty((n, self.out_bytes), dtype=torch.uint8, device=src.device)
-        if not (dst.is_cuda and dst.dtype == torch.uint8 and dst.is_contiguous() and dst.numel() == n * self.out_bytes):
-            raise TtsError(-1, "dst must be a contiguous uint8 CUDA tensor of n*out_bytes")
+        self._check_tensor(dst, "dst")
+        if dst.numel() != n * self.out_bytes:
+            raise TtsError(-1, "dst must hold n*out_bytes bytes")
         if stream is None:
             stream = torch.cuda.current_stream(src.device).cuda_stream
         check(_lib.lib().tts_run_batch(self._h, src.data_ptr(), self.in_bytes, dst.data_ptr(), self.out_bytes, n,
@@ -144,6 +165,8 @@ class Plan:
     def strided_bytes(self, which, stride_y, stride_c):
         """Bytes of one frame (which = "in" / "out") whose rows lie stride_y / stride_c bytes apart."""
         w, h = self.in_size if which == "in" else self.out_size
+        if which != "in" and self.geom.out_fmt:
+            return stride_y * h                      # packed RGB: one plane
         return stride_y * h + 2 * stride_c * ((h + 1) // 2)
 
     def run_batch_strided(self, src, src_strides, dst, dst_strides, n, stream=None):
@@ -151,6 +174,8 @@ class Plan:
         strided_bytes(...) each; *_strides = (luma stride, chroma stride)."""
         import torch
         sp, dp = self.strided_bytes("in", *src_strides), self.strided_bytes("out", *dst_strides)
+        self._check_tensor(src, "src")
+        self._check_tensor(dst, "dst")
         if src.numel() < n * sp or dst.numel() < n * dp:
             raise TtsError(-1, "buffers are smaller than n strided frames")
         if stream is None:
@@ -162,14 +187,16 @@ class Plan:
     def run_batch_order(self, src, order, dst=None, stream=None):
         """Like run_batch, but output frame j comes from source frame order[j] (trimmed / looped clips)."""
         import torch
-        if not (src.is_cuda and src.dtype == torch.uint8 and src.is_contiguous()) or src.numel() % self.in_bytes:
-            raise TtsError(-1, "src must be a contiguous uint8 CUDA tensor of whole frames")
+        self._check_tensor(src, "src")
+        if src.numel() % self.in_bytes:
+            raise TtsError(-1, "src must hold whole frames")
         order = np.ascontiguousarray(order, dtype=np.int32)
         n_src, n = src.numel() // self.in_bytes, int(order.size)
         if dst is None:
             dst = torch.empty((n, self.out_bytes), dtype=torch.uint8, device=src.device)
-        if not (dst.is_cuda and dst.dtype == torch.uint8 and dst.is_contiguous() and dst.numel() == n * self.out_bytes):
-            raise TtsError(-1, "dst must be a contiguous uint8 CUDA tensor of n*out_bytes")
+        self._check_tensor(dst, "dst")
+        if dst.numel() != n * self.out_bytes:
+            raise TtsError(-1, "dst must hold n*out_bytes bytes")
         if stream is None:
             stream = torch.cuda.current_stream(src.device).cuda_stream
         check(_lib.lib().tts_run_batch_order(self._h, src.data_ptr(), self.in_bytes, n_src, dst.data_ptr(), self.out_bytes,
@@ -190,7 +217,7 @@ class Plan:
             D[i].width, D[i].height = self.out_size
         if stream is None:
             import torch
-            stream = torch.cuda.current_stream().cuda_stream
+            stream = torch.cuda.current_stream(self.device).cuda_stream
         check(_lib.lib().tts_run(self._h, S, D, n, ctypes.c_void_p(stream)))
 
     def run_host(self, src, out=None):
