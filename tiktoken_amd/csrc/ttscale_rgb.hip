@@ -27,6 +27,7 @@
 
 #include <algorithm>
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <new>
 #include <tuple>
@@ -221,6 +222,198 @@ __global__ __launch_bounds__(kBlock) void rgb_generic_kernel(const RgbGenericArg
     rgb_store_pixel(dp + size_t(y) * f.dst_stride + size_t(x) * f.bpp, f.bpp, f.swap, r, g, b);
 }
 
+
+// ---- every axis <= 4 taps (the portrait upscales): a lane owns 8 adjacent output pixels --------------
+// Same walk as the planar strip kernels (ttscale_kernels.h): a lane takes 8 adjacent output pixels of one
+// frame -- 8 luma columns and the 4 chroma columns under them, for U and for V -- and goes down a segment of
+// output rows.  Source rows arrive as grouped 8-byte windows (one per 4 columns: 2 luma, 1 U, 1 V per lane)
+// through plain buffer loads issued one source row ahead; the 15-bit horizontal results sit in three
+// register rings of 4 rows (shift registers: the newest row enters at the top, so the vertical taps keep
+// their natural order).  Luma and chroma advance at different rates -- chroma has half the source rows but
+// is interpolated to EVERY output row -- so the host tabulates, per output row, how many new luma and chroma
+// source rows it needs first.  Then 16 two-instruction vertical sums, the yuv -> RGB closed form (per
+// chroma sample: three products shared by its two pixels; per pixel and channel one add) and 24 (32) bytes
+// stored per lane: a wave writes 1.5 (2) KiB of one RGB row, contiguous.  No yuv intermediate exists.
+struct RgbStripArgs {
+    uint32_t hoffl, sell, coefl;       // luma tables (dword offsets into tab): [strips][2], [strips][8][2], [strips][8][2]
+    uint32_t hoffc, selc, coefc;       // chroma: [strips], [strips][4][2], [strips][4][2]
+    uint32_t vrow;                     // [ph][6]: new luma rows, new chroma rows, luma taps (2 dwords), chroma taps (2 dwords)
+    uint32_t seginfo;                  // [nseg][2]: first luma / chroma source row of the segment's ring fill (may be < 0: clamped, zero taps)
+    int32_t strips, n_items, nseg, seg_rows, ph, pw;
+    int32_t src_h_l, src_h_c;          // rows of the (pre-cropped) source planes
+    int32_t src_stride_y, src_stride_c, dst_stride;
+    int32_t swap;
+    uint64_t src_span, dst_span;
+    RgbCoef coef;
+    FrameAddr addr;
+};
+
+__device__ __forceinline__ uint32_t sat_pk_u8(uint32_t packed_i16)
+{
+    uint32_t r;
+    asm("v_sat_pk_u8_i16 %0, %1" : "=v"(r) : "v"(packed_i16));
+    return r;
+}
+// two 32-bit sums -> their high halves (sum >> 16) clipped to bytes, in bits 0..15
+__device__ __forceinline__ uint32_t hi2_u8(int a, int b)
+{
+    return sat_pk_u8(__builtin_amdgcn_perm(uint32_t(b), uint32_t(a), 0x07060302));
+}
+__device__ __forceinline__ int clip255(int v) { return v < 0 ? 0 : v > 255 ? 255 : v; }   // (v_med3_i32)
+
+template <int BPP>
+__global__ __launch_bounds__(kBlock) void rgb_strip_kernel(const uint8_t *__restrict__ src, uint8_t *__restrict__ dst,
+                                                           const uint32_t *__restrict__ tab, const RgbStripArgs a)
+{
+    static_assert(BPP == 3 || BPP == 4, "rgb24 / bgr24 or rgba / bgra");
+    const uint32_t lb = xcd_remap(blockIdx.x, gridDim.x);
+    const int seg = int(lb % uint32_t(a.nseg));
+    const int sb  = int(lb / uint32_t(a.nseg));
+    int g = sb * kBlock + int(threadIdx.x);
+    const bool live = g < a.n_items;
+    if (!live) g = a.n_items - 1;                  // dead lanes (a suffix of the last workgroup) shadow the last live one
+    const int strip = g % a.strips;
+    const int frame = g / a.strips;
+
+    // this wave's bases and the lane's 32-bit offsets from them (see frame_offsets in ttscale_kernels.h)
+    const uint8_t *wsrc = src;
+    uint8_t *wdst = dst;
+    uint32_t so[3], doff, src_rec, dst_rec;
+    if (a.addr.use_table) {
+#pragma unroll
+        for (int k = 0; k < 3; ++k) so[k] = a.addr.src_tab[k][frame];
+        doff = a.addr.dst_tab[0][frame];
+        src_rec = uint32_t(a.src_span); dst_rec = uint32_t(a.dst_span);
+    } else {
+        const uint32_t f0 = uni(uint32_t(frame));
+        const uint64_t sbase = uint64_t(f0) * a.addr.src_pitch, dbase = uint64_t(f0) * a.addr.dst_pitch;
+        wsrc += sbase; wdst += dbase;
+        src_rec = a.src_span > sbase ? uint32_t(min(a.src_span - sbase, uint64_t(kMaxSpan))) : 0u;
+        dst_rec = a.dst_span > dbase ? uint32_t(min(a.dst_span - dbase, uint64_t(kMaxSpan))) : 0u;
+#pragma unroll
+        for (int k = 0; k < 3; ++k) so[k] = (uint32_t(frame) - f0) * a.addr.src_pitch + a.addr.src_plane[k];
+        doff = (uint32_t(frame) - f0) * a.addr.dst_pitch;
+    }
+    doff += uint32_t(min(strip * 8, a.pw - 8)) * BPP;        // the last strip is slid left, not cut short
+    if (!live) doff = kDiscard;                               // the descriptor's range check drops these stores
+
+    // per-lane horizontal tables stay in registers for the whole walk
+    uint32_t offl[2], offu, offv, sell[8][2], coefl[8][2], selc[4][2], coefc[4][2];
+    {
+        offl[0] = tab[a.hoffl + strip * 2] + so[0];
+        offl[1] = tab[a.hoffl + strip * 2 + 1] + so[0];
+        const uint32_t oc = tab[a.hoffc + strip];
+        offu = oc + so[1]; offv = oc + so[2];
+#pragma unroll
+        for (int i = 0; i < 8; ++i)
+#pragma unroll
+            for (int k = 0; k < 2; ++k) { sell[i][k] = tab[a.sell + (strip * 8 + i) * 2 + k]; coefl[i][k] = tab[a.coefl + (strip * 8 + i) * 2 + k]; }
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+#pragma unroll
+            for (int k = 0; k < 2; ++k) { selc[i][k] = tab[a.selc + (strip * 4 + i) * 2 + k]; coefc[i][k] = tab[a.coefc + (strip * 4 + i) * 2 + k]; }
+    }
+
+    const __amdgpu_buffer_rsrc_t srs = __builtin_amdgcn_make_buffer_rsrc(const_cast<uint8_t *>(wsrc), 0, src_rec, 0x00020000);
+    const uint64_t dbase64 = reinterpret_cast<uint64_t>(wdst);
+    const u32x4_t drs = {uni(uint32_t(dbase64)), uni(uint32_t(dbase64 >> 32) & 0xffffu), uni(dst_rec), 0x00020000u};
+
+    uint32_t ry[8][2], ru[4][2], rv[4][2];           // rings: rows (oldest, .) (., newest) as int16 pairs
+#pragma unroll
+    for (int i = 0; i < 8; ++i) ry[i][0] = ry[i][1] = 0;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) ru[i][0] = ru[i][1] = rv[i][0] = rv[i][1] = 0;
+
+    int lrow = int(uni(tab[a.seginfo + 2 * seg])), crow = int(uni(tab[a.seginfo + 2 * seg + 1]));
+    const int lmax = a.src_h_l - 1, cmax = a.src_h_c - 1;
+    const int sy = int(uni(uint32_t(a.src_stride_y))), sc = int(uni(uint32_t(a.src_stride_c))), ds = int(uni(uint32_t(a.dst_stride)));
+    u32x2_t wl[2], wu, wv;                           // the next source rows, requested one row ahead
+    {
+        const int lo = min(max(lrow, 0), lmax) * sy, co = min(max(crow, 0), cmax) * sc;
+        wl[0] = __builtin_amdgcn_raw_buffer_load_b64(srs, offl[0], lo, 0);
+        wl[1] = __builtin_amdgcn_raw_buffer_load_b64(srs, offl[1], lo, 0);
+        wu = __builtin_amdgcn_raw_buffer_load_b64(srs, offu, co, 0);
+        wv = __builtin_amdgcn_raw_buffer_load_b64(srs, offv, co, 0);
+    }
+    // the closed form's constants (wave-uniform)
+    const int cy = a.coef.cy, crv = a.coef.crv, cbu = a.coef.cbu, cgu = a.coef.cgu, cgv = a.coef.cgv;
+    const int kr = a.coef.off_r * cy + a.coef.k, kg = a.coef.off_g * cy + a.coef.k, kb = a.coef.off_b * cy + a.coef.k;
+    const bool swap = a.swap != 0;
+
+    const int y0 = seg * a.seg_rows, y1 = min(y0 + a.seg_rows, a.ph);
+    for (int y = y0; y < y1; ++y) {
+        const uint32_t *vr = tab + a.vrow + 6 * y;
+        const int nl = y == y0 ? 4 : int(uni(vr[0])), nc = y == y0 ? 4 : int(uni(vr[1]));
+        for (int n = 0; n < nl; ++n) {                         // wave-uniform
+#pragma unroll
+            for (int i = 0; i < 8; ++i) {
+                const u32x2_t w = wl[i / 4];
+                int acc = dot2(__builtin_amdgcn_perm(w.y, w.x, sell[i][0]), coefl[i][0], 0);
+                acc = dot2(__builtin_amdgcn_perm(w.y, w.x, sell[i][1]), coefl[i][1], acc);
+                const uint32_t t = hfinish(acc);
+                ry[i][0] = __builtin_amdgcn_alignbit(ry[i][1], ry[i][0], 16);
+                ry[i][1] = __builtin_amdgcn_alignbit(t, ry[i][1], 16);
+            }
+            ++lrow;
+            const int lo = min(max(lrow, 0), lmax) * sy;
+            wl[0] = __builtin_amdgcn_raw_buffer_load_b64(srs, offl[0], lo, 0);
+            wl[1] = __builtin_amdgcn_raw_buffer_load_b64(srs, offl[1], lo, 0);
+        }
+        for (int n = 0; n < nc; ++n) {                         // wave-uniform
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                int au = dot2(__builtin_amdgcn_perm(wu.y, wu.x, selc[i][0]), coefc[i][0], 0);
+                au = dot2(__builtin_amdgcn_perm(wu.y, wu.x, selc[i][1]), coefc[i][1], au);
+                int av = dot2(__builtin_amdgcn_perm(wv.y, wv.x, selc[i][0]), coefc[i][0], 0);
+                av = dot2(__builtin_amdgcn_perm(wv.y, wv.x, selc[i][1]), coefc[i][1], av);
+                const uint32_t tu = hfinish(au), tv = hfinish(av);
+                ru[i][0] = __builtin_amdgcn_alignbit(ru[i][1], ru[i][0], 16);
+                ru[i][1] = __builtin_amdgcn_alignbit(tu, ru[i][1], 16);
+                rv[i][0] = __builtin_amdgcn_alignbit(rv[i][1], rv[i][0], 16);
+                rv[i][1] = __builtin_amdgcn_alignbit(tv, rv[i][1], 16);
+            }
+            ++crow;
+            const int co = min(max(crow, 0), cmax) * sc;
+            wu = __builtin_amdgcn_raw_buffer_load_b64(srs, offu, co, 0);
+            wv = __builtin_amdgcn_raw_buffer_load_b64(srs, offv, co, 0);
+        }
+
+        // vertical pass: yuv2rgb_X_c_template's 1 << 18 rounding, >> 19, no clip
+        const uint32_t vl0 = uni(vr[2]), vl1 = uni(vr[3]), vc0 = uni(vr[4]), vc1 = uni(vr[5]);
+        int P[8], CR[4], CG[4], CB[4];
+#pragma unroll
+        for (int i = 0; i < 8; ++i) P[i] = (dot2(ry[i][1], vl1, dot2(ry[i][0], vl0, 1 << 18)) >> 19) * cy;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const int U = clip255(dot2(ru[j][1], vc1, dot2(ru[j][0], vc0, 1 << 18)) >> 19);
+            const int V = clip255(dot2(rv[j][1], vc1, dot2(rv[j][0], vc0, 1 << 18)) >> 19);
+            const int cr = ((V * crv) >> 16) * cy + kr;
+            const int cb = ((U * cbu) >> 16) * cy + kb;
+            CG[j] = (((U * cgu) >> 16) + ((V * cgv) >> 16)) * cy + kg;
+            CR[j] = swap ? cb : cr;                              // (bgr: the first byte of a pixel is B)
+            CB[j] = swap ? cr : cb;
+        }
+        const int yoff = y * ds;
+        if constexpr (BPP == 3) {
+            int v[24];
+#pragma unroll
+            for (int i = 0; i < 8; ++i) { v[3 * i] = P[i] + CR[i / 2]; v[3 * i + 1] = P[i] + CG[i / 2]; v[3 * i + 2] = P[i] + CB[i / 2]; }
+            uint32_t o[6];
+#pragma unroll
+            for (int q = 0; q < 6; ++q) o[q] = hi2_u8(v[4 * q], v[4 * q + 1]) | (hi2_u8(v[4 * q + 2], v[4 * q + 3]) << 16);
+            store_b128(u32x4_t{o[0], o[1], o[2], o[3]}, drs, doff, yoff);
+            store_b64(u32x2_t{o[4], o[5]}, drs, doff + 16u, yoff);
+        } else {
+            uint32_t o[8];
+#pragma unroll
+            for (int i = 0; i < 8; ++i)
+                o[i] = hi2_u8(P[i] + CR[i / 2], P[i] + CG[i / 2]) | (hi2_u8(P[i] + CB[i / 2], 0x7fff0000) << 16);   // alpha 255
+            store_b128(u32x4_t{o[0], o[1], o[2], o[3]}, drs, doff, yoff);
+            store_b128(u32x4_t{o[4], o[5], o[6], o[7]}, drs, doff + 16u, yoff);
+        }
+    }
+}
+
 template <class T>
 bool upload_vec(T *&dptr, const std::vector<T> &host)
 {
@@ -250,6 +443,12 @@ struct RgbPlan {
     int n_cus = 256;
     int bpp = 3, swap = 0;
     enum Mode { kUnscaled, kGeneric } mode = kGeneric;
+    // the fused strip walk (every axis <= 4 taps, no pad, even crop): tables in HBM, one set per segment length
+    bool strip_ok = false;
+    uint32_t *d_tab = nullptr;
+    RgbStripArgs strip{};              // table offsets and constants; per-launch fields are filled in by rgb_launch
+    struct Seg { int seg_rows, nseg; uint32_t seginfo; };
+    std::vector<Seg> segs;
     bool two_stage = false;            // kGeneric: yuv420p scale, then the unscaled converter over the finished canvas
     int cpx = 0, cpy = 0, cpw = 0, cph = 0, cox = 0, coy = 0;
     AxisFilter lh, lv, ch, cv;
@@ -260,6 +459,82 @@ struct RgbPlan {
     RgbCoef coef{};
     char name[96] = "";
 };
+
+// Tables of the fused strip walk, if this geometry can take it.
+static bool build_rgb_strip(RgbPlan *p)
+{
+    const tts_geom &g = p->g;
+    const AxisFilter &lh = p->lh, &lv = p->lv, &ch = p->ch, &cv = p->cv;
+    if (std::getenv("TTS_FORCE_GENERIC") && std::atoi(std::getenv("TTS_FORCE_GENERIC"))) return false;
+    if (g.rgb_stage != TTS_RGB_AT_SCALE || g.do_pad || p->two_stage) return false;
+    if (lh.size > 4 || lv.size > 4 || ch.size > 4 || cv.size > 4) return false;
+    if ((g.crop_x & 1) || (g.crop_w & 1) || g.crop_w < 8) return false;           // pixel pairs must not straddle a strip
+    if (lh.src < 8 || ch.src < 8) return false;
+    for (size_t i = 1; i < lv.pos.size(); ++i) if (lv.pos[i] < lv.pos[i - 1]) return false;
+    for (size_t i = 1; i < cv.pos.size(); ++i) if (cv.pos[i] < cv.pos[i - 1]) return false;
+    const int pw = g.crop_w, ph = g.crop_h, strips = (pw + 7) / 8;
+    std::vector<uint32_t> tab;
+    RgbStripArgs &a = p->strip;
+    auto pack16 = [](int16_t lo, int16_t hi) { return uint32_t(uint16_t(lo)) | (uint32_t(uint16_t(hi)) << 16); };
+    // one 8-byte window per 4 columns; each column picks its taps with a byte selector (taps <= 4 and 4
+    // columns within 8 bytes: every enlargement)
+    auto group = [&](const AxisFilter &f, int first_col, uint32_t &hoff_out, uint32_t *sel, uint32_t *coef) {
+        const int glo = std::min(f.pos[first_col], f.src - 8);
+        for (int j = 0; j < 4; ++j) {
+            const int col = std::min(first_col + j, f.dst - 1);
+            const int d = f.pos[col] - glo;
+            if (d < 0 || d + f.size > 8) return false;
+            int16_t t4[4] = {0, 0, 0, 0};
+            for (int k = 0; k < f.size; ++k) t4[k] = f.taps[size_t(col) * f.size + k];
+            sel[2 * j] = 0x0c000c00u | uint32_t(d) | (uint32_t(d + 1) << 16);
+            sel[2 * j + 1] = 0x0c000c00u | uint32_t(d + 2) | (uint32_t(d + 3) << 16);
+            coef[2 * j] = pack16(t4[0], t4[1]); coef[2 * j + 1] = pack16(t4[2], t4[3]);
+        }
+        hoff_out = uint32_t(glo);
+        return true;
+    };
+    a.hoffl = uint32_t(tab.size()); tab.resize(tab.size() + size_t(strips) * 2);
+    a.sell = uint32_t(tab.size());  tab.resize(tab.size() + size_t(strips) * 16);
+    a.coefl = uint32_t(tab.size()); tab.resize(tab.size() + size_t(strips) * 16);
+    a.hoffc = uint32_t(tab.size()); tab.resize(tab.size() + size_t(strips));
+    a.selc = uint32_t(tab.size());  tab.resize(tab.size() + size_t(strips) * 8);
+    a.coefc = uint32_t(tab.size()); tab.resize(tab.size() + size_t(strips) * 8);
+    for (int s0 = 0; s0 < strips; ++s0) {
+        const int vx = g.crop_x + std::min(s0 * 8, pw - 8);                      // even: crop_x and pw are
+        for (int q = 0; q < 2; ++q)
+            if (!group(lh, vx + 4 * q, tab[a.hoffl + s0 * 2 + q], &tab[a.sell + (size_t(s0) * 8 + 4 * q) * 2], &tab[a.coefl + (size_t(s0) * 8 + 4 * q) * 2])) return false;
+        if (!group(ch, vx >> 1, tab[a.hoffc + s0], &tab[a.selc + size_t(s0) * 8], &tab[a.coefc + size_t(s0) * 8])) return false;
+    }
+    // per output row: source rows that enter the rings first; the 4 ring rows end at the filter's last tap,
+    // so shorter filters sit right-aligned behind zero taps
+    a.vrow = uint32_t(tab.size()); tab.resize(tab.size() + size_t(ph) * 6);
+    for (int y = 0; y < ph; ++y) {
+        const int vy = g.crop_y + y;
+        uint32_t *r = &tab[a.vrow + size_t(y) * 6];
+        r[0] = y ? uint32_t(lv.pos[vy] - lv.pos[vy - 1]) : 0u;
+        r[1] = y ? uint32_t(cv.pos[vy] - cv.pos[vy - 1]) : 0u;
+        int16_t tl[4] = {0, 0, 0, 0}, tc[4] = {0, 0, 0, 0};
+        for (int k = 0; k < lv.size; ++k) tl[4 - lv.size + k] = lv.taps[size_t(vy) * lv.size + k];
+        for (int k = 0; k < cv.size; ++k) tc[4 - cv.size + k] = cv.taps[size_t(vy) * cv.size + k];
+        r[2] = pack16(tl[0], tl[1]); r[3] = pack16(tl[2], tl[3]);
+        r[4] = pack16(tc[0], tc[1]); r[5] = pack16(tc[2], tc[3]);
+    }
+    for (int sr : {16, 24, 32, 48, 64, 96, 128, 192, 256}) {
+        RgbPlan::Seg sg;
+        sg.seg_rows = sr; sg.nseg = (ph + sr - 1) / sr; sg.seginfo = uint32_t(tab.size());
+        for (int k = 0; k < sg.nseg; ++k) {
+            const int vy = g.crop_y + k * sr;
+            tab.push_back(uint32_t(lv.pos[vy] + lv.size - 4));
+            tab.push_back(uint32_t(cv.pos[vy] + cv.size - 4));
+        }
+        p->segs.push_back(sg);
+        if (sg.nseg == 1) break;
+    }
+    a.strips = strips; a.ph = ph; a.pw = pw;
+    a.src_h_l = lv.src; a.src_h_c = cv.src;
+    a.swap = p->swap; a.coef = p->coef;
+    return upload_vec(p->d_tab, tab);
+}
 
 int rgb_plan_create(const tts_geom &g, int n_cus, RgbPlan **out)
 {
@@ -336,6 +611,7 @@ int rgb_plan_create(const tts_geom &g, int n_cus, RgbPlan **out)
         for (int i = 0; i < 4 && !rc; ++i)
             if (!upload_vec(p->d_pos[i], f[i]->pos) || !upload_vec(p->d_taps[i], f[i]->taps)) { set_last_error("table upload failed (hipMalloc / hipMemcpy)"); rc = TTS_ERR_INITIALIZATION_FAILED; }
         std::snprintf(p->name, sizeof p->name, "rgb_generic<%d,%d,%d,%d>", p->lh.size, p->lv.size, p->ch.size, p->cv.size);
+        if (!rc && (p->strip_ok = build_rgb_strip(p))) std::snprintf(p->name, sizeof p->name, "rgb_strip<%d>", p->bpp);
     }
     if (rc) { rgb_plan_destroy(p); return rc; }
     *out = p;
@@ -346,6 +622,7 @@ void rgb_plan_destroy(RgbPlan *p)
 {
     if (!p) return;
     for (int i = 0; i < 4; ++i) { (void)hipFree(p->d_pos[i]); (void)hipFree(p->d_taps[i]); }
+    (void)hipFree(p->d_tab);
     delete p;
 }
 
@@ -354,7 +631,31 @@ const char *rgb_plan_kernel_name(const RgbPlan *p) { return p ? p->name : ""; }
 int rgb_launch(const RgbPlan *p, const uint8_t *src, uint8_t *dst, int n, const int src_stride[2], int dst_stride,
                uint64_t src_span, uint64_t dst_span, const FrameAddr &addr, hipStream_t st)
 {
-    (void)src_span; (void)dst_span;
+    if (p->strip_ok) {
+        // lanes are the flattened (frame, strip) index and address from their wave's first frame with 32-bit
+        // offsets: the frames 64 lanes can touch must lie within kMaxSpan of it (else: the generic kernel)
+        const size_t wave_frames = size_t(63 / p->strip.strips + 2);
+        const bool fits = addr.use_table || (wave_frames * addr.src_pitch <= kMaxSpan && wave_frames * addr.dst_pitch <= kMaxSpan);
+        const int64_t items = int64_t(n) * p->strip.strips;
+        if (fits && items < (int64_t(1) << 30)) {
+            auto fn = p->bpp == 3 ? rgb_strip_kernel<3> : rgb_strip_kernel<4>;
+            static int per_cu[2] = {0, 0};                  // resident workgroups per CU, asked once per instantiation
+            int &occ = per_cu[p->bpp == 4];
+            if (!occ && (hipOccupancyMaxActiveBlocksPerMultiprocessor(&occ, fn, kBlock, 0) != hipSuccess || occ < 1)) occ = 1;
+            // the longest segment <= 96 rows that still leaves 3 workgroups per resident slot, else the shortest
+            const double slots = double(p->n_cus) * occ;
+            const int64_t sblocks = (items + kBlock - 1) / kBlock;
+            size_t best = 0;
+            for (size_t i = 0; i < p->segs.size() && p->segs[i].seg_rows <= 96; ++i)
+                if (i == 0 || double(sblocks) * p->segs[i].nseg >= 3.0 * slots) best = i;
+            RgbStripArgs a = p->strip;
+            a.seginfo = p->segs[best].seginfo; a.nseg = p->segs[best].nseg; a.seg_rows = p->segs[best].seg_rows;
+            a.n_items = int(items);
+            a.src_stride_y = src_stride[0]; a.src_stride_c = src_stride[1]; a.dst_stride = dst_stride;
+            a.src_span = src_span; a.dst_span = dst_span; a.addr = addr;
+            return launch_rgb("rgb_strip_kernel", fn, dim3(uint32_t(sblocks) * uint32_t(a.nseg)), dim3(kBlock), 0, st, src, dst, p->d_tab, a);
+        }
+    }
     RgbFrameArgs f{};
     f.src = src; f.dst = dst;
     f.canvas_w = p->g.out_w; f.canvas_h = p->g.out_h;

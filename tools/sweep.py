@@ -32,6 +32,12 @@ CASES = {
     "area4": ("scale=320:180:flags=area", 1280, 720, 1382400 + 86400),
     "bil4": ("scale=320:180:flags=bilinear", 1280, 720, 1382400 + 86400),
     "area12": ("scale=320:180:flags=area", 3840, 2160, 12441600 + 86400),
+    # packed RGB out: the same source window read once + 3 (4) bytes a pixel written once
+    "portrait_rgb24": ("scale=1080:1920:force_original_aspect_ratio=increase,crop=1080:1920,format=rgb24", 1920, 1080, 984960 + 6220800),
+    "portrait_rgba": ("scale=1080:1920:force_original_aspect_ratio=increase,crop=1080:1920,format=rgba", 1920, 1080, 984960 + 8294400),
+    "720p_rgb24": ("scale=1080:1920:force_original_aspect_ratio=increase,crop=1080:1920,format=rgb24", 1280, 720, 438480 + 6220800),
+    "stretch_rgb24": ("scale=w=720:h=1280,format=rgb24", 480, 854, 614880 + 2764800),
+    "thumbref_rgb24": ("scale=320x180:force_original_aspect_ratio=decrease,pad=320x180:-1:-1:color=black,format=rgb24", 1920, 1080, 3110400 + 172800),
 }
 
 
