@@ -27,7 +27,7 @@ typedef enum tts_status {
 } tts_status;
 
 enum { TTS_ALG_BICUBIC = 0, TTS_ALG_AREA = 1, TTS_ALG_BILINEAR = 2 };
-enum { TTS_MEM_DEVICE = 0, TTS_MEM_HOST = 1 };
+enum { TTS_MEM_DEVICE = 0, TTS_MEM_HOST = 1 };   /* tts_frame.mem: see tts_run */
 /* Range step applied to the finished 8-bit frame, borders included: what the swscale pass that
  * ffmpeg auto-inserts between a yuv420p chain and an encoder wanting yuvj420p does -- the mjpeg
  * thumbnail of src/services/video.js:329-334 (`-q:v 2 out.jpg`).  SURVEY.md S7 / 8f-1. */
@@ -105,9 +105,12 @@ size_t tts_plan_frame_bytes(const tts_plan *p, int which);
 /*
  * Run n_frames frames through the plan, asynchronously on hip_stream (a hipStream_t,
  * NULL = default stream).  Replaces the per-frame scale/crop/pad loop of the ffmpeg
- * child (scripts/processVideos.js:71-108).  Frames must be TTS_MEM_DEVICE; the caller
- * owns every buffer and nothing is allocated here.  Planes may lie anywhere (every plane its
+ * child (scripts/processVideos.js:71-108).  TTS_MEM_DEVICE frames: the caller owns every
+ * buffer and nothing is allocated here.  Planes may lie anywhere (every plane its
  * own allocation, any stride >= width; U and V strides equal); nothing outside a plane is read.
+ * TTS_MEM_HOST frames (every frame of the call, both sides; any strides): copied plane by plane
+ * through the staging pool of tts_run_host, synchronously -- hip_stream is not used, and the
+ * frames are finished when the call returns.
  */
 int tts_run(const tts_plan *p, const tts_frame *src, const tts_frame *dst, int n_frames, void *hip_stream);
 
@@ -156,10 +159,14 @@ int tts_run_batch_order(const tts_plan *p, const void *src, size_t src_frame_pit
                         void *dst, size_t dst_frame_pitch, const int32_t *order, int n_out, void *hip_stream);
 
 /*
- * Convenience for callers that hold host memory (the CLI, the Node addon): allocates
- * staging buffers, copies in, runs, copies out, synchronises.  Packed I420 as above.
+ * Convenience for callers that hold host memory (the CLI, the Node addon): copies in, runs,
+ * copies out, synchronises.  Packed frames as for tts_run_batch.  The staging buffers and streams
+ * belong to a per-device pool that grows to the largest call seen and is reused by later calls
+ * (one thumbnail per call, as src/services/video.js:315-368 works, pays no allocation after the
+ * first); tts_trim() frees the pool of the current device.  Calls on one device take turns.
  */
 int tts_run_host(const tts_plan *p, const void *src, void *dst, int n_frames);
+void tts_trim(void);
 
 /*
  * Read back the integer filter tables of one plane class (0 = luma, 1 = chroma) and

@@ -632,3 +632,40 @@ def test_plan_refuses_another_device(tts):
         with pytest.raises(tts.TtsError, match="INVALID_INPUT"):
             plan.run_batch(src, dst)
         torch.cuda.synchronize()
+
+
+def test_host_frames_through_tts_run(tts, oracle):
+    """tts_frame.mem = TTS_MEM_HOST: tts_run stages host frames (padded rows, scattered planes) itself."""
+    iw, ih, n = 160, 90, 7
+    plan = tts.Plan.from_vf("scale=284:160", iw, ih)
+    ow, oh = plan.out_size
+    src = synth.frames("random", iw, ih, n)
+    want = oracle.run_chain(plan.geom, src)
+    keep, sp, dp, ss, ds = [], [], [], [], []
+    for i in range(n):
+        planes = []
+        for k, pl in enumerate(synth.split(src[i], iw, ih)):
+            buf = np.full((pl.shape[0], pl.shape[1] + 5 + k), 0xEE, np.uint8)     # padded rows
+            buf[:, : pl.shape[1]] = pl
+            planes.append(buf)
+        outs = [np.full((oh, ow + 3), 0xA5, np.uint8), np.full(((oh + 1) // 2, (ow + 1) // 2 + 1), 0xA5, np.uint8),
+                np.full(((oh + 1) // 2, (ow + 1) // 2 + 1), 0xA5, np.uint8)]
+        keep.append((planes, outs))
+        sp.append([b.ctypes.data for b in planes]); ss.append([b.shape[1] for b in planes])
+        dp.append([b.ctypes.data for b in outs]); ds.append([b.shape[1] for b in outs])
+    plan.run_frames(sp, dp, ss, ds, host=True)
+    for i in range(n):
+        outs = keep[i][1]
+        got = np.concatenate([outs[0][:, :ow].ravel(), outs[1][:, : (ow + 1) // 2].ravel(), outs[2][:, : (ow + 1) // 2].ravel()])
+        assert np.array_equal(got, want[i])
+        assert (outs[0][:, ow:] == 0xA5).all() and (outs[1][:, (ow + 1) // 2:] == 0xA5).all()
+    # mixing host and device frames in one call is an error, not a crash
+    import torch
+    d = torch.zeros(plan.out_bytes, dtype=torch.uint8, device="cuda")
+    S, D = (tts.Frame * 1)(), (tts.Frame * 1)()
+    for k in range(3):
+        S[0].plane[k], S[0].stride[k] = sp[0][k], ss[0][k]
+        D[0].plane[k], D[0].stride[k] = d.data_ptr(), ow
+    S[0].width, S[0].height, D[0].width, D[0].height = iw, ih, ow, oh
+    S[0].mem, D[0].mem = 1, 0
+    assert tts._lib.lib().tts_run(plan._h, S, D, 1, None) == -1

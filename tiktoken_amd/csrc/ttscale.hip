@@ -275,6 +275,8 @@ int tts_run_batch_strided(const tts_plan *p, const void *src, size_t src_frame_p
     return run_batch_impl(p, src, src_frame_pitch, sstride, dst, dst_frame_pitch, dstride, n_frames, hip_stream);
 }
 
+static int run_host_frames(const tts_plan *p, const tts_frame *src, const tts_frame *dst, int n_frames);
+
 int tts_run(const tts_plan *p, const tts_frame *src, const tts_frame *dst, int n_frames, void *hip_stream)
 {
     if (!p || n_frames < 0) return TTS_ERR_INVALID_INPUT;
@@ -283,8 +285,13 @@ int tts_run(const tts_plan *p, const tts_frame *src, const tts_frame *dst, int n
     const tts_geom &g = p->g;
     const int bpp = g.out_fmt == TTS_FMT_YUV420P ? 0 : g.out_fmt >= TTS_FMT_RGBA ? 4 : 3;
     const int ndp = bpp ? 1 : 3;                       // destination planes: packed RGB frames have one
+    // Host frames (TTS_MEM_HOST, every frame of the call, both sides): staged through the per-device pool
+    // of tts_run_host, synchronous, on the pool's own streams (hip_stream is not used).
+    int n_host = 0;
+    for (int i = 0; i < n_frames; ++i) n_host += (src[i].mem == TTS_MEM_HOST) + (dst[i].mem == TTS_MEM_HOST);
+    if (n_host == 2 * n_frames) return run_host_frames(p, src, dst, n_frames);
     for (int i = 0; i < n_frames; ++i) {
-        if (src[i].mem != TTS_MEM_DEVICE || dst[i].mem != TTS_MEM_DEVICE) return TTS_ERR_INVALID_INPUT;
+        if (src[i].mem != TTS_MEM_DEVICE || dst[i].mem != TTS_MEM_DEVICE) { g_last_error = "a call takes device frames or host frames, not both"; return TTS_ERR_INVALID_INPUT; }
         if (src[i].width != g.in_w || src[i].height != g.in_h || dst[i].width != g.out_w || dst[i].height != g.out_h) return TTS_ERR_INVALID_INPUT;
         for (int k = 0; k < 3; ++k) {
             if (!src[i].plane[k] || (k < ndp && !dst[i].plane[k])) return TTS_ERR_INVALID_INPUT;
@@ -354,6 +361,112 @@ int tts_run(const tts_plan *p, const tts_frame *src, const tts_frame *dst, int n
     return rc;
 }
 
+}  // extern "C"
+
+namespace {
+
+// ---- staging for callers that hold host memory -----------------------------------------------------
+// tts_run_host used to hipMalloc four buffers and create two streams on every call (one thumbnail per
+// call through the Node addon paid ~1 ms of allocation for microseconds of work).  The buffers and
+// streams now live in a per-device pool that grows to the largest chunk seen and is reused by every later
+// call on that device; tts_trim() gives it back.  One call at a time per device holds the pool (host
+// calls are synchronous and share one PCIe link anyway).
+struct HostPool {
+    std::mutex mu;
+    void *src[2] = {nullptr, nullptr}, *dst[2] = {nullptr, nullptr};
+    size_t src_cap[2] = {0, 0}, dst_cap[2] = {0, 0};
+    hipStream_t st[2] = {nullptr, nullptr};
+    bool reserve(int slot, size_t sbytes, size_t dbytes)
+    {
+        auto grow = [](void *&ptr, size_t &cap, size_t want) {
+            if (want <= cap) return true;
+            (void)hipFree(ptr); ptr = nullptr; cap = 0;
+            if (hipMalloc(&ptr, want) != hipSuccess) return false;
+            cap = want;
+            return true;
+        };
+        if (!st[slot] && hipStreamCreateWithFlags(&st[slot], hipStreamNonBlocking) != hipSuccess) return false;
+        return grow(src[slot], src_cap[slot], sbytes) && grow(dst[slot], dst_cap[slot], dbytes);
+    }
+    void release()
+    {
+        for (int s = 0; s < 2; ++s) {
+            (void)hipFree(src[s]); (void)hipFree(dst[s]);
+            src[s] = dst[s] = nullptr; src_cap[s] = dst_cap[s] = 0;
+            if (st[s]) (void)hipStreamDestroy(st[s]);
+            st[s] = nullptr;
+        }
+    }
+};
+constexpr int kMaxDevices = 64;
+HostPool g_host_pool[kMaxDevices];
+
+}  // namespace
+
+extern "C" {
+
+void tts_trim(void)
+{
+    int dev = -1;
+    if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= kMaxDevices) return;
+    HostPool &pool = g_host_pool[dev];
+    std::lock_guard<std::mutex> lock(pool.mu);
+    pool.release();
+}
+
+// tts_run with TTS_MEM_HOST frames: plane by plane (rows may be padded) into packed frames in the pool's
+// device buffers, one batch launch set, plane by plane back.
+static int run_host_frames(const tts_plan *p, const tts_frame *src, const tts_frame *dst, int n_frames)
+{
+    const tts_geom &g = p->g;
+    const int bpp = g.out_fmt == TTS_FMT_YUV420P ? 0 : g.out_fmt >= TTS_FMT_RGBA ? 4 : 3;
+    const int ndp = bpp ? 1 : 3;
+    for (int i = 0; i < n_frames; ++i) {
+        if (src[i].width != g.in_w || src[i].height != g.in_h || dst[i].width != g.out_w || dst[i].height != g.out_h) return TTS_ERR_INVALID_INPUT;
+        for (int k = 0; k < 3; ++k) {
+            if (!src[i].plane[k] || src[i].stride[k] < ceil_shift(g.in_w, k ? 1 : 0)) return TTS_ERR_INVALID_INPUT;
+            if (k < ndp && (!dst[i].plane[k] || dst[i].stride[k] < (bpp ? g.out_w * bpp : ceil_shift(g.out_w, k ? 1 : 0)))) return TTS_ERR_INVALID_INPUT;
+        }
+    }
+    if (const int drc = check_device(p)) return drc;
+    if (p->device < 0 || p->device >= kMaxDevices) return TTS_ERR_UNSUPPORTED;
+    const size_t sb = tts_plan_frame_bytes(p, 0), db = tts_plan_frame_bytes(p, 1);
+    const int per = int(std::max<size_t>(1, std::min<size_t>(size_t(n_frames), (size_t(p->knobs.host_chunk_mb) << 20) / (sb + db))));
+    HostPool &pool = g_host_pool[p->device];
+    std::lock_guard<std::mutex> lock(pool.mu);
+    if (!pool.reserve(0, sb * per, db * per)) { g_last_error = "staging pool: hipMalloc / hipStreamCreate failed"; return TTS_ERR_INITIALIZATION_FAILED; }
+    hipStream_t st = pool.st[0];
+    uint8_t *ds = static_cast<uint8_t *>(pool.src[0]), *dd = static_cast<uint8_t *>(pool.dst[0]);
+    int rc = TTS_OK;
+    for (int f0 = 0; f0 < n_frames && !rc; f0 += per) {
+        const int cnt = std::min(per, n_frames - f0);
+        for (int i = 0; i < cnt && !rc; ++i) {
+            size_t off = 0;
+            for (int k = 0; k < 3 && !rc; ++k) {
+                const int w = ceil_shift(g.in_w, k ? 1 : 0), h = ceil_shift(g.in_h, k ? 1 : 0);
+                if (hipMemcpy2DAsync(ds + size_t(i) * sb + off, size_t(w), src[f0 + i].plane[k], size_t(src[f0 + i].stride[k]), size_t(w), size_t(h),
+                                     hipMemcpyHostToDevice, st) != hipSuccess) rc = TTS_ERR_PROCESSING_FAILED;
+                off += size_t(w) * h;
+            }
+        }
+        if (!rc) rc = tts_run_batch(p, ds, sb, dd, db, cnt, st);
+        for (int i = 0; i < cnt && !rc; ++i) {
+            size_t off = 0;
+            for (int k = 0; k < ndp && !rc; ++k) {
+                const size_t w = bpp ? size_t(g.out_w) * bpp : size_t(ceil_shift(g.out_w, k ? 1 : 0));
+                const size_t h = bpp ? size_t(g.out_h) : size_t(ceil_shift(g.out_h, k ? 1 : 0));
+                if (hipMemcpy2DAsync(dst[f0 + i].plane[k], size_t(dst[f0 + i].stride[k]), dd + size_t(i) * db + off, w, w, h,
+                                     hipMemcpyDeviceToHost, st) != hipSuccess) rc = TTS_ERR_PROCESSING_FAILED;
+                off += w * h;
+            }
+        }
+        // (one slot: the next chunk's uploads must not overtake this chunk's downloads; same stream, so they cannot)
+    }
+    if (hipStreamSynchronize(st) != hipSuccess && !rc) rc = TTS_ERR_PROCESSING_FAILED;
+    if (rc == TTS_ERR_PROCESSING_FAILED && g_last_error.empty()) g_last_error = "copy between host frames and the staging pool failed";
+    return rc;
+}
+
 int tts_run_host(const tts_plan *p, const void *src, void *dst, int n_frames)
 {
     if (!p || n_frames < 0) return TTS_ERR_INVALID_INPUT;
@@ -372,12 +485,14 @@ int tts_run_host(const tts_plan *p, const void *src, void *dst, int n_frames)
     const int per = int(std::max<size_t>(1, std::min<size_t>(size_t(n_frames), chunk_bytes / (sb + db))));
     const int nchunks = (n_frames + per - 1) / per;
     const int slots = std::min(2, nchunks);
-    void *ds[2] = {nullptr, nullptr}, *dd[2] = {nullptr, nullptr};
-    hipStream_t st[2] = {nullptr, nullptr};
+    if (p->device < 0 || p->device >= kMaxDevices) return TTS_ERR_UNSUPPORTED;
+    HostPool &pool = g_host_pool[p->device];
+    std::lock_guard<std::mutex> lock(pool.mu);
+    void **ds = pool.src, **dd = pool.dst;
+    hipStream_t *st = pool.st;
     int rc = TTS_OK;
     for (int s = 0; s < slots && !rc; ++s)
-        if (hipMalloc(&ds[s], sb * per) != hipSuccess || hipMalloc(&dd[s], db * per) != hipSuccess ||
-            hipStreamCreateWithFlags(&st[s], hipStreamNonBlocking) != hipSuccess) rc = TTS_ERR_INITIALIZATION_FAILED;
+        if (!pool.reserve(s, sb * per, db * per)) { g_last_error = "staging pool: hipMalloc / hipStreamCreate failed"; rc = TTS_ERR_INITIALIZATION_FAILED; }
     for (int i = 0; i < nchunks && !rc; ++i) {
         const int s = i % slots, f0 = i * per, cnt = std::min(per, n_frames - f0);
         const uint8_t *hs = static_cast<const uint8_t *>(src) + size_t(f0) * sb;
@@ -388,10 +503,6 @@ int tts_run_host(const tts_plan *p, const void *src, void *dst, int n_frames)
     }
     for (int s = 0; s < slots; ++s)
         if (st[s] && hipStreamSynchronize(st[s]) != hipSuccess && !rc) rc = TTS_ERR_PROCESSING_FAILED;
-    for (int s = 0; s < slots; ++s) {
-        if (st[s]) (void)hipStreamDestroy(st[s]);
-        (void)hipFree(ds[s]); (void)hipFree(dd[s]);
-    }
     return rc;
 }
 

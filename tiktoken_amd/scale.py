@@ -203,8 +203,9 @@ class Plan:
                                              order.ctypes.data_as(ctypes.c_void_p), n, ctypes.c_void_p(stream)))
         return dst
 
-    def run_frames(self, src_planes, dst_planes, src_strides, dst_strides, stream=None):
-        """Arbitrary plane pointers: lists (one entry per frame) of 3 device pointers / 3 strides."""
+    def run_frames(self, src_planes, dst_planes, src_strides, dst_strides, stream=None, host=False):
+        """Arbitrary plane pointers: lists (one entry per frame) of 3 pointers / 3 strides (packed RGB out:
+        plane 0 / stride 0 alone).  host=True: the pointers are host memory (TTS_MEM_HOST; synchronous)."""
         n = len(src_planes)
         S, D = (Frame * n)(), (Frame * n)()
         for i in range(n):
@@ -215,6 +216,10 @@ class Plan:
                 D[i].stride[k] = dst_strides[i][k]
             S[i].width, S[i].height = self.in_size
             D[i].width, D[i].height = self.out_size
+            S[i].mem = D[i].mem = 1 if host else 0
+        if host:
+            check(_lib.lib().tts_run(self._h, S, D, n, None), _lib.lib().tts_last_error().decode())
+            return
         if stream is None:
             import torch
             stream = torch.cuda.current_stream(self.device).cuda_stream
@@ -231,3 +236,4 @@ class Plan:
         check(_lib.lib().tts_run_host(self._h, src.ctypes.data_as(ctypes.c_void_p),
                                       dst.ctypes.data_as(ctypes.c_void_p), n))
         return dst
+
