@@ -169,6 +169,19 @@ int tts_run_host(const tts_plan *p, const void *src, void *dst, int n_frames);
 void tts_trim(void);
 
 /*
+ * tts_run_host for callers that cannot allocate (code under HIP graph capture, tight serving loops,
+ * harnesses that forbid hipMalloc).  No counterpart in the reference.  Stages through a 64 MiB
+ * `static __device__` array inside the library (each GPU the library runs on holds its copy until the
+ * process ends) instead of pool buffers: calls no hipMalloc / hipFree / hipStreamCreate, runs on the
+ * caller's hip_stream, and does NOT synchronise -- dst is complete once hip_stream has passed the
+ * call's last copy (pinned host buffers make the copies truly asynchronous).  Batches larger than
+ * the array go through it in several passes; TTS_ERR_UNSUPPORTED if a single frame (source + output,
+ * each rounded up to 256 bytes) exceeds 64 MiB.  Every call on a GPU shares that GPU's array: calls
+ * that overlap in time on one GPU (two streams, two threads) race and corrupt each other's frames.
+ */
+int tts_run_host_static(const tts_plan *p, const void *src, void *dst, int n_frames, void *hip_stream);
+
+/*
  * Read back the integer filter tables of one plane class (0 = luma, 1 = chroma) and
  * axis (0 = horizontal, 1 = vertical) so tests can compare them with the oracle.
  * coef/pos may be NULL to query sizes.  Replaces nothing in the reference: swscale

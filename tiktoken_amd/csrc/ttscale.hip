@@ -401,9 +401,68 @@ struct HostPool {
 constexpr int kMaxDevices = 64;
 HostPool g_host_pool[kMaxDevices];
 
+// ---- the scratch of tts_run_host_static ------------------------------------------------------------
+// Device memory that belongs to the library's code object: every GPU the library runs on holds its own
+// copy from module load until the process ends.  In host code the array's NAME is a host-side stand-in,
+// not a device address: only the pointer hipGetSymbolAddress returns -- asked once per device, with that
+// device current -- may be handed to kernels and copies.
+constexpr size_t kScratchBytes = size_t(64) << 20;
+static __device__ __align__(256) unsigned char scratch[kScratchBytes];
+std::mutex g_scratch_mu;
+unsigned char *g_scratch_ptr[kMaxDevices] = {};
+
+int scratch_for_device(int dev, unsigned char **out)
+{
+    if (dev < 0 || dev >= kMaxDevices) { g_last_error = "device index out of range"; return TTS_ERR_UNSUPPORTED; }
+    std::lock_guard<std::mutex> lock(g_scratch_mu);
+    if (!g_scratch_ptr[dev]) {
+        void *ptr = nullptr;
+        const hipError_t e = hipGetSymbolAddress(&ptr, HIP_SYMBOL(scratch));       // (the caller has made `dev` current)
+        if (e != hipSuccess || !ptr) {
+            g_last_error = std::string("hipGetSymbolAddress(scratch): ") + hipGetErrorString(e);
+            return TTS_ERR_INITIALIZATION_FAILED;
+        }
+        g_scratch_ptr[dev] = static_cast<unsigned char *>(ptr);
+    }
+    *out = g_scratch_ptr[dev];
+    return TTS_OK;
+}
+
 }  // namespace
 
 extern "C" {
+
+int tts_run_host_static(const tts_plan *p, const void *src, void *dst, int n_frames, void *hip_stream)
+{
+    if (!p || n_frames < 0) return TTS_ERR_INVALID_INPUT;
+    if (n_frames == 0) return TTS_OK;
+    if (!src || !dst) return TTS_ERR_INVALID_INPUT;
+    if (const int drc = check_device(p)) return drc;
+    unsigned char *base = nullptr;
+    if (const int rc = scratch_for_device(p->device, &base)) return rc;
+    const size_t sb = tts_plan_frame_bytes(p, 0), db = tts_plan_frame_bytes(p, 1);
+    auto up = [](size_t v) { return (v + 255) & ~size_t(255); };
+    if (up(sb) + up(db) > kScratchBytes) {
+        g_last_error = "one frame in (" + std::to_string(sb) + " B) and out (" + std::to_string(db) + " B) exceeds the " +
+                       std::to_string(kScratchBytes >> 20) + " MiB static scratch of tts_run_host_static";
+        return TTS_ERR_UNSUPPORTED;
+    }
+    // frames per pass: the source chunk at the start of the array, the output chunk behind it
+    const size_t per = std::min<size_t>(size_t(n_frames), std::max<size_t>(1, (kScratchBytes - 256) / (sb + db)));
+    unsigned char *dsrc = base, *ddst = base + up(per * sb);
+    hipStream_t st = static_cast<hipStream_t>(hip_stream);
+    for (size_t f0 = 0; f0 < size_t(n_frames); f0 += per) {
+        const size_t cnt = std::min(per, size_t(n_frames) - f0);
+        if (hipMemcpyAsync(dsrc, static_cast<const uint8_t *>(src) + f0 * sb, sb * cnt, hipMemcpyHostToDevice, st) != hipSuccess) {
+            g_last_error = "hipMemcpyAsync (host to scratch) failed"; return TTS_ERR_PROCESSING_FAILED;
+        }
+        if (const int rc = tts_run_batch(p, dsrc, sb, ddst, db, int(cnt), st)) return rc;
+        if (hipMemcpyAsync(static_cast<uint8_t *>(dst) + f0 * db, ddst, db * cnt, hipMemcpyDeviceToHost, st) != hipSuccess) {
+            g_last_error = "hipMemcpyAsync (scratch to host) failed"; return TTS_ERR_PROCESSING_FAILED;
+        }
+    }
+    return TTS_OK;
+}
 
 void tts_trim(void)
 {

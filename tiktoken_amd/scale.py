@@ -237,3 +237,18 @@ class Plan:
                                       dst.ctypes.data_as(ctypes.c_void_p), n))
         return dst
 
+    def run_host_static(self, src, out, stream=None):
+        """tts_run_host_static: like run_host, staged through the library's static device scratch (no
+        allocation) on `stream`, NOT synchronised: `out` (required; pinned memory makes the copies
+        asynchronous) is complete once the stream has passed the call."""
+        src = np.ascontiguousarray(src, dtype=np.uint8)
+        n = src.size // self.in_bytes
+        if not (out.dtype == np.uint8 and out.flags.c_contiguous and out.size == n * self.out_bytes):
+            raise TtsError(-1, "out must be a C-contiguous uint8 array of n*out_bytes")
+        if stream is None:
+            import torch
+            stream = torch.cuda.current_stream(self.device).cuda_stream
+        rc = _lib.lib().tts_run_host_static(self._h, src.ctypes.data_as(ctypes.c_void_p), out.ctypes.data_as(ctypes.c_void_p),
+                                            n, ctypes.c_void_p(stream))
+        check(rc, _lib.lib().tts_last_error().decode() if rc else "")
+        return out
