@@ -36,6 +36,62 @@ def assign(clips: Sequence[Clip], world: int, out_size: Tuple[int, int]) -> List
     return shards
 
 
+@dataclass(frozen=True)
+class Piece:
+    """A run of consecutive frames of one clip: what a rank is handed when long clips are cut at GOP boundaries."""
+    clip: int          # index into the clip list
+    first: int
+    frames: int
+
+
+def split_gops(clips: Sequence[Clip], world: int, out_size: Tuple[int, int], gop: int = 30) -> List[Piece]:
+    """Cut every clip that costs more than the mean rank load into near-equal pieces at GOP boundaries
+    (multiples of `gop` frames: where a decoder can start), so that one long clip -- a 600-frame 4K clip
+    among short ones, or fewer clips than GPUs -- spreads over several GPUs.  Frames are independent, so any
+    frame boundary would do for the scaler; the GOP grid is what the decoder feeding it needs.  Shorter clips
+    stay whole (a piece per clip).  Deterministic."""
+    if world < 1 or gop < 1:
+        raise ValueError("world and gop must be >= 1")
+    total = sum(c.cost(*out_size) for c in clips)
+    mean = total / world if world else 0
+    pieces: List[Piece] = []
+    for i, c in enumerate(clips):
+        gops = (c.frames + gop - 1) // gop
+        parts = 1
+        if mean > 0 and c.cost(*out_size) > mean:
+            # pieces of about a quarter of the mean load (the greedy assignment then evens the ranks out to a
+            # few per cent), at most one piece per GOP
+            parts = min(gops, -(-4 * c.cost(*out_size) // max(int(mean), 1)))
+        first = 0
+        for k in range(parts):
+            g = gops // parts + (1 if k < gops % parts else 0)            # GOPs of this piece
+            n = min(g * gop, c.frames - first)
+            if n > 0:
+                pieces.append(Piece(i, first, n))
+            first += n
+    return pieces
+
+
+def assign_pieces(clips: Sequence[Clip], world: int, out_size: Tuple[int, int], gop: int = 30) -> List[List[Piece]]:
+    """assign() over GOP-granular pieces: per rank, the pieces it processes (longest-processing-time first)."""
+    pieces = split_gops(clips, world, out_size, gop)
+    cost = [Clip(clips[p.clip].name, clips[p.clip].width, clips[p.clip].height, p.frames).cost(*out_size) for p in pieces]
+    order = sorted(range(len(pieces)), key=lambda i: (-cost[i], i))
+    load = [0] * world
+    shards: List[List[Piece]] = [[] for _ in range(world)]
+    for i in order:
+        r = min(range(world), key=lambda k: (load[k], k))
+        shards[r].append(pieces[i])
+        load[r] += cost[i]
+    return shards
+
+
+def piece_imbalance(clips: Sequence[Clip], shards: List[List[Piece]], out_size: Tuple[int, int]) -> float:
+    loads = [sum(Clip("", clips[p.clip].width, clips[p.clip].height, p.frames).cost(*out_size) for p in s) for s in shards]
+    mean = sum(loads) / max(len(loads), 1)
+    return max(loads) / mean if mean else 1.0
+
+
 def imbalance(clips: Sequence[Clip], shards: List[List[int]], out_size: Tuple[int, int]) -> float:
     """max rank load / mean rank load (1.0 = perfect)."""
     loads = [sum(clips[i].cost(*out_size) for i in s) for s in shards]
@@ -43,22 +99,36 @@ def imbalance(clips: Sequence[Clip], shards: List[List[int]], out_size: Tuple[in
     return max(loads) / mean if mean else 1.0
 
 
-def run_shard(clips: Sequence[Clip], my: Sequence[int], vf: str, make_frames, batch: int = 64) -> Dict[str, int]:
-    """Process this rank's clips on the current GPU; returns {clip name: checksum of its output bytes}.
-    `make_frames(clip, first, n)` supplies packed I420 frames as a uint8 CUDA tensor [n, in_bytes]."""
+def run_shard(clips: Sequence[Clip], my: Sequence, vf: str, make_frames, batch: int = 64, timing: Dict = None) -> Dict[str, int]:
+    """Process this rank's share on the current GPU: `my` holds clip indices (assign) or Pieces
+    (assign_pieces).  Returns {clip name: checksum of the output bytes this rank produced for it} -- the sum
+    of all output bytes, so the checksums of a clip's pieces add up to the whole clip's whatever the cut.
+    `make_frames(clip, first, n)` supplies packed I420 frames as a uint8 CUDA tensor [n, in_bytes].
+    `timing`, if given, receives "scale_s" (device time of the scaler launches alone, HIP events) and "frames"."""
     import torch
     from .scale import Plan
     plans: Dict[Tuple[int, int], Plan] = {}
     sums: Dict[str, int] = {}
-    for i in my:
-        c = clips[i]
+    scale_ms, frames = 0.0, 0
+    for item in my:
+        piece = item if isinstance(item, Piece) else Piece(item, 0, clips[item].frames)
+        c = clips[piece.clip]
         plan = plans.get((c.width, c.height))
-        if plan is None:
+        if plan is None:                                   # plan switch: one plan per source geometry per GPU
             plan = plans[(c.width, c.height)] = Plan.from_vf(vf, c.width, c.height)
         total = 0
-        for first in range(0, c.frames, batch):
-            n = min(batch, c.frames - first)
-            out = plan.run_batch(make_frames(c, first, n))
-            total += int(out.to(torch.int64).sum().item())
-        sums[c.name] = total
+        for first in range(piece.first, piece.first + piece.frames, batch):
+            n = min(batch, piece.first + piece.frames - first)
+            src = make_frames(c, first, n)
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record()
+            out = plan.run_batch(src)
+            e1.record()
+            total += int(out.sum(dtype=torch.int64).item())        # (synchronises)
+            scale_ms += e0.elapsed_time(e1)
+            frames += n
+        sums[c.name] = sums.get(c.name, 0) + total
+    if timing is not None:
+        timing["scale_s"] = timing.get("scale_s", 0.0) + scale_ms * 1e-3
+        timing["frames"] = timing.get("frames", 0) + frames
     return sums
