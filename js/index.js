@@ -97,4 +97,5 @@ ttscale.loopOrder = native.loopOrder;
 ttscale.parseVf = native.parseVf;
 ttscale.frameBytes = native.frameBytes;
 ttscale.runHost = native.runHost;
+ttscale.terminate = native.terminate;
 module.exports = ttscale;

@@ -81,9 +81,23 @@ napi_value FrameBytes(napi_env env, napi_callback_info info)
 // Plans are kept between calls (a script converts many clips of a few geometries, the app one
 // thumbnail after another): building one costs about a millisecond, a frame far less.  Node runs
 // addon calls on one thread; the map is never shared.
+std::map<std::string, tts_plan *> plans;
+
+// videoProcessor.terminate() (web/src/tests/video/compression.test.js:27-29): give back what is cached between
+// calls -- the plans (tables in HBM) and the library's host-path staging pool
+napi_value Terminate(napi_env env, napi_callback_info)
+{
+    const size_t n = plans.size();
+    for (auto &kv : plans) tts_plan_destroy(kv.second);
+    plans.clear();
+    tts_trim();
+    napi_value out;
+    napi_create_uint32(env, uint32_t(n), &out);
+    return out;
+}
+
 tts_plan *cached_plan(const std::string &vf, int32_t iw, int32_t ih, const tts_geom &g, int *rc)
 {
-    static std::map<std::string, tts_plan *> plans;
     const std::string key = vf + "|" + std::to_string(iw) + "x" + std::to_string(ih);
     auto it = plans.find(key);
     if (it != plans.end()) { *rc = TTS_OK; return it->second; }
@@ -174,6 +188,7 @@ napi_value Init(napi_env env, napi_value exports)
         {"runHost", nullptr, RunHost, nullptr, nullptr, nullptr, napi_default, nullptr},
         {"trimRange", nullptr, TrimRange, nullptr, nullptr, nullptr, napi_default, nullptr},
         {"loopOrder", nullptr, LoopOrder, nullptr, nullptr, nullptr, napi_default, nullptr},
+        {"terminate", nullptr, Terminate, nullptr, nullptr, nullptr, napi_default, nullptr},
     };
     napi_define_properties(env, exports, sizeof(props) / sizeof(props[0]), props);
     return exports;

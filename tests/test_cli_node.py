@@ -78,20 +78,31 @@ const out = {};
 out.portrait = v.scaleFilter({width: 1080, height: 1920});
 out.square = v.scaleFilter({width: 1080, height: 1080});
 out.tall = v.scaleFilter({width: 720, height: 2560});
-out.valid = v.validatePortraitMode({width: 720, height: 1280}).isValid;
-try { v.validatePortraitMode({}); } catch (e) { out.meta = e.message; }
+const small = {type: 'video/mp4', width: 8, height: 8, data: Buffer.alloc(96)};
 Promise.all([
   v.compress(null).catch((e) => e.message),
   v.compress(undefined).catch((e) => e.message),
   v.compress({type: 'video/webm', width: 8, height: 8, data: Buffer.alloc(96)}).catch((e) => e.message),
   v.compress({type: 'video/mp4', width: 8, height: 8, data: Buffer.alloc(95)}).catch((e) => e.message),
-]).then((errs) => { out.errs = errs; console.log(JSON.stringify(out)); });
+  v.validatePortraitMode({width: 720, height: 1280, size: 10}).then((r) => r.isValid),
+  v.validatePortraitMode({size: 10}).catch((e) => e.message),                       // portrait.test.js:148-154
+  v.validatePortraitMode({width: 720, height: 1280, size: 0}).catch((e) => e.message),   // portrait.test.js:127-131
+  v.validatePortraitMode({width: 720, height: 1280, data: Buffer.alloc(0)}).catch((e) => e.message),
+  v.compress(small).then((r) => r === small),                                       // compression.test.js:44-50: under 100 MB
+  v.compress(Object.assign({size: 50 * 1024 * 1024}, small)).then((r) => r.size === 50 * 1024 * 1024 && r.data === small.data),
+]).then((r) => {
+  out.errs = r.slice(0, 4); out.valid = r[4]; out.meta = r[5]; out.empty = [r[6], r[7]]; out.gate = [r[8], r[9]];
+  out.dropped = v.terminate();
+  console.log(JSON.stringify(out));
+});
 """ % os.path.join(ROOT, "js", "videoProcessor.js")
     out = json.loads(subprocess.run([NODE, "-e", js], capture_output=True, text=True, check=True).stdout)
     assert out["portrait"] == "scale=720:1280"
     assert "force_original_aspect_ratio=decrease" in out["square"] and "min(720" in out["square"]
     assert "min(1280" in out["tall"]
     assert out["valid"] is True and out["meta"] == "Invalid video metadata"
+    assert out["empty"] == ["Invalid video file", "Invalid video file"]
+    assert out["gate"] == [True, True] and out["dropped"] == 0
     assert [e.split(":")[0] for e in out["errs"]] == ["INVALID_INPUT", "INVALID_INPUT", "INVALID_FORMAT", "INVALID_INPUT"]
     # the chains it emits resolve to what the web spec asks for
     assert tts.parse_vf(out["square"], 1080, 1080).as_dict()["out_w"] == 720
@@ -108,11 +119,12 @@ def test_video_processor_compress_pixels(tts, oracle, tmp_path):
 const fs = require('fs');
 const {videoProcessor: v} = require(%r);
 const seen = [];
-v.compress({type: 'video/mp4', width: 360, height: 640, data: fs.readFileSync(%r)}, {onProgress: (p) => seen.push(p)})
-  .then((r) => { fs.writeFileSync(%r, r.data); console.log(JSON.stringify({w: r.width, h: r.height, vf: r.vf, seen})); });
+// (the spec's gate is the 150 MB container file; these raw frames stand for it)
+v.compress({type: 'video/mp4', width: 360, height: 640, size: 150 * 1024 * 1024, data: fs.readFileSync(%r)}, {onProgress: (p) => seen.push(p)})
+  .then((r) => { fs.writeFileSync(%r, r.data); console.log(JSON.stringify({w: r.width, h: r.height, vf: r.vf, seen, dropped: v.terminate()})); });
 """ % (os.path.join(ROOT, "js", "videoProcessor.js"), str(tmp_path / "in.yuv"), str(tmp_path / "out.yuv"))
     r = json.loads(subprocess.run([NODE, "-e", js], capture_output=True, text=True, check=True).stdout)
-    assert (r["w"], r["h"], r["vf"], r["seen"]) == (720, 1280, "scale=720:1280", [0, 100])
+    assert (r["w"], r["h"], r["vf"], r["seen"], r["dropped"]) == (720, 1280, "scale=720:1280", [0, 100], 1)
     got = np.frombuffer((tmp_path / "out.yuv").read_bytes(), np.uint8).reshape(2, -1)
     assert np.array_equal(got, oracle.run_chain(tts.parse_vf("scale=720:1280", 360, 640), src))
 
