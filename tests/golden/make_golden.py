@@ -20,7 +20,7 @@ import synth  # noqa: E402
 from oracle import oracle  # noqa: E402
 
 # (name, geometry dict) -- geometry spelled out so that this file does not depend on the product's parser
-def geom(in_w, in_h, sc_w, sc_h, alg=0, pre=None, crop=None, pad=None, fill=(16, 128, 128), out_range=0):
+def geom(in_w, in_h, sc_w, sc_h, alg=0, pre=None, crop=None, pad=None, fill=(16, 128, 128), out_range=0, rgb=None):
     pre = pre or (0, 0, in_w, in_h)
     crop = crop or (0, 0, sc_w, sc_h)
     g = dict(in_w=in_w, in_h=in_h, pre_x=pre[0], pre_y=pre[1], pre_w=pre[2], pre_h=pre[3],
@@ -32,6 +32,8 @@ def geom(in_w, in_h, sc_w, sc_h, alg=0, pre=None, crop=None, pad=None, fill=(16,
         g["out_range"] = out_range                     # (left out when 0 so the older fixtures keep their key lists)
     if pad:
         g.update(do_pad=1, pad_x=pad[0], pad_y=pad[1], out_w=pad[2], out_h=pad[3])
+    if rgb:                                            # (out_fmt, rgb_stage, fill_rgb): packed RGB written by the chain
+        g.update(out_fmt=rgb[0], rgb_stage=rgb[1], fill_rgb=rgb[2])
     return g
 
 
@@ -46,6 +48,10 @@ CASES = {
     "precrop_scale": geom(100, 60, 128, 96, pre=(10, 6, 64, 32)),
     "identity": geom(64, 48, 64, 48),
     "thumb_pad_jpeg_72x128": geom(72, 128, 101, 180, pad=(108, 0, 320, 180), out_range=1),   # ... then the mjpeg full-range pass
+    # packed RGB: the scale writes rgb24 (pad on RGB pixels, picture at the odd x = 109), and the conversion-only pass
+    "portrait_rgb24_192x108": geom(192, 108, 341, 192, crop=(116, 0, 108, 192), rgb=(1, 1, 0)),
+    "thumb_pad_rgb24_72x128": geom(72, 128, 101, 180, pad=(109, 0, 320, 180), rgb=(1, 1, 0)),
+    "convert_only_bgra_64x48": geom(64, 48, 64, 48, rgb=(4, 2, 0)),
 }
 PATTERNS = ("random", "impulse", "zone")
 

@@ -99,3 +99,53 @@ def test_range_step_is_the_textbook_mapping_within_one_level(tts, oracle):
     assert np.abs(y - np.clip((p - 16) * 255 / 219, 0, 255)).max() <= 1.0
     assert np.abs(c - np.clip((np.clip(p, 16, 240) - 128) * 255 / 224 + 128, 0, 255)).max() <= 1.0
     assert np.array_equal(np.concatenate([got[f, 320:] for f in range(4)]), c.astype(np.uint8))
+
+
+def test_rgb_tables_are_bt601_within_a_stated_bound(tts, oracle):
+    """format=rgb24 alone: swscale's unscaled converter over its yuv2rgb tables, as recalled (ITU-R BT.601,
+    limited range; oracle/swscale_oracle.c tto_yuv2rgb_init).  Textbook: R = 1.164 (Y - 16) + 1.596 (V - 128),
+    G = 1.164 (Y - 16) - 0.392 (U - 128) - 0.813 (V - 128), B = 1.164 (Y - 16) + 2.017 (U - 128), clipped.
+    STATED BOUND: within 3 levels, and on average between 0 and 2 levels DARKER than the textbook: the recalled
+    table origin (yoffs = 326 against a 384 << 16 ramp start) sits 1.5 luma steps low, and the chroma offsets
+    are floored twice.  A wrong matrix, swapped U / V or a full-range table shows up as tens of levels."""
+    w, h = 64, 48
+    g = tts.parse_vf("format=rgb24", w, h)
+    src = synth.frames("limited", w, h, 4)
+    got = oracle.run_chain(g, src).reshape(4, h, w, 3).astype(np.float64)
+    for i in range(4):
+        y, u, v = (p.astype(np.float64) for p in synth.split(src[i], w, h))
+        u = np.repeat(np.repeat(u, 2, 0), 2, 1) - 128
+        v = np.repeat(np.repeat(v, 2, 0), 2, 1) - 128
+        yy = 255.0 / 219.0 * (y - 16)
+        ref = np.clip(np.stack([yy + 1.596027 * v, yy - 0.391762 * u - 0.812968 * v, yy + 2.017232 * u], -1), 0, 255)
+        d = got[i] - ref
+        inside = (ref > 3) & (ref < 252)                      # away from the clip points, where a shift is a shift
+        assert np.abs(d).max() <= 3.0, np.abs(d).max()
+        assert -2.0 <= d[inside].mean() <= 0.0, d[inside].mean()
+    # grey ramp: neutral chroma gives R = G = B, monotone in Y, black at 16 and (recalled tables) 253 at 235
+    ramp = np.zeros((1, w * h + 2 * (w // 2) * (h // 2)), np.uint8)
+    ramp[0, : w * h] = np.arange(w * h) % 256
+    ramp[0, w * h:] = 128
+    px = oracle.run_chain(g, ramp).reshape(h * w, 3)[:256]
+    assert (px[:, 0] == px[:, 1]).all() and (px[:, 1] == px[:, 2]).all()
+    assert (np.diff(px[:, 0].astype(int)) >= 0).all() and px[16, 0] == 0 and px[235, 0] in (253, 254, 255) and px[255, 0] == 255
+
+
+def test_rgb_scaled_path_agrees_with_scaling_then_converting_in_float(tts, oracle):
+    """scale=...,format=rgb24: luma to W x H, chroma to ceil(W / 2) x H (two pixels share a sample, every row its
+    own), then the matrix -- against the float resampler above followed by the float matrix.  STATED BOUND: 8.5
+    levels worst case, 1.6 on average: the planes themselves agree with the float resampler to 2 levels (first
+    test of this file), the matrix multiplies a chroma error by up to 2.017 (B) and a luma error by 1.164, and the
+    recalled tables sit 1.8 levels dark: 2 x 2.017 + 2 x 1.164 + 1.8."""
+    iw, ih, ow, oh = 96, 54, 200, 112
+    g = tts.parse_vf("scale=%d:%d,format=rgb24" % (ow, oh), iw, ih)
+    src = synth.frames("limited", iw, ih, 1)
+    got = oracle.run_chain(g, src).reshape(oh, ow, 3).astype(np.float64)
+    y, u, v = synth.split(src[0], iw, ih)
+    yf = float_plane(y, ow, oh, "bicubic")
+    uf = np.repeat(float_plane(u, (ow + 1) // 2, oh, "bicubic"), 2, 1)[:, :ow] - 128
+    vf_ = np.repeat(float_plane(v, (ow + 1) // 2, oh, "bicubic"), 2, 1)[:, :ow] - 128
+    yy = 255.0 / 219.0 * (yf - 16)
+    ref = np.clip(np.stack([yy + 1.596027 * vf_, yy - 0.391762 * uf - 0.812968 * vf_, yy + 2.017232 * uf], -1), 0, 255)
+    d = np.abs(got - ref)[8:, 8:]                              # (first outputs of an enlarged axis: see above)
+    assert d.max() <= 8.5 and d.mean() < 1.6, (d.max(), d.mean())
