@@ -259,4 +259,28 @@ void build_range_lut(int out_range, bool chroma, unsigned char lut[256])
     }
 }
 
+// The same step as clip_u8((p * mul + add) >> shift): p << 7 folds into the multiplier, and
+// floor((floor(X / 2^a) + 64) / 128) == floor((X + 64 * 2^a) / 2^(a + 7)); the input clamp of the *ToJpeg forms
+// only acts where the result is 255 already.  Checked against the table for every byte; false = no such form.
+bool range_affine(int out_range, bool chroma, int &mul, int &add, int &shift)
+{
+    if (out_range == TTS_RANGE_TO_FULL) {
+        if (chroma) { mul = 128 * 4663; add = -9289992 + (64 << 12); shift = 19; }
+        else        { mul = 128 * 19077; add = -39057361 + (64 << 14); shift = 21; }
+    } else if (out_range == TTS_RANGE_TO_LIMITED) {
+        if (chroma) { mul = 128 * 1799; add = 4081085 + (64 << 11); shift = 18; }
+        else        { mul = 128 * 14071; add = 33561947 + (64 << 14); shift = 21; }
+    } else {
+        return false;
+    }
+    unsigned char lut[256];
+    build_range_lut(out_range, chroma, lut);
+    for (int p = 0; p < 256; ++p) {
+        int v = (p * mul + add) >> shift;
+        v = v < 0 ? 0 : v > 255 ? 255 : v;
+        if (v != lut[p]) return false;
+    }
+    return true;
+}
+
 }  // namespace tts

@@ -30,6 +30,7 @@ int  check_geom(const tts_geom &g);
 // (1-tap H pass: v = p << 7; lum/chrRangeToJpeg_c or ...FromJpeg_c on the 15-bit value; 1-tap V
 // pass: (v + 64) >> 7, clipped).  A function of one byte, so a 256-entry table per plane class.
 void build_range_lut(int out_range, bool chroma, unsigned char lut[256]);
+bool range_affine(int out_range, bool chroma, int &mul, int &add, int &shift);   // the same step in closed form, verified against the table
 
 // "-vf" chain parser; err receives a one-line reason on failure.
 int  parse_vf(const char *vf, int iw, int ih, tts_geom &g, std::string &err);

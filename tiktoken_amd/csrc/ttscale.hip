@@ -75,6 +75,22 @@ int tts_plan_create(const tts_geom *g, tts_plan **out)
         return TTS_OK;
     }
     for (int ci = 0; ci < 2 && rc == TTS_OK; ++ci) rc = build_class(*g, ci, p->cls[ci], tab);
+    // Column walk: luma and chroma ratios differ by a rounding, so their tap counts may straddle an
+    // instantiation boundary (720x1280 -> 101x180: 16 tap pairs luma, 14 chroma) and the chain would take two
+    // launches.  The class with fewer is rebuilt with the other's window: a seventh more arithmetic on a third
+    // of the samples against one launch less on a path that is one thumbnail per call in the reference.
+    if (rc == TTS_OK && p->cls[0].kind == 2 && p->cls[1].kind == 2 && p->cls[0].NTP != p->cls[1].NTP &&
+        std::abs(p->cls[0].NTP - p->cls[1].NTP) <= 2 && !p->knobs.no_merge) {
+        const int lo = p->cls[0].NTP < p->cls[1].NTP ? 0 : 1, want = p->cls[1 - lo].NTP;
+        free_class(p->cls[lo]);
+        p->cls[lo] = ClassPlan();
+        rc = build_class(*g, lo, p->cls[lo], tab, want);
+        if (rc == TTS_OK && p->cls[lo].kind != 2) {         // (the wider window does not fit this class's rows: as it was)
+            free_class(p->cls[lo]);
+            p->cls[lo] = ClassPlan();
+            rc = build_class(*g, lo, p->cls[lo], tab);
+        }
+    }
     if (rc == TTS_OK && !upload(p->d_tab, tab)) rc = TTS_ERR_INITIALIZATION_FAILED;
     if (rc) {
         if (rc == TTS_ERR_INITIALIZATION_FAILED) g_last_error = "table upload failed (hipMalloc / hipMemcpy)";

@@ -65,6 +65,17 @@ __device__ __forceinline__ uint32_t hfinish(int acc)
     return uint32_t(acc < 32767 ? acc : 32767);
 }
 
+// two int16 -> two clipped bytes in bits 0..15 (bits 16..31 zero).  Inline asm on purpose: hipcc matches
+// "shift right, clamp to 0..255, pack" written in C++ to gfx950's v_ashr_pk_u8_i32, whose result carried
+// non-zero bits 16..31 on MI355X (seen as bytes 2 and 3 of a packed dword OR-ed with garbage in the range
+// epilogue's first version); an asm statement is opaque to that pattern.
+__device__ __forceinline__ uint32_t sat_pk_u8(uint32_t packed_i16)
+{
+    uint32_t r;
+    asm("v_sat_pk_u8_i16 %0, %1" : "=v"(r) : "v"(packed_i16));
+    return r;
+}
+
 // four vertical sums -> four clipped bytes (val >> 19, clip to 0..255)
 __device__ __forceinline__ uint32_t pack4(int v0, int v1, int v2, int v3)
 {

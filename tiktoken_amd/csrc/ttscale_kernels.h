@@ -25,11 +25,70 @@ struct StripClass {
     uint32_t src_row_rel;          // bytes from that origin to the end of its row
 };
 
+// The range step of `format=yuvj420p` (or back) as a closed form per plane class, applied to the finished
+// byte in the scaler's store epilogue: clip_u8((p * mul + add) >> shift) -- what swscale's second, unscaled
+// pass computes (p << 7, lum/chrRangeToJpeg_c, (v + 64) >> 7), folded (the host checks it against
+// build_range_lut for all 256 values before a plan uses it).
+struct RangeStep { int32_t on; int32_t mul[2], add[2], shift[2]; };
+
+// The pad border of one plane class, written by extra workgroups of the SAME launch (they follow the scaler's
+// workgroups in the logical block order): a workgroup takes `blockDim / 64` canvas rows x 256 columns of one
+// plane and stores the fill byte (already range-mapped) wherever the picture is not.
+struct PadClass {
+    int32_t w, h, stride;              // canvas of this plane class
+    int32_t px, py, pw, ph;            // picture rectangle that is left alone
+    int32_t planes, plane0;
+    int32_t chunks, rowgroups;         // 256-column chunks per row, groups of blockDim / 64 rows
+    uint32_t origin;                   // bytes from the canvas origin to the picture origin (frame offsets point at the picture)
+    uint32_t nblocks;
+    int32_t fill[3];
+};
+
 struct StripArgs {
     StripClass c[2];
     uint64_t src_span, dst_span;   // bytes reachable from the base pointers (buffer range check)
+    RangeStep range;
+    PadClass pad[2];
+    uint32_t scaler_blocks;        // logical blocks [0, scaler_blocks) scale, the rest fill pad borders
     FrameAddr addr;
 };
+
+__device__ __forceinline__ void pad_fill_blocks(const StripArgs &a, uint8_t *dst, uint32_t fb)
+{
+    const int k = fb >= a.pad[0].nblocks ? 1 : 0;
+    if (k) fb -= a.pad[0].nblocks;
+    const PadClass &c = a.pad[k];
+    const int chunk = int(fb % uint32_t(c.chunks));
+    const uint32_t rest = fb / uint32_t(c.chunks);
+    const int rg = int(rest % uint32_t(c.rowgroups)), fp = int(rest / uint32_t(c.rowgroups));
+    const int x = chunk * 256 + int(threadIdx.x & 63) * 4;
+    const int y = rg * int(blockDim.x >> 6) + int(threadIdx.x >> 6);
+    if (x >= c.w || y >= c.h) return;
+    const int plane = c.plane0 + fp % c.planes, frame = fp / c.planes;
+    const size_t doff = (a.addr.use_table ? size_t(a.addr.dst_tab[plane][frame])
+                                          : size_t(frame) * a.addr.dst_pitch + a.addr.dst_plane[plane]) - c.origin;
+    uint8_t *row = dst + doff + size_t(y) * size_t(c.stride);
+    const uint8_t f = uint8_t(c.fill[plane]);
+    const bool in_rows = y >= c.py && y < c.py + c.ph;
+    for (int i = x; i < min(x + 4, c.w); ++i)
+        if (!(in_rows && i >= c.px && i < c.px + c.pw)) row[i] = f;
+}
+
+// the range step on one finished byte / on four packed bytes ((p * mul + add) >> shift lies within int16:
+// -20 .. 280 for the four forms of filter.cpp; the clip is v_sat_pk_u8_i16's)
+__device__ __forceinline__ int range_byte(int p, int mul, int add, int shift)
+{
+    const int v = (p * mul + add) >> shift;
+    return int(sat_pk_u8(uint32_t(v) & 0xffffu));
+}
+__device__ __forceinline__ uint32_t range_bytes4(uint32_t o, int mul, int add, int shift)
+{
+    const int v0 = (int(o & 255u) * mul + add) >> shift, v1 = (int((o >> 8) & 255u) * mul + add) >> shift;
+    const int v2 = (int((o >> 16) & 255u) * mul + add) >> shift, v3 = (int(o >> 24) * mul + add) >> shift;
+    const uint32_t lo = sat_pk_u8((uint32_t(v0) & 0xffffu) | (uint32_t(v1) << 16));
+    const uint32_t hi = sat_pk_u8((uint32_t(v2) & 0xffffu) | (uint32_t(v3) << 16));
+    return lo | (hi << 16);
+}
 
 // Where this lane's plane lies.  Lane offsets are 32-bit, a launch is not: in packed mode every wave
 // addresses from ITS first frame (lanes are ordered by frame, so that is lane 0's; the host checks that
@@ -104,7 +163,10 @@ __global__ __launch_bounds__(kBlock) void strip_kernel(const uint8_t *__restrict
     static_assert(!G4 || LW == 4, "grouped windows carry at most 4 taps");
     using RW = RowWin<LW, N, G4>;
 
-    uint32_t lb = xcd_remap(blockIdx.x, gridDim.x);
+    // (pad workgroups come last in dispatch order and are left out of the XCD remap: remapped with the
+    // rest they would fill whole XCDs by themselves and leave the scaler the others -- 4.5x slower thumbnails)
+    if (blockIdx.x >= a.scaler_blocks) { pad_fill_blocks(a, dst, blockIdx.x - a.scaler_blocks); return; }
+    uint32_t lb = xcd_remap(blockIdx.x, a.scaler_blocks);
     const int ci = lb >= a.c[0].nblocks ? 1 : 0;
     if (ci) lb -= a.c[0].nblocks;
     const StripClass &c = a.c[ci];
@@ -214,6 +276,10 @@ __global__ __launch_bounds__(kBlock) void strip_kernel(const uint8_t *__restrict
                         v[j] = acc;
                     }
                     o[q] = pack4(v[0], v[1], v[2], v[3]);
+                }
+                if (a.range.on) {                               // wave-uniform
+#pragma unroll
+                    for (int q = 0; q < N / 4; ++q) o[q] = range_bytes4(o[q], a.range.mul[ci], a.range.add[ci], a.range.shift[ci]);
                 }
                 const int outoff = y * c.dst_stride;
                 if (all_full || cols == N) {
@@ -407,7 +473,8 @@ __global__ __launch_bounds__(kMaxLdsBlock, (GC == 4 && R == 4 && LW == 4) ? 8 : 
     extern __shared__ __attribute__((aligned(16))) uint8_t lds_raw[];      // (blockDim.x / 64) x D slots
     uint8_t (*lds)[D][kSlotBytes] = reinterpret_cast<uint8_t (*)[D][kSlotBytes]>(lds_raw);
 
-    uint32_t lb = xcd_remap(blockIdx.x, gridDim.x);
+    if (blockIdx.x >= a.scaler_blocks) { pad_fill_blocks(a, dst, blockIdx.x - a.scaler_blocks); return; }   // (whole workgroups: no barrier is skipped; see strip_kernel)
+    uint32_t lb = xcd_remap(blockIdx.x, a.scaler_blocks);
     const int ci = lb >= a.c[0].nblocks ? 1 : 0;
     if (ci) lb -= a.c[0].nblocks;
     const StripClass &c = a.c[ci];
@@ -500,6 +567,8 @@ __global__ __launch_bounds__(kMaxLdsBlock, (GC == 4 && R == 4 && LW == 4) ? 8 : 
     const int dst_stride = int(uni(uint32_t(c.dst_stride)));
     const int last_y = c.oh - 1;
     const bool bar = c.paced != 0;
+    const bool rng = a.range.on != 0;
+    const int rmul = a.range.mul[ci], radd = a.range.add[ci], rsh = a.range.shift[ci];
 
     const __amdgpu_buffer_rsrc_t srs = __builtin_amdgcn_make_buffer_rsrc(const_cast<uint8_t *>(wsrc), 0, src_rec, 0x00020000);
     const uint64_t dbase = reinterpret_cast<uint64_t>(wdst);
@@ -616,6 +685,7 @@ __global__ __launch_bounds__(kMaxLdsBlock, (GC == 4 && R == 4 && LW == 4) ? 8 : 
                     }
                     o[q] = pack4(v[0], v[1], v[2], v[3]);
                 }
+                if (rng) { o[0] = range_bytes4(o[0], rmul, radd, rsh); o[1] = range_bytes4(o[1], rmul, radd, rsh); }   // wave-uniform
                 if (bar) asm volatile("s_barrier" ::: "memory");
                 store_b64(u32x2_t{o[0], o[1]}, drs, doff, y * dst_stride);
                 ++y;
@@ -700,7 +770,10 @@ __global__ __launch_bounds__(kBlock) void column_lds_kernel(const uint8_t *__res
     constexpr int kSlotBytes = NDMA * 1024 + 16;
     __shared__ __attribute__((aligned(16))) uint8_t lds[kBlock / 64][D][kSlotBytes];
 
-    uint32_t lb = xcd_remap(blockIdx.x, gridDim.x);
+    // (pad workgroups come last in dispatch order and are left out of the XCD remap: remapped with the
+    // rest they would fill whole XCDs by themselves and leave the scaler the others -- 4.5x slower thumbnails)
+    if (blockIdx.x >= a.scaler_blocks) { pad_fill_blocks(a, dst, blockIdx.x - a.scaler_blocks); return; }
+    uint32_t lb = xcd_remap(blockIdx.x, a.scaler_blocks);
     const int ci = lb >= a.c[0].nblocks ? 1 : 0;
     if (ci) lb -= a.c[0].nblocks;
     const StripClass &c = a.c[ci];
@@ -764,6 +837,8 @@ __global__ __launch_bounds__(kBlock) void column_lds_kernel(const uint8_t *__res
     const uint32_t *vco  = tab + c.vcoef;
     int y = seg * c.seg_rows;
     const int dst_stride = int(uni(uint32_t(c.dst_stride)));
+    const bool rng = a.range.on != 0;
+    const int rmul = a.range.mul[ci], radd = a.range.add[ci], rsh = a.range.shift[ci];
 
     const __amdgpu_buffer_rsrc_t srs = __builtin_amdgcn_make_buffer_rsrc(const_cast<uint8_t *>(wsrc), 0, src_rec, 0x00020000);
     const uint64_t dbase = reinterpret_cast<uint64_t>(wdst);
@@ -822,10 +897,16 @@ __global__ __launch_bounds__(kBlock) void column_lds_kernel(const uint8_t *__res
                 }
                 const int yoff = int(uni(uint32_t(y * dst_stride)));
                 if constexpr (NC == 4) {
-                    store_b32(pack4(v[0], v[1], v[2], v[3]), drs, doff, yoff);
+                    uint32_t o4 = pack4(v[0], v[1], v[2], v[3]);
+                    if (rng) o4 = range_bytes4(o4, rmul, radd, rsh);
+                    store_b32(o4, drs, doff, yoff);
                 } else {
 #pragma unroll
                     for (int j = 0; j < NC; ++j) { v[j] >>= 19; v[j] = v[j] < 0 ? 0 : v[j] > 255 ? 255 : v[j]; }
+                    if (rng) {                                  // wave-uniform
+#pragma unroll
+                        for (int j = 0; j < NC; ++j) v[j] = range_byte(v[j], rmul, radd, rsh);
+                    }
                     if constexpr (NC == 2) store_b16(uint32_t(v[0]) | (uint32_t(v[1]) << 8), drs, doff, yoff);
                     else store_b8(uint32_t(v[0]), drs, doff, yoff);
                 }

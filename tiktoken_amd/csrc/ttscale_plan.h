@@ -199,7 +199,9 @@ int lds_dmas(const ClassPlan &c, const HTables &t, int N, const int *lo, int nw,
     return worst <= 64u ? 1 : worst <= 128u ? 2 : (four && worst <= 256u) ? 4 : 0;
 }
 
-int build_class(const tts_geom &g, int sub, ClassPlan &c, std::vector<uint32_t> &tab)
+// min_ntp: column walk only -- at least this many tap pairs (so that both classes of a chain can run the same
+// instantiation, i.e. one launch: see tts_plan_create)
+int build_class(const tts_geom &g, int sub, ClassPlan &c, std::vector<uint32_t> &tab, int min_ntp = 0)
 {
     c.sub = sub;
     c.src_w = ceil_shift(g.pre_w, sub); c.src_h = ceil_shift(g.pre_h, sub);
@@ -229,7 +231,7 @@ int build_class(const tts_geom &g, int sub, ClassPlan &c, std::vector<uint32_t> 
         // (windows of 2 NTP bytes, ring of 2 NTP rows) -- the work is one v_perm + v_dot2 per tap pair per
         // source row, so a window cut to fit the taps is that much less arithmetic
         const int mt = std::max(HT, VT);
-        const int NTP = std::max(6, ((mt + 1) / 2 + 1) & ~1), Rc = 2 * NTP;
+        const int NTP = std::max(std::max(6, ((mt + 1) / 2 + 1) & ~1), min_ntp), Rc = 2 * NTP;
         if (HT > 64 || VT > 64 || c.src_w < 2 * NTP || !monotone(c.v.pos) || env_int("TTS_FORCE_GENERIC", 0)) return TTS_OK;
         HTables t;                                     // (only `strips` is used by lds_dmas)
         t.strips = c.ow;
@@ -685,9 +687,47 @@ int launch_all(const tts_plan *p, const uint8_t *src, uint8_t *dst, int n, const
     auto active  = [&](int ci) { return only_plane < 0 || ci == (only_plane ? 1 : 0); };
     auto nplanes = [&](int ci) { return only_plane < 0 ? (ci ? 2 : 1) : 1; };
     auto plane0  = [&](int ci) { return only_plane < 0 ? (ci ? 1 : 0) : only_plane; };
+    // Which classes take the generic kernel in this launch set?  Their pad border and range step stay kernels
+    // of their own (fill_kernel before, range_kernel after); the strip and column walks carry both themselves:
+    // the border is written by extra workgroups of the scaler's launch, the range step sits in its store
+    // epilogue, so the reference's thumbnail chain (src/services/video.js:329-334) is ONE launch.
+    bool to_generic[2] = {false, false};
+    for (int ci = 0; ci < 2; ++ci) {
+        const ClassPlan &c = p->cls[ci];
+        if (c.kind == 0) to_generic[ci] = true;
+        if (c.kind == 2 && (src_span < 4096u || (addr.use_table && (c.segs[0].nseg < 2 || c.segs[0].spans_plane || c.src_w < 48 || c.src_h < 32)))) to_generic[ci] = true;
+    }
+    RangeStep range{};
+    if (p->g.out_range != TTS_RANGE_KEEP) {
+        range.on = 1;
+        for (int ci = 0; ci < 2; ++ci)
+            if (!tts::range_affine(p->g.out_range, ci != 0, range.mul[ci], range.add[ci], range.shift[ci])) range.on = 0;
+    }
+    const bool fuse_range = range.on != 0;             // (always, with the constants of filter.cpp; else every class keeps range_kernel)
+    auto pad_class = [&](int ci, int threads, PadClass &pc) {
+        const ClassPlan &c = p->cls[ci];
+        pc = PadClass{};
+        if (!p->g.do_pad) return;
+        if (c.pad_x == 0 && c.pad_y == 0 && c.ow == c.canvas_w && c.oh == c.canvas_h) return;   // the picture fills the canvas (1080p -> 320x180): no border
+        pc.w = c.canvas_w; pc.h = c.canvas_h; pc.stride = dst_stride[ci];
+        pc.px = c.pad_x; pc.py = c.pad_y; pc.pw = c.ow; pc.ph = c.oh;
+        pc.planes = nplanes(ci); pc.plane0 = plane0(ci);
+        pc.chunks = (c.canvas_w + 255) / 256; pc.rowgroups = (c.canvas_h + threads / 64 - 1) / (threads / 64);
+        pc.origin = uint32_t(c.pad_y) * uint32_t(dst_stride[ci]) + uint32_t(c.pad_x);
+        const int fill[3] = {p->g.fill_y, p->g.fill_u, p->g.fill_v};
+        for (int k = 0; k < 3; ++k) {
+            pc.fill[k] = fill[k];
+            if (fuse_range) {                          // the border goes through the range step like every other byte
+                unsigned char lut[256];
+                tts::build_range_lut(p->g.out_range, k != 0, lut);
+                pc.fill[k] = lut[fill[k] & 255];
+            }
+        }
+        pc.nblocks = uint32_t(pc.chunks) * uint32_t(pc.rowgroups) * uint32_t(n) * uint32_t(pc.planes);
+    };
     if (p->g.do_pad) {
         for (int ci = 0; ci < 2; ++ci) {
-            if (!active(ci)) continue;
+            if (!active(ci) || !to_generic[ci]) continue;
             const ClassPlan &c = p->cls[ci];
             FillArgs f{};
             f.dst = dst; f.w = c.canvas_w; f.h = c.canvas_h; f.stride = dst_stride[ci];
@@ -759,21 +799,26 @@ int launch_all(const tts_plan *p, const uint8_t *src, uint8_t *dst, int n, const
             fill_strip_class(p, ci, n, ch.N, ch.g4, ch.LW, src_stride[ci], dst_stride[ci], p->cls[ci].segs[si[0]], bs.threads, bs.paced, nplanes(ci), plane0(ci), a.c[0]);
             a.c[1] = a.c[0]; a.c[1].nblocks = 0;
         }
-        const uint32_t blocks = a.c[0].nblocks + (merged ? a.c[1].nblocks : 0);
+        a.scaler_blocks = a.c[0].nblocks + (merged ? a.c[1].nblocks : 0);
+        if (fuse_range) a.range = range;
+        if (merged) { pad_class(0, bs.threads, a.pad[0]); pad_class(1, bs.threads, a.pad[1]); }
+        else {
+            pad_class(ci, bs.threads, a.pad[0]);
+            if (fuse_range && ci) { a.range.mul[0] = range.mul[1]; a.range.add[0] = range.add[1]; a.range.shift[0] = range.shift[1]; }   // (a single class rides in slot 0)
+        }
+        const uint32_t blocks = a.scaler_blocks + a.pad[0].nblocks + a.pad[1].nblocks;
         if (const int rc = launch_checked("strip kernel", fn, dim3(blocks), dim3(bs.threads), bs.lds_bytes, st, src, dst, p->d_tab, a)) return rc;
         if (merged) break;
     }
 
     // column classes (9..64 taps): one launch when both classes run the same instantiation
-    bool to_generic[2] = {false, false};               // column classes this launch hands to the generic kernel instead
     {
         int col_cls[2], nc = 0;
         for (int ci = 0; ci < 2; ++ci) {
             const ClassPlan &c = p->cls[ci];
             if (c.kind != 2 || !active(ci)) continue;
-            // (per-frame plane pointers: see the strip classes above; tiny sources likewise)
-            if (src_span < 4096u || (addr.use_table && (c.segs[0].nseg < 2 || c.segs[0].spans_plane || c.src_w < 48 || c.src_h < 32))) to_generic[ci] = true;
-            else col_cls[nc++] = ci;
+            // (per-frame plane pointers: see the strip classes above; tiny sources likewise: to_generic, decided above)
+            if (!to_generic[ci]) col_cls[nc++] = ci;
         }
         const int min_segs = addr.use_table ? 2 : 1;
         ColMode cm[2] = {{p->cls[0].col_nc, p->cls[0].col_dmas}, {p->cls[1].col_nc, p->cls[1].col_dmas}};
@@ -819,7 +864,14 @@ int launch_all(const tts_plan *p, const uint8_t *src, uint8_t *dst, int n, const
                 fill_column_class(p, ci, cm[ci], n, src_stride[ci], dst_stride[ci], p->cls[ci].segs[si], nplanes(ci), plane0(ci), a.c[0]);
                 a.c[1] = a.c[0]; a.c[1].nblocks = 0;
             }
-            const uint32_t blocks = a.c[0].nblocks + (cmerged ? a.c[1].nblocks : 0);
+            a.scaler_blocks = a.c[0].nblocks + (cmerged ? a.c[1].nblocks : 0);
+            if (fuse_range) a.range = range;
+            if (cmerged) { pad_class(0, kBlock, a.pad[0]); pad_class(1, kBlock, a.pad[1]); }
+            else {
+                pad_class(ci, kBlock, a.pad[0]);
+                if (fuse_range && ci) { a.range.mul[0] = range.mul[1]; a.range.add[0] = range.add[1]; a.range.shift[0] = range.shift[1]; }
+            }
+            const uint32_t blocks = a.scaler_blocks + a.pad[0].nblocks + a.pad[1].nblocks;
             if (const int rc = launch_checked("column kernel", fn, dim3(blocks), dim3(kBlock), 0, st, src, dst, p->d_tab, a)) return rc;
             if (cmerged) break;
         }
@@ -827,7 +879,7 @@ int launch_all(const tts_plan *p, const uint8_t *src, uint8_t *dst, int n, const
 
     for (int ci = 0; ci < 2; ++ci) {
         const ClassPlan &c = p->cls[ci];
-        if (!(c.kind == 0 || to_generic[ci]) || !active(ci)) continue;
+        if (!to_generic[ci] || !active(ci)) continue;
         GenericArgs a{};
         a.src = src; a.dst = dst;
         a.hpos = c.d_hpos; a.htaps = c.d_htaps; a.vpos = c.d_vpos; a.vtaps = c.d_vtaps;
@@ -845,7 +897,7 @@ int launch_all(const tts_plan *p, const uint8_t *src, uint8_t *dst, int n, const
     }
     if (p->g.out_range != TTS_RANGE_KEEP) {
         for (int ci = 0; ci < 2; ++ci) {
-            if (!active(ci)) continue;
+            if (!active(ci) || (fuse_range && !to_generic[ci])) continue;
             const ClassPlan &c = p->cls[ci];
             RangeArgs r{};
             r.dst = dst; r.w = c.canvas_w; r.h = c.canvas_h; r.stride = dst_stride[ci];

@@ -248,12 +248,6 @@ struct RgbStripArgs {
     FrameAddr addr;
 };
 
-__device__ __forceinline__ uint32_t sat_pk_u8(uint32_t packed_i16)
-{
-    uint32_t r;
-    asm("v_sat_pk_u8_i16 %0, %1" : "=v"(r) : "v"(packed_i16));
-    return r;
-}
 // two 32-bit sums -> their high halves (sum >> 16) clipped to bytes, in bits 0..15
 __device__ __forceinline__ uint32_t hi2_u8(int a, int b)
 {
