@@ -5,6 +5,8 @@ import os
 
 HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(HERE, "libttscale.so")
+if os.environ.get("TTS_LIB"):          # tools only: an experiments build (make -C tiktoken_amd/csrc exp)
+    LIB_PATH = os.environ["TTS_LIB"]
 
 
 class Geom(ctypes.Structure):

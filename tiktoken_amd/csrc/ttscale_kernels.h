@@ -50,6 +50,7 @@ struct StripArgs {
     RangeStep range;
     PadClass pad[2];
     uint32_t scaler_blocks;        // logical blocks [0, scaler_blocks) scale, the rest fill pad borders
+    uint64_t *dbg;                 // -DTTS_EXPERIMENTS builds: (start, end) clock of every workgroup of strip_lds_kernel; else null, unused
     FrameAddr addr;
 };
 
@@ -78,13 +79,13 @@ __device__ __forceinline__ void pad_fill_blocks(const StripArgs &a, uint8_t *dst
 // -20 .. 280 for the four forms of filter.cpp; the clip is v_sat_pk_u8_i16's)
 __device__ __forceinline__ int range_byte(int p, int mul, int add, int shift)
 {
-    const int v = (p * mul + add) >> shift;
+    const int v = (__mul24(p, mul) + add) >> shift;          // (p < 2^8, mul < 2^23: the full-rate 24-bit multiply)
     return int(sat_pk_u8(uint32_t(v) & 0xffffu));
 }
 __device__ __forceinline__ uint32_t range_bytes4(uint32_t o, int mul, int add, int shift)
 {
-    const int v0 = (int(o & 255u) * mul + add) >> shift, v1 = (int((o >> 8) & 255u) * mul + add) >> shift;
-    const int v2 = (int((o >> 16) & 255u) * mul + add) >> shift, v3 = (int(o >> 24) * mul + add) >> shift;
+    const int v0 = (__mul24(int(o & 255u), mul) + add) >> shift, v1 = (__mul24(int((o >> 8) & 255u), mul) + add) >> shift;
+    const int v2 = (__mul24(int((o >> 16) & 255u), mul) + add) >> shift, v3 = (__mul24(int(o >> 24), mul) + add) >> shift;
     const uint32_t lo = sat_pk_u8((uint32_t(v0) & 0xffffu) | (uint32_t(v1) << 16));
     const uint32_t hi = sat_pk_u8((uint32_t(v2) & 0xffffu) | (uint32_t(v3) << 16));
     return lo | (hi << 16);
@@ -475,6 +476,9 @@ __global__ __launch_bounds__(kMaxLdsBlock, (GC == 4 && R == 4 && LW == 4) ? 8 : 
 
     if (blockIdx.x >= a.scaler_blocks) { pad_fill_blocks(a, dst, blockIdx.x - a.scaler_blocks); return; }   // (whole workgroups: no barrier is skipped; see strip_kernel)
     uint32_t lb = xcd_remap(blockIdx.x, a.scaler_blocks);
+#ifdef TTS_EXPERIMENTS
+    if (a.dbg && threadIdx.x == 0) a.dbg[2 * blockIdx.x] = __builtin_amdgcn_s_memrealtime();
+#endif
     const int ci = lb >= a.c[0].nblocks ? 1 : 0;
     if (ci) lb -= a.c[0].nblocks;
     const StripClass &c = a.c[ci];
@@ -693,6 +697,9 @@ __global__ __launch_bounds__(kMaxLdsBlock, (GC == 4 && R == 4 && LW == 4) ? 8 : 
             hist[s % D] = cnt;
         }
     }
+#ifdef TTS_EXPERIMENTS
+    if (a.dbg && threadIdx.x == 0) a.dbg[2 * blockIdx.x + 1] = __builtin_amdgcn_s_memrealtime();
+#endif
 #endif
 }
 

@@ -120,6 +120,27 @@ struct Knobs {
     }
 };
 
+#ifdef TTS_EXPERIMENTS
+// workgroup timeline of the last strip launch (tools/timeline.py): 2 clocks per workgroup, 100 MHz
+static uint64_t *g_exp_dbg = nullptr;
+static uint32_t g_exp_dbg_blocks = 0;
+static uint64_t *exp_dbg_buffer(uint32_t blocks)
+{
+    constexpr uint32_t kCap = 1u << 20;
+    if (!std::getenv("TTS_EXP_TIMELINE") || blocks > kCap) { g_exp_dbg_blocks = 0; return nullptr; }
+    if (!g_exp_dbg && hipMalloc(reinterpret_cast<void **>(&g_exp_dbg), size_t(kCap) * 16) != hipSuccess) return nullptr;
+    g_exp_dbg_blocks = blocks;
+    return g_exp_dbg;
+}
+extern "C" int tts_exp_timeline(uint64_t *out, uint32_t cap)
+{
+    if (!g_exp_dbg || !g_exp_dbg_blocks) return 0;
+    const uint32_t n = std::min(cap, g_exp_dbg_blocks);
+    if (hipMemcpy(out, g_exp_dbg, size_t(n) * 16, hipMemcpyDeviceToHost) != hipSuccess) return -1;
+    return int(n);
+}
+#endif
+
 struct tts_plan {
     tts_geom g;
     Knobs knobs;
@@ -800,6 +821,9 @@ int launch_all(const tts_plan *p, const uint8_t *src, uint8_t *dst, int n, const
             a.c[1] = a.c[0]; a.c[1].nblocks = 0;
         }
         a.scaler_blocks = a.c[0].nblocks + (merged ? a.c[1].nblocks : 0);
+#ifdef TTS_EXPERIMENTS
+        a.dbg = exp_dbg_buffer(a.scaler_blocks);
+#endif
         if (fuse_range) a.range = range;
         if (merged) { pad_class(0, bs.threads, a.pad[0]); pad_class(1, bs.threads, a.pad[1]); }
         else {
