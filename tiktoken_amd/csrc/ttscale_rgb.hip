@@ -241,6 +241,7 @@ struct RgbStripArgs {
     uint32_t seginfo;                  // [nseg][2]: first luma / chroma source row of the segment's ring fill (may be < 0: clamped, zero taps)
     int32_t strips, n_items, nseg, seg_rows, ph, pw;
     int32_t src_h_l, src_h_c;          // rows of the (pre-cropped) source planes
+    uint32_t end_rel[2];               // luma / chroma: bytes from a plane's (pre-cropped) origin to one past its last byte
     int32_t src_stride_y, src_stride_c, dst_stride;
     int32_t swap;
     uint64_t src_span, dst_span;
@@ -249,17 +250,118 @@ struct RgbStripArgs {
 };
 
 // two 32-bit sums -> their high halves (sum >> 16) clipped to bytes, in bits 0..15
-__device__ __forceinline__ uint32_t hi2_u8(int a, int b)
+[[maybe_unused]] __device__ __forceinline__ uint32_t hi2_u8(int a, int b)
 {
     return sat_pk_u8(__builtin_amdgcn_perm(uint32_t(b), uint32_t(a), 0x07060302));
 }
-__device__ __forceinline__ int clip255(int v) { return v < 0 ? 0 : v > 255 ? 255 : v; }   // (v_med3_i32)
+[[maybe_unused]] __device__ __forceinline__ int clip255(int v) { return v < 0 ? 0 : v > 255 ? 255 : v; }   // (v_med3_i32)
 
-template <int BPP>
-__global__ __launch_bounds__(kBlock) void rgb_strip_kernel(const uint8_t *__restrict__ src, uint8_t *__restrict__ dst,
+// ---- LDS staging of the source rows (LDS = true) --------------------------------------------------------
+// With plain per-lane window loads the kernel ran at 0.89 ms per 300 frames of 1080p -> portrait -> rgb24
+// although its instruction stream alone takes 0.50 ms, its loads alone 0.54 and its stores alone 0.55
+// (zero-record descriptors, experiments build): the window gathers and the stores fight over the vector L1.
+// So, as in the planar strip_lds_kernel, a wave fetches the run of source bytes that holds all of its lanes'
+// windows with ONE coalesced LDS-DMA per plane and source row (`buffer_load_dwordx4 ... lds`, 16 bytes a
+// lane, into the wave's own 1 KiB slot; one slot per plane), and the lanes pick their windows out of LDS as
+// aligned dwords.  Nothing in flight lives in VGPRs; the waits are ours and exact: before a row is read, wait
+// until only the vector-memory operations issued AFTER its DMA are outstanding (counted at run time; the
+// counter retires in issue order; a smaller count is always safe).
+typedef __attribute__((address_space(3))) void rgb_lds_t;
+[[maybe_unused]] constexpr int kRgbSlot = 1024 + 16;
+constexpr int kRgbMaxPieces = 8;
+
+[[maybe_unused]] __device__ __forceinline__ void rgb_wait_vm(int outstanding)
+{
+    switch (outstanding < 7 ? outstanding : 7) {
+    case 0: asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); break;
+    case 1: asm volatile("s_waitcnt vmcnt(1)" ::: "memory"); break;
+    case 2: asm volatile("s_waitcnt vmcnt(2)" ::: "memory"); break;
+    case 3: asm volatile("s_waitcnt vmcnt(3)" ::: "memory"); break;
+    case 4: asm volatile("s_waitcnt vmcnt(4)" ::: "memory"); break;
+    case 5: asm volatile("s_waitcnt vmcnt(5)" ::: "memory"); break;
+    case 6: asm volatile("s_waitcnt vmcnt(6)" ::: "memory"); break;
+    default: asm volatile("s_waitcnt vmcnt(7)" ::: "memory"); break;
+    }
+}
+
+// two 8-byte windows at any byte phase: the three aligned dwords that hold each, and the wait, in ONE asm
+// statement (no output register exists, as far as the compiler can tell, before its data has landed)
+[[maybe_unused]] __device__ __forceinline__ void rgb_lds_read2(uint32_t (&w)[2][3], uint32_t p0, uint32_t p1)
+{
+    asm volatile("ds_read_b32 %0, %6\n\tds_read_b32 %1, %6 offset:4\n\tds_read_b32 %2, %6 offset:8\n\t"
+                 "ds_read_b32 %3, %7\n\tds_read_b32 %4, %7 offset:4\n\tds_read_b32 %5, %7 offset:8\n\t"
+                 "s_waitcnt lgkmcnt(0)"
+                 : "=&v"(w[0][0]), "=&v"(w[0][1]), "=&v"(w[0][2]), "=&v"(w[1][0]), "=&v"(w[1][1]), "=&v"(w[1][2])
+                 : "v"(p0), "v"(p1) : "memory");
+}
+
+// The source run of one plane for this wave: one piece per frame row its 64 lanes touch (a new piece starts
+// at every lane whose strip is the first of a row, `new_row`), each rounded out to 16-byte chunks, packed
+// one after another into the wave's 64-chunk slot; chunk c is fetched by lane c.  In: this lane's bytes
+// [first, last) of the plane's row 0 (the DMA adds row * stride as its scalar offset), the plane's origin
+// `soff`, `end_rel` = bytes from that origin to one past the plane's last byte, `last_rowoff` = offset of the
+// plane's last row.  A run that would pass the plane's end on that last row is slid down to end exactly on
+// the piece's last byte (at the end of a launch's span the range check zero-fills whole dwords).  Packed
+// batches only: the bytes before a plane are the previous plane's.  Out: what this lane fetches; slot
+// position minus source offset for this lane's piece.
+[[maybe_unused]] __device__ __forceinline__ void rgb_plan_run(uint32_t first, uint32_t last, uint32_t soff, uint32_t end_rel, uint32_t last_rowoff,
+                                             bool new_row, int lane, uint32_t &csrc, uint32_t &lbase)
+{
+    uint64_t pm = __builtin_amdgcn_ballot_w64(new_row) | 1ull;
+    uint32_t prefix = 0;
+    lbase = 0;
+    csrc = ~0u;
+    for (int p = 0; p < kRgbMaxPieces && pm; ++p) {
+        const int l0 = __builtin_ctzll(pm);
+        pm &= pm - 1;
+        const int l1 = pm ? __builtin_ctzll(pm) : 64;
+        const uint32_t hi_abs = uint32_t(__builtin_amdgcn_readlane(int(soff), l0)) + end_rel;
+        const uint32_t end = uint32_t(__builtin_amdgcn_readlane(int(last), l1 - 1));
+        uint32_t start = uint32_t(__builtin_amdgcn_readlane(int(first), l0)) & ~15u;
+        const uint32_t n = (end - start + 15u) >> 4;
+        if (start + 16u * n + last_rowoff > hi_abs && end >= 16u * n) start = end - 16u * n;
+        if (lane >= l0 && lane < l1) lbase = 16u * prefix - start;
+        if (p == 0) csrc = start;                   // spare lanes re-fetch the first piece's first chunk
+        if (uint32_t(lane) >= prefix && uint32_t(lane) < prefix + n) csrc = start + 16u * (uint32_t(lane) - prefix);
+        prefix += n;
+    }
+    // the host picks the LDS variant only for geometries whose runs fit; anything else here would be silent corruption
+    if (pm || prefix > 64u) __builtin_trap();
+}
+
+// ---- whole-sector stores (XP = true) --------------------------------------------------------------------
+// A lane's 8 pixels are 24 (32) bytes; stored lane by lane (16 + 8 bytes at a stride of 24) every store
+// instruction touches every 64-byte sector of the wave's row piece and leaves it partly written: PMC showed
+// 24.9 L2 write requests per store instruction, twice what the bytes need, and the kernel ran at the speed of
+// those requests.  So the wave's output row goes through a small LDS exchange first: every lane writes its
+// bytes at lane * 24 (32), then lane j reads 16-byte chunk j (and chunk 64 + j) of that 1.5 (2) KiB string
+// and stores it: 1 KiB of whole sectors per instruction.  Chunk c of rgb24 comes from lane 16c / 24 and, when
+// it starts at byte 16 of that lane, ends in the next lane; where the two lanes' pixels are not neighbours in
+// memory (a wave's 64 strips wrap over frames once; the host sends other shapes to XP = false) that ONE chunk
+// is held back and stored as two 8-byte halves.
+[[maybe_unused]] __device__ __forceinline__ void rgb_lds_exchange3(uint32_t waddr, const uint32_t (&o)[6], uint32_t r1, uint32_t r2, u32x4_t &v1, u32x4_t &v2)
+{
+    asm volatile("ds_write_b64 %2, %3\n\tds_write_b64 %2, %4 offset:8\n\tds_write_b64 %2, %5 offset:16\n\t"
+                 "ds_read_b128 %0, %6\n\tds_read_b128 %1, %7\n\ts_waitcnt lgkmcnt(0)"
+                 : "=&v"(v1), "=&v"(v2)
+                 : "v"(waddr), "v"(u32x2_t{o[0], o[1]}), "v"(u32x2_t{o[2], o[3]}), "v"(u32x2_t{o[4], o[5]}), "v"(r1), "v"(r2) : "memory");
+}
+[[maybe_unused]] __device__ __forceinline__ void rgb_lds_exchange4(uint32_t waddr, const uint32_t (&o)[8], uint32_t r1, uint32_t r2, u32x4_t &v1, u32x4_t &v2)
+{
+    asm volatile("ds_write_b128 %2, %3\n\tds_write_b128 %2, %4 offset:16\n\t"
+                 "ds_read_b128 %0, %5\n\tds_read_b128 %1, %6\n\ts_waitcnt lgkmcnt(0)"
+                 : "=&v"(v1), "=&v"(v2)
+                 : "v"(waddr), "v"(u32x4_t{o[0], o[1], o[2], o[3]}), "v"(u32x4_t{o[4], o[5], o[6], o[7]}), "v"(r1), "v"(r2) : "memory");
+}
+
+template <int BPP, bool LDS, bool XP>
+__global__ __launch_bounds__(kBlock, 4) void rgb_strip_kernel(const uint8_t *__restrict__ src, uint8_t *__restrict__ dst,
                                                            const uint32_t *__restrict__ tab, const RgbStripArgs a)
 {
     static_assert(BPP == 3 || BPP == 4, "rgb24 / bgr24 or rgba / bgra");
+#if defined(__HIP_DEVICE_COMPILE__)   // the LDS-DMA builtin exists in the device pass only
+    __shared__ __attribute__((aligned(16))) uint8_t lds[LDS ? kBlock / 64 : 1][3][LDS ? kRgbSlot : 16];
+    __shared__ __attribute__((aligned(16))) uint8_t xlds[XP ? kBlock / 64 : 1][XP ? 64 * 8 * BPP : 16];   // the waves' output rows in exchange
     const uint32_t lb = xcd_remap(blockIdx.x, gridDim.x);
     const int seg = int(lb % uint32_t(a.nseg));
     const int sb  = int(lb / uint32_t(a.nseg));
@@ -290,6 +392,30 @@ __global__ __launch_bounds__(kBlock) void rgb_strip_kernel(const uint8_t *__rest
     }
     doff += uint32_t(min(strip * 8, a.pw - 8)) * BPP;        // the last strip is slid left, not cut short
     if (!live) doff = kDiscard;                               // the descriptor's range check drops these stores
+    // XP: where this lane's two chunks go (row offsets come as the stores' scalar offset), the held-back chunk
+    [[maybe_unused]] uint32_t dest1 = kDiscard, dest2 = kDiscard, dest_a = kDiscard, dest_b = kDiscard, xw = 0, xr1 = 0, xr2 = 0;
+    [[maybe_unused]] bool split_second = false, any_split = false;
+    if constexpr (XP) {
+        const int lane = int(threadIdx.x) & 63, xwave = int(threadIdx.x) >> 6;
+        constexpr int kChunks = 64 * 8 * BPP / 16;             // 96 (rgb24) or 128 (rgba)
+        const uint32_t xbase = uint32_t(reinterpret_cast<uintptr_t>((rgb_lds_t *)&xlds[xwave][0]));
+        xw = xbase + uint32_t(lane) * (8u * BPP);
+#pragma unroll
+        for (int q = 0; q < 2; ++q) {
+            const int c = lane + 64 * q;
+            const int cc = c < kChunks ? c : 0;                 // (lanes without a second chunk read chunk 0 and store nowhere)
+            const int L = 16 * cc / (8 * BPP), inner = 16 * cc - 8 * BPP * L;
+            uint32_t d = uint32_t(__builtin_amdgcn_ds_bpermute(L * 4, int(doff))) + uint32_t(inner);
+            if constexpr (BPP == 3) {
+                const uint32_t d0 = d - uint32_t(inner), dn = uint32_t(__builtin_amdgcn_ds_bpermute(min(L + 1, 63) * 4, int(doff)));
+                if (c < kChunks && inner == 16 && dn != d0 + 24u) { dest_a = d; dest_b = dn; split_second = q == 1; d = kDiscard; }
+            }
+            if (c >= kChunks) d = kDiscard;
+            (q ? dest2 : dest1) = d;
+            (q ? xr2 : xr1) = xbase + 16u * uint32_t(cc);
+        }
+        any_split = __builtin_amdgcn_ballot_w64(dest_a != kDiscard || dest_b != kDiscard) != 0;
+    }
 
     // per-lane horizontal tables stay in registers for the whole walk
     uint32_t offl[2], offu, offv, sell[8][2], coefl[8][2], selc[4][2], coefc[4][2];
@@ -321,13 +447,34 @@ __global__ __launch_bounds__(kBlock) void rgb_strip_kernel(const uint8_t *__rest
     int lrow = int(uni(tab[a.seginfo + 2 * seg])), crow = int(uni(tab[a.seginfo + 2 * seg + 1]));
     const int lmax = a.src_h_l - 1, cmax = a.src_h_c - 1;
     const int sy = int(uni(uint32_t(a.src_stride_y))), sc = int(uni(uint32_t(a.src_stride_c))), ds = int(uni(uint32_t(a.dst_stride)));
-    u32x2_t wl[2], wu, wv;                           // the next source rows, requested one row ahead
+    u32x2_t wl[2], wu, wv;                           // register variant: the next source rows, requested one row ahead
+    // LDS variant: what this lane fetches in each plane's DMA, where its windows lie in the slots, and the
+    // vector-memory operations issued since the pending luma DMA / since the pending chroma DMAs
+    [[maybe_unused]] uint32_t cs[3] = {0, 0, 0}, lposl[2] = {0, 0}, lposu = 0, lposv = 0;
+    [[maybe_unused]] int since_l = 0, since_c = 0;
+    [[maybe_unused]] const int wave = __builtin_amdgcn_readfirstlane(int(threadIdx.x) >> 6);
     {
         const int lo = min(max(lrow, 0), lmax) * sy, co = min(max(crow, 0), cmax) * sc;
-        wl[0] = __builtin_amdgcn_raw_buffer_load_b64(srs, offl[0], lo, 0);
-        wl[1] = __builtin_amdgcn_raw_buffer_load_b64(srs, offl[1], lo, 0);
-        wu = __builtin_amdgcn_raw_buffer_load_b64(srs, offu, co, 0);
-        wv = __builtin_amdgcn_raw_buffer_load_b64(srs, offv, co, 0);
+        if constexpr (LDS) {
+            const int lane = int(threadIdx.x) & 63;
+            const bool new_row = lane > 0 && strip == 0 && live;
+            uint32_t lbase[3];
+            rgb_plan_run(offl[0], offl[1] + 8u, so[0], a.end_rel[0], uint32_t(lmax) * uint32_t(sy), new_row, lane, cs[0], lbase[0]);
+            rgb_plan_run(offu, offu + 8u, so[1], a.end_rel[1], uint32_t(cmax) * uint32_t(sc), new_row, lane, cs[1], lbase[1]);
+            rgb_plan_run(offv, offv + 8u, so[2], a.end_rel[1], uint32_t(cmax) * uint32_t(sc), new_row, lane, cs[2], lbase[2]);
+            auto slot = [&](int k) { return uint32_t(reinterpret_cast<uintptr_t>((rgb_lds_t *)&lds[wave][k][0])); };
+            lposl[0] = offl[0] + lbase[0] + slot(0); lposl[1] = offl[1] + lbase[0] + slot(0);
+            lposu = offu + lbase[1] + slot(1); lposv = offv + lbase[2] + slot(2);
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(srs, (rgb_lds_t *)&lds[wave][0][0], 16, cs[0], lo, 0, 0);
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(srs, (rgb_lds_t *)&lds[wave][1][0], 16, cs[1], co, 0, 0);
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(srs, (rgb_lds_t *)&lds[wave][2][0], 16, cs[2], co, 0, 0);
+            since_l = 2; since_c = 0;
+        } else {
+            wl[0] = __builtin_amdgcn_raw_buffer_load_b64(srs, offl[0], lo, 0);
+            wl[1] = __builtin_amdgcn_raw_buffer_load_b64(srs, offl[1], lo, 0);
+            wu = __builtin_amdgcn_raw_buffer_load_b64(srs, offu, co, 0);
+            wv = __builtin_amdgcn_raw_buffer_load_b64(srs, offv, co, 0);
+        }
     }
     // the closed form's constants (wave-uniform)
     const int cy = a.coef.cy, crv = a.coef.crv, cbu = a.coef.cbu, cgu = a.coef.cgu, cgv = a.coef.cgv;
@@ -339,6 +486,19 @@ __global__ __launch_bounds__(kBlock) void rgb_strip_kernel(const uint8_t *__rest
         const uint32_t *vr = tab + a.vrow + 6 * y;
         const int nl = y == y0 ? 4 : int(uni(vr[0])), nc = y == y0 ? 4 : int(uni(vr[1]));
         for (int n = 0; n < nl; ++n) {                         // wave-uniform
+            if constexpr (LDS) {
+                rgb_wait_vm(since_l);
+                uint32_t w3[2][3];
+                rgb_lds_read2(w3, lposl[0] & ~3u, lposl[1] & ~3u);
+#pragma unroll
+                for (int j = 0; j < 2; ++j) {
+                    wl[j].x = __builtin_amdgcn_alignbyte(w3[j][1], w3[j][0], lposl[j]);
+                    wl[j].y = __builtin_amdgcn_alignbyte(w3[j][2], w3[j][1], lposl[j]);
+                }
+                // the slot is free again (its bytes sit in registers): request the next row into it
+                __builtin_amdgcn_raw_ptr_buffer_load_lds(srs, (rgb_lds_t *)&lds[wave][0][0], 16, cs[0], min(max(lrow + 1, 0), lmax) * sy, 0, 0);
+                since_l = 0; since_c += 1;
+            }
 #pragma unroll
             for (int i = 0; i < 8; ++i) {
                 const u32x2_t w = wl[i / 4];
@@ -349,11 +509,24 @@ __global__ __launch_bounds__(kBlock) void rgb_strip_kernel(const uint8_t *__rest
                 ry[i][1] = __builtin_amdgcn_alignbit(t, ry[i][1], 16);
             }
             ++lrow;
-            const int lo = min(max(lrow, 0), lmax) * sy;
-            wl[0] = __builtin_amdgcn_raw_buffer_load_b64(srs, offl[0], lo, 0);
-            wl[1] = __builtin_amdgcn_raw_buffer_load_b64(srs, offl[1], lo, 0);
+            if constexpr (!LDS) {
+                const int lo = min(max(lrow, 0), lmax) * sy;
+                wl[0] = __builtin_amdgcn_raw_buffer_load_b64(srs, offl[0], lo, 0);
+                wl[1] = __builtin_amdgcn_raw_buffer_load_b64(srs, offl[1], lo, 0);
+            }
         }
         for (int n = 0; n < nc; ++n) {                         // wave-uniform
+            if constexpr (LDS) {
+                rgb_wait_vm(since_c);
+                uint32_t w3[2][3];
+                rgb_lds_read2(w3, lposu & ~3u, lposv & ~3u);
+                wu.x = __builtin_amdgcn_alignbyte(w3[0][1], w3[0][0], lposu); wu.y = __builtin_amdgcn_alignbyte(w3[0][2], w3[0][1], lposu);
+                wv.x = __builtin_amdgcn_alignbyte(w3[1][1], w3[1][0], lposv); wv.y = __builtin_amdgcn_alignbyte(w3[1][2], w3[1][1], lposv);
+                const int co = min(max(crow + 1, 0), cmax) * sc;
+                __builtin_amdgcn_raw_ptr_buffer_load_lds(srs, (rgb_lds_t *)&lds[wave][1][0], 16, cs[1], co, 0, 0);
+                __builtin_amdgcn_raw_ptr_buffer_load_lds(srs, (rgb_lds_t *)&lds[wave][2][0], 16, cs[2], co, 0, 0);
+                since_c = 0; since_l += 2;
+            }
 #pragma unroll
             for (int i = 0; i < 4; ++i) {
                 int au = dot2(__builtin_amdgcn_perm(wu.y, wu.x, selc[i][0]), coefc[i][0], 0);
@@ -367,23 +540,27 @@ __global__ __launch_bounds__(kBlock) void rgb_strip_kernel(const uint8_t *__rest
                 rv[i][1] = __builtin_amdgcn_alignbit(tv, rv[i][1], 16);
             }
             ++crow;
-            const int co = min(max(crow, 0), cmax) * sc;
-            wu = __builtin_amdgcn_raw_buffer_load_b64(srs, offu, co, 0);
-            wv = __builtin_amdgcn_raw_buffer_load_b64(srs, offv, co, 0);
+            if constexpr (!LDS) {
+                const int co = min(max(crow, 0), cmax) * sc;
+                wu = __builtin_amdgcn_raw_buffer_load_b64(srs, offu, co, 0);
+                wv = __builtin_amdgcn_raw_buffer_load_b64(srs, offv, co, 0);
+            }
         }
 
         // vertical pass: yuv2rgb_X_c_template's 1 << 18 rounding, >> 19, no clip
         const uint32_t vl0 = uni(vr[2]), vl1 = uni(vr[3]), vc0 = uni(vr[4]), vc1 = uni(vr[5]);
         int P[8], CR[4], CG[4], CB[4];
 #pragma unroll
-        for (int i = 0; i < 8; ++i) P[i] = (dot2(ry[i][1], vl1, dot2(ry[i][0], vl0, 1 << 18)) >> 19) * cy;
+        // (every product below has operands within 24 bits -- |Y|, |offsets| < 2^11, constants < 2^18 -- so the
+        // full-rate v_mul_i32_i24 / v_mad_i32_i24 serve; a plain `*` costs a quarter-rate v_mul_lo_u32 each)
+        for (int i = 0; i < 8; ++i) P[i] = __mul24(dot2(ry[i][1], vl1, dot2(ry[i][0], vl0, 1 << 18)) >> 19, cy);
 #pragma unroll
         for (int j = 0; j < 4; ++j) {
             const int U = clip255(dot2(ru[j][1], vc1, dot2(ru[j][0], vc0, 1 << 18)) >> 19);
             const int V = clip255(dot2(rv[j][1], vc1, dot2(rv[j][0], vc0, 1 << 18)) >> 19);
-            const int cr = ((V * crv) >> 16) * cy + kr;
-            const int cb = ((U * cbu) >> 16) * cy + kb;
-            CG[j] = (((U * cgu) >> 16) + ((V * cgv) >> 16)) * cy + kg;
+            const int cr = __mul24(__mul24(V, crv) >> 16, cy) + kr;
+            const int cb = __mul24(__mul24(U, cbu) >> 16, cy) + kb;
+            CG[j] = __mul24((__mul24(U, cgu) >> 16) + (__mul24(V, cgv) >> 16), cy) + kg;
             CR[j] = swap ? cb : cr;                              // (bgr: the first byte of a pixel is B)
             CB[j] = swap ? cr : cb;
         }
@@ -395,17 +572,39 @@ __global__ __launch_bounds__(kBlock) void rgb_strip_kernel(const uint8_t *__rest
             uint32_t o[6];
 #pragma unroll
             for (int q = 0; q < 6; ++q) o[q] = hi2_u8(v[4 * q], v[4 * q + 1]) | (hi2_u8(v[4 * q + 2], v[4 * q + 3]) << 16);
-            store_b128(u32x4_t{o[0], o[1], o[2], o[3]}, drs, doff, yoff);
-            store_b64(u32x2_t{o[4], o[5]}, drs, doff + 16u, yoff);
+            if constexpr (XP) {
+                u32x4_t v1, v2;
+                rgb_lds_exchange3(xw, o, xr1, xr2, v1, v2);
+                store_b128(v1, drs, dest1, yoff);
+                store_b128(v2, drs, dest2, yoff);
+                if (any_split) {                               // wave-uniform: the one chunk whose halves lie apart
+                    const u32x4_t h = split_second ? v2 : v1;
+                    store_b64(u32x2_t{h.x, h.y}, drs, dest_a, yoff);
+                    store_b64(u32x2_t{h.z, h.w}, drs, dest_b, yoff);
+                    since_l += 2; since_c += 2;
+                }
+            } else {
+                store_b128(u32x4_t{o[0], o[1], o[2], o[3]}, drs, doff, yoff);
+                store_b64(u32x2_t{o[4], o[5]}, drs, doff + 16u, yoff);
+            }
         } else {
             uint32_t o[8];
 #pragma unroll
             for (int i = 0; i < 8; ++i)
                 o[i] = hi2_u8(P[i] + CR[i / 2], P[i] + CG[i / 2]) | (hi2_u8(P[i] + CB[i / 2], 0x7fff0000) << 16);   // alpha 255
-            store_b128(u32x4_t{o[0], o[1], o[2], o[3]}, drs, doff, yoff);
-            store_b128(u32x4_t{o[4], o[5], o[6], o[7]}, drs, doff + 16u, yoff);
+            if constexpr (XP) {
+                u32x4_t v1, v2;
+                rgb_lds_exchange4(xw, o, xr1, xr2, v1, v2);
+                store_b128(v1, drs, dest1, yoff);
+                store_b128(v2, drs, dest2, yoff);
+            } else {
+                store_b128(u32x4_t{o[0], o[1], o[2], o[3]}, drs, doff, yoff);
+                store_b128(u32x4_t{o[4], o[5], o[6], o[7]}, drs, doff + 16u, yoff);
+            }
         }
+        since_l += 2; since_c += 2;                              // two stores a row, either format
     }
+#endif
 }
 
 template <class T>
@@ -439,6 +638,7 @@ struct RgbPlan {
     enum Mode { kUnscaled, kGeneric } mode = kGeneric;
     // the fused strip walk (every axis <= 4 taps, no pad, even crop): tables in HBM, one set per segment length
     bool strip_ok = false;
+    bool strip_lds = false;            // ... with the source rows staged through LDS (the runs of any 64 strips fit a 1 KiB slot per plane)
     uint32_t *d_tab = nullptr;
     RgbStripArgs strip{};              // table offsets and constants; per-launch fields are filled in by rgb_launch
     struct Seg { int seg_rows, nseg; uint32_t seginfo; };
@@ -524,6 +724,25 @@ static bool build_rgb_strip(RgbPlan *p)
         p->segs.push_back(sg);
         if (sg.nseg == 1) break;
     }
+    // LDS staging: any 64 consecutive strips (they wrap over frames: one piece per row touched) must need at
+    // most kRgbMaxPieces runs and 64 sixteen-byte chunks per plane, whatever the runs' alignment
+    auto fits = [&](uint32_t hoff, int windows) {
+        if (std::getenv("TTS_NO_LDS") && std::atoi(std::getenv("TTS_NO_LDS"))) return false;
+        if (strips < 2) return false;
+        for (int s0 = 0; s0 < strips; ++s0) {
+            uint32_t chunks = 0;
+            int pieces = 0, s1 = s0, left = 64;
+            while (left > 0) {
+                const int take = std::min(left, strips - s1);
+                const uint32_t b = tab[hoff + size_t(s1) * windows], e = tab[hoff + size_t(s1 + take - 1) * windows + windows - 1] + 8u;
+                chunks += (e - b + 30u) >> 4;
+                ++pieces; left -= take; s1 = 0;
+            }
+            if (pieces > kRgbMaxPieces || chunks > 64u) return false;
+        }
+        return true;
+    };
+    p->strip_lds = fits(a.hoffl, 2) && fits(a.hoffc, 1);
     a.strips = strips; a.ph = ph; a.pw = pw;
     a.src_h_l = lv.src; a.src_h_c = cv.src;
     a.swap = p->swap; a.coef = p->coef;
@@ -605,7 +824,7 @@ int rgb_plan_create(const tts_geom &g, int n_cus, RgbPlan **out)
         for (int i = 0; i < 4 && !rc; ++i)
             if (!upload_vec(p->d_pos[i], f[i]->pos) || !upload_vec(p->d_taps[i], f[i]->taps)) { set_last_error("table upload failed (hipMalloc / hipMemcpy)"); rc = TTS_ERR_INITIALIZATION_FAILED; }
         std::snprintf(p->name, sizeof p->name, "rgb_generic<%d,%d,%d,%d>", p->lh.size, p->lv.size, p->ch.size, p->cv.size);
-        if (!rc && (p->strip_ok = build_rgb_strip(p))) std::snprintf(p->name, sizeof p->name, "rgb_strip<%d>", p->bpp);
+        if (!rc && (p->strip_ok = build_rgb_strip(p))) std::snprintf(p->name, sizeof p->name, "rgb_strip<%d,%s>", p->bpp, p->strip_lds ? "lds" : "regs");
     }
     if (rc) { rgb_plan_destroy(p); return rc; }
     *out = p;
@@ -632,9 +851,20 @@ int rgb_launch(const RgbPlan *p, const uint8_t *src, uint8_t *dst, int n, const 
         const bool fits = addr.use_table || (wave_frames * addr.src_pitch <= kMaxSpan && wave_frames * addr.dst_pitch <= kMaxSpan);
         const int64_t items = int64_t(n) * p->strip.strips;
         if (fits && items < (int64_t(1) << 30)) {
-            auto fn = p->bpp == 3 ? rgb_strip_kernel<3> : rgb_strip_kernel<4>;
-            static int per_cu[2] = {0, 0};                  // resident workgroups per CU, asked once per instantiation
-            int &occ = per_cu[p->bpp == 4];
+            // (per-frame plane pointers keep the register variant: a staged run may round into bytes around a
+            // plane, which only a packed batch is known to own)
+            const bool lds = p->strip_lds && !addr.use_table && src_span >= 4096u;
+            // whole-sector stores: rgba always (a chunk never leaves its lane); rgb24 where a wave's strips wrap
+            // over frames at most once and no last strip is slid over its neighbour (one held-back chunk at most)
+            const bool no_xp = std::getenv("TTS_NO_XP") && std::atoi(std::getenv("TTS_NO_XP"));
+            const bool xp = !no_xp && (p->bpp == 4 || (p->strip.pw % 8 == 0 && p->strip.strips >= 64));
+            typedef void (*rgb_fn)(const uint8_t *, uint8_t *, const uint32_t *, const RgbStripArgs);
+            static const rgb_fn fns[8] = {rgb_strip_kernel<3, false, false>, rgb_strip_kernel<3, false, true>, rgb_strip_kernel<3, true, false>, rgb_strip_kernel<3, true, true>,
+                                          rgb_strip_kernel<4, false, false>, rgb_strip_kernel<4, false, true>, rgb_strip_kernel<4, true, false>, rgb_strip_kernel<4, true, true>};
+            const int which = (p->bpp == 4) * 4 + lds * 2 + xp;
+            rgb_fn fn = fns[which];
+            static int per_cu[8] = {0, 0, 0, 0, 0, 0, 0, 0};   // resident workgroups per CU, asked once per instantiation
+            int &occ = per_cu[which];
             if (!occ && (hipOccupancyMaxActiveBlocksPerMultiprocessor(&occ, fn, kBlock, 0) != hipSuccess || occ < 1)) occ = 1;
             // the longest segment <= 96 rows that still leaves 3 workgroups per resident slot, else the shortest
             const double slots = double(p->n_cus) * occ;
@@ -647,6 +877,18 @@ int rgb_launch(const RgbPlan *p, const uint8_t *src, uint8_t *dst, int n, const 
             a.n_items = int(items);
             a.src_stride_y = src_stride[0]; a.src_stride_c = src_stride[1]; a.dst_stride = dst_stride;
             a.src_span = src_span; a.dst_span = dst_span; a.addr = addr;
+            {   // the source planes, seen from the pre-cropped origin the frame offsets point at
+                const tts_geom &g = p->g;
+                for (int k = 0; k < 2; ++k) {
+                    const int pw_ = (g.in_w + k) >> k, ph_ = (g.in_h + k) >> k, px_ = g.pre_x >> k, py_ = g.pre_y >> k;
+                    a.end_rel[k] = uint32_t(ph_ - py_ - 1) * uint32_t(src_stride[k]) + uint32_t(pw_ - px_);
+                }
+            }
+#ifdef TTS_EXPERIMENTS
+            // timing experiments (outputs are wrong): a zero-record descriptor drops that side's traffic, the instruction stream stays
+            if (std::getenv("TTS_EXP_NOSRC")) a.src_span = 0;
+            if (std::getenv("TTS_EXP_NODST")) a.dst_span = 0;
+#endif
             return launch_rgb("rgb_strip_kernel", fn, dim3(uint32_t(sblocks) * uint32_t(a.nseg)), dim3(kBlock), 0, st, src, dst, p->d_tab, a);
         }
     }
