@@ -62,6 +62,7 @@ typedef struct tts_geom {
     int32_t out_fmt;                          /* TTS_FMT_*: what the chain hands out (0 = yuv420p) */
     int32_t rgb_stage;                        /* TTS_RGB_*: where the yuv -> RGB conversion sits (0 when out_fmt is yuv420p) */
     int32_t fill_rgb;                         /* pad colour as 0xRRGGBB, used when the pad stage works on RGB pixels */
+    int32_t in_fmt;                           /* TTS_FMT_YUV420P or TTS_FMT_RGB24: what the chain is fed (tts_parse_vf_fmt) */
 } tts_geom;
 
 /* One frame: Y, U, V plane pointers and byte strides (yuv420p), or plane[0] / stride[0] alone (packed RGB). */
@@ -85,6 +86,18 @@ typedef struct tts_plan tts_plan;
  * format=yuv420p | yuvj420p | rgb24 | bgr24 | rgba | bgra.
  */
 int tts_parse_vf(const char *vf, int iw, int ih, tts_geom *out);
+
+/*
+ * The same for a chain fed with packed rgb24 frames (`-f rawvideo -pix_fmt rgb24 -i ...`, in_fmt =
+ * TTS_FMT_RGB24; TTS_FMT_YUV420P is tts_parse_vf): the other direction of the colour conversion BASELINE.json's
+ * north_star names.  The chain must hand out yuv420p.  As libavfilter negotiates it, the
+ * chain's `scale` reads the RGB (a crop in front of it works on RGB pixels: no chroma grid) and writes yuv420p:
+ * swscale's input side (libswscale/input.c rgb24ToY_c, rgb24ToUV_half_c: BT.601 limited range, two
+ * neighbouring pixels averaged into one chroma sample, every source row its own chroma row) feeding the scaler's
+ * 16-bit horizontal pass.  Without a scale the conversion is a pass of its own behind the crops.
+ * Source frames are ONE plane of in_w * 3 bytes a row; in_w (after a crop: its width) must be even.
+ */
+int tts_parse_vf_fmt(const char *vf, int iw, int ih, int in_fmt, tts_geom *out);
 
 /*
  * Build the per-geometry state on the current HIP device (coefficient tables in HBM).

@@ -23,7 +23,7 @@ class Chain(ctypes.Structure):
     _fields_ = [(n, ctypes.c_int) for n in (
         "in_w", "in_h", "pre_x", "pre_y", "pre_w", "pre_h", "do_scale", "alg", "sc_w", "sc_h",
         "crop_x", "crop_y", "crop_w", "crop_h", "do_pad", "pad_x", "pad_y", "out_w", "out_h",
-        "fill_y", "fill_u", "fill_v", "out_range", "out_fmt", "rgb_stage", "fill_rgb")]
+        "fill_y", "fill_u", "fill_v", "out_range", "out_fmt", "rgb_stage", "fill_rgb", "in_fmt")]
 
 
 _lib = None
@@ -50,6 +50,7 @@ def lib():
                                    [ctypes.c_void_p] * 3 + [ctypes.c_int] * 3
         L.tto_run_chain_rgb.argtypes = [ctypes.POINTER(Chain)] + [ctypes.c_void_p] * 3 + [ctypes.c_int] * 3 + \
                                        [ctypes.c_void_p, ctypes.c_int]
+        L.tto_run_chain_rgbin.argtypes = [ctypes.POINTER(Chain), ctypes.c_void_p, ctypes.c_int] + [ctypes.c_void_p] * 3 + [ctypes.c_int] * 3
         L.tto_sws_yuv420_to_rgb.argtypes = [ctypes.c_void_p] * 3 + [ctypes.c_int] * 5 + [ctypes.c_void_p] + [ctypes.c_int] * 5
         _lib = L
     return _lib
@@ -105,10 +106,24 @@ def out_frame_bytes(c):
     return frame_bytes(c.out_w, c.out_h)
 
 
+def in_frame_bytes(c):
+    return c.in_w * c.in_h * 3 if c.in_fmt else frame_bytes(c.in_w, c.in_h)
+
+
 def run_chain(geom, frames):
-    """frames: uint8 [n, frame_bytes(in)] packed I420 -> [n, out_frame_bytes] (packed I420 or packed RGB)."""
+    """frames: uint8 [n, in_frame_bytes] (packed I420, or packed rgb24 when geom.in_fmt says so)
+    -> [n, out_frame_bytes] (packed I420 or packed RGB)."""
     c = chain_from(geom)
-    frames = np.ascontiguousarray(frames, np.uint8).reshape(-1, frame_bytes(c.in_w, c.in_h))
+    frames = np.ascontiguousarray(frames, np.uint8).reshape(-1, in_frame_bytes(c))
+    if c.in_fmt:
+        out = np.empty((frames.shape[0], frame_bytes(c.out_w, c.out_h)), np.uint8)
+        ow, oh = c.out_w, c.out_h
+        ocw, och = (ow + 1) // 2, (oh + 1) // 2
+        for i in range(frames.shape[0]):
+            d = out[i].ctypes.data
+            rc = lib().tto_run_chain_rgbin(ctypes.byref(c), frames[i].ctypes.data, c.in_w * 3, d, d + ow * oh, d + ow * oh + ocw * och, ow, ocw, ocw)
+            assert rc == 0, rc
+        return out
     out = np.empty((frames.shape[0], out_frame_bytes(c)), np.uint8)
     iw, ih, ow, oh = c.in_w, c.in_h, c.out_w, c.out_h
     icw, ich, ocw, och = (iw + 1) // 2, (ih + 1) // 2, (ow + 1) // 2, (oh + 1) // 2

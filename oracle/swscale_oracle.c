@@ -587,3 +587,105 @@ int tto_run_chain_rgb(const tto_chain *c, const uint8_t *sy, const uint8_t *su, 
     }
     return rc;
 }
+
+/* ------------------------------------------------------------------------------------------------
+ * Packed rgb24 INPUT (the other direction).  RECALLED, UNVERIFIED:
+ *   utils.c fill_rgb2yuv_table(): for the default (ITU-R BT.601) matrix the table is overwritten with
+ *     (int)(0.299 * 219 / 255 * (1 << 15) + 0.5) & co. -- limited-range coefficients in 15 fractional bits;
+ *   input.c rgb24ToY_c(): (ry r + gy g + by b + (32 << 14) + (1 << 8)) >> 9          -> Y << 6 (14 bits);
+ *   input.c rgb24ToUV_half_c() (chrSrcHSubSample = 1 without full_chroma_inp): the SUMS of two neighbouring
+ *     pixels, (ru r + gu g + bu b + (256 << 15) + (1 << 9)) >> 10                       -> C << 6;
+ *   every source row yields a chroma row (chrSrcVSubSample = 0 for RGB), so chroma is scaled sh -> ceil(dh / 2);
+ *   swscale.c hScale16To15_c() with sh = 13 for RGB sources: min(sum >> 13, 32767)     -> 15 bits, then the
+ *   vertical pass of the planar path (yuv2planeX_8_c / yuv2plane1_8_c).
+ * ------------------------------------------------------------------------------------------------ */
+static void tto_hscale16_plane(const int16_t *src, int sw, int sh, const tto_filter *hf, int16_t *tmp)
+{
+    for (int y = 0; y < sh; y++) {
+        const int16_t *s = src + (size_t)y * sw;
+        int16_t *t = tmp + (size_t)y * hf->dst;
+        for (int x = 0; x < hf->dst; x++) {
+            int val = 0, p = hf->pos[x];
+            for (int j = 0; j < hf->size; j++) val += (int)s[p + j] * hf->coef[hf->size * x + j];
+            val >>= 13;
+            t[x] = (int16_t)(val < (1 << 15) - 1 ? val : (1 << 15) - 1);
+        }
+    }
+}
+
+static void tto_vscale_plane(const int16_t *tmp, int dw, const tto_filter *vf, uint8_t *dst, int dstride)
+{
+    for (int y = 0; y < vf->dst; y++) {
+        uint8_t *d = dst + (size_t)y * dstride;
+        const int p = vf->pos[y];
+        const int16_t *c = vf->coef + (size_t)vf->size * y;
+        for (int x = 0; x < dw; x++) {
+            if (vf->size == 1) { d[x] = tto_clip_u8((tmp[(size_t)p * dw + x] + 64) >> 7); continue; }
+            int val = 64 << 12;
+            for (int j = 0; j < vf->size; j++) val += tmp[(size_t)(p + j) * dw + x] * c[j];
+            d[x] = tto_clip_u8(val >> 19);
+        }
+    }
+}
+
+int tto_sws_rgb24_to_yuv420(const uint8_t *src, int sstride, int sw, int sh,
+                            uint8_t *dy, uint8_t *du, uint8_t *dv, int dys, int dus, int dvs, int dw, int dh, int alg)
+{
+    const int S = 15;                                                      /* RGB2YUV_SHIFT */
+    const int ry = (int)(0.299 * 219 / 255 * (1 << S) + 0.5), gy = (int)(0.587 * 219 / 255 * (1 << S) + 0.5), by = (int)(0.114 * 219 / 255 * (1 << S) + 0.5);
+    const int ru = -(int)(0.169 * 224 / 255 * (1 << S) + 0.5), gu = -(int)(0.331 * 224 / 255 * (1 << S) + 0.5), bu = (int)(0.500 * 224 / 255 * (1 << S) + 0.5);
+    const int rv = (int)(0.500 * 224 / 255 * (1 << S) + 0.5), gv = -(int)(0.419 * 224 / 255 * (1 << S) + 0.5), bv = -(int)(0.081 * 224 / 255 * (1 << S) + 0.5);
+    const int csw = (sw + 1) >> 1, cdw = (dw + 1) >> 1, cdh = (dh + 1) >> 1;
+    tto_filter lh, lv, ch, cv;
+    int16_t *y14, *u14, *v14, *ty, *tu, *tv;
+    if (sw < 2 || (sw & 1) || sh < 1 || dw < 1 || dh < 1) return -1;       /* (the pair reader would run past an odd row's end) */
+    if (tto_filter_init(&lh, sw, dw, 1 << 14, alg) || tto_filter_init(&lv, sh, dh, 1 << 12, alg) ||
+        tto_filter_init(&ch, csw, cdw, 1 << 14, alg) || tto_filter_init(&cv, sh, cdh, 1 << 12, alg)) return -1;
+    y14 = (int16_t *)malloc((size_t)sw * sh * sizeof(int16_t));
+    u14 = (int16_t *)malloc((size_t)csw * sh * sizeof(int16_t));
+    v14 = (int16_t *)malloc((size_t)csw * sh * sizeof(int16_t));
+    for (int y = 0; y < sh; y++) {
+        const uint8_t *s = src + (size_t)y * sstride;
+        for (int i = 0; i < sw; i++) {
+            const int r = s[3 * i], g = s[3 * i + 1], b = s[3 * i + 2];
+            y14[(size_t)y * sw + i] = (int16_t)((ry * r + gy * g + by * b + (32 << (S - 1)) + (1 << (S - 7))) >> (S - 6));
+        }
+        for (int i = 0; i < csw; i++) {
+            const int r = s[6 * i] + s[6 * i + 3], g = s[6 * i + 1] + s[6 * i + 4], b = s[6 * i + 2] + s[6 * i + 5];
+            u14[(size_t)y * csw + i] = (int16_t)((ru * r + gu * g + bu * b + (256 << S) + (1 << (S - 6))) >> (S - 5));
+            v14[(size_t)y * csw + i] = (int16_t)((rv * r + gv * g + bv * b + (256 << S) + (1 << (S - 6))) >> (S - 5));
+        }
+    }
+    ty = (int16_t *)malloc((size_t)dw * sh * sizeof(int16_t));
+    tu = (int16_t *)malloc((size_t)cdw * sh * sizeof(int16_t));
+    tv = (int16_t *)malloc((size_t)cdw * sh * sizeof(int16_t));
+    tto_hscale16_plane(y14, sw, sh, &lh, ty);
+    tto_hscale16_plane(u14, csw, sh, &ch, tu);
+    tto_hscale16_plane(v14, csw, sh, &ch, tv);
+    tto_vscale_plane(ty, dw, &lv, dy, dys);
+    tto_vscale_plane(tu, cdw, &cv, du, dus);
+    tto_vscale_plane(tv, cdw, &cv, dv, dvs);
+    free(y14); free(u14); free(v14); free(ty); free(tu); free(tv);
+    tto_filter_free(&lh); tto_filter_free(&lv); tto_filter_free(&ch); tto_filter_free(&cv);
+    return 0;
+}
+
+int tto_run_chain_rgbin(const tto_chain *c, const uint8_t *src, int sstride,
+                        uint8_t *dy, uint8_t *du, uint8_t *dv, int dys, int dus, int dvs)
+{
+    /* the chain's scale (or, without one, a conversion pass behind the crops) reads the RGB of the pre-cropped
+     * rectangle -- a crop on RGB pixels, any offset -- and writes yuv420p; crop / pad behind it are the planar ones */
+    const int vw = c->sc_w, vh = c->sc_h, cw = (vw + 1) >> 1, chh = (vh + 1) >> 1;
+    uint8_t *buf = (uint8_t *)malloc((size_t)vw * vh + 2 * (size_t)cw * chh);
+    uint8_t *py = buf, *pu = buf + (size_t)vw * vh, *pv = pu + (size_t)cw * chh;
+    tto_chain rest = *c;
+    int rc = tto_sws_rgb24_to_yuv420(src + (size_t)c->pre_y * sstride + (size_t)c->pre_x * 3, sstride, c->pre_w, c->pre_h,
+                                     py, pu, pv, vw, cw, cw, vw, vh, c->alg);
+    if (!rc) {
+        /* what is left of the chain sees a yuv420p frame of the scaled size */
+        rest.in_fmt = 0; rest.in_w = vw; rest.in_h = vh; rest.pre_x = rest.pre_y = 0; rest.pre_w = vw; rest.pre_h = vh; rest.do_scale = 0;
+        rc = tto_run_chain(&rest, py, pu, pv, vw, cw, cw, dy, du, dv, dys, dus, dvs);
+    }
+    free(buf);
+    return rc;
+}

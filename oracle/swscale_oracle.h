@@ -48,6 +48,7 @@ typedef struct tto_chain {
     int out_fmt;                      /* TTO_FMT_*: packed RGB written by the chain's swscale pass */
     int rgb_stage;                    /* 0 none, 1 inside the chain's scale (crop / pad then work on RGB), 2 a pass of its own at the end */
     int fill_rgb;                     /* pad colour 0xRRGGBB for pads that work on RGB */
+    int in_fmt;                       /* TTO_FMT_YUV420P, or TTO_FMT_RGB24: the chain's swscale pass reads packed rgb24 */
 } tto_chain;
 
 enum { TTO_FMT_YUV420P = 0, TTO_FMT_RGB24 = 1, TTO_FMT_BGR24 = 2, TTO_FMT_RGBA = 3, TTO_FMT_BGRA = 4 };
@@ -75,6 +76,16 @@ int tto_sws_yuv420_to_rgb(const uint8_t *sy, const uint8_t *su, const uint8_t *s
 /* a chain that ends in packed RGB (c->out_fmt != 0): dst holds out_h rows of out_w * bpp bytes */
 int tto_run_chain_rgb(const tto_chain *c, const uint8_t *sy, const uint8_t *su, const uint8_t *sv,
                       int sys, int sus, int svs, uint8_t *dst, int dstride);
+
+/* One swscale context packed rgb24 (sw x sh, sw even) -> yuv420p (dw x dh), C path, default flags:
+ * libswscale/input.c rgb24ToY_c / rgb24ToUV_half_c (14-bit samples), swscale.c hScale16To15_c, output.c
+ * yuv2planeX_8_c.  Chroma: ceil(sw / 2) x sh samples scaled to ceil(dw / 2) x ceil(dh / 2). */
+int tto_sws_rgb24_to_yuv420(const uint8_t *src, int sstride, int sw, int sh,
+                            uint8_t *dy, uint8_t *du, uint8_t *dv, int dys, int dus, int dvs, int dw, int dh, int alg);
+
+/* a chain fed with packed rgb24 (c->in_fmt == TTO_FMT_RGB24) that hands out yuv420p */
+int tto_run_chain_rgbin(const tto_chain *c, const uint8_t *src, int sstride,
+                        uint8_t *dy, uint8_t *du, uint8_t *dv, int dys, int dus, int dvs);
 
 #ifdef __cplusplus
 }

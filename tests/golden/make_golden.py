@@ -53,6 +53,11 @@ CASES = {
     "thumb_pad_rgb24_72x128": geom(72, 128, 101, 180, pad=(109, 0, 320, 180), rgb=(1, 1, 0)),
     "convert_only_bgra_64x48": geom(64, 48, 64, 48, rgb=(4, 2, 0)),
 }
+# packed rgb24 IN (yuv420p out): inputs are seeded random bytes, 3 a pixel
+RGBIN_CASES = {
+    "rgbin_stretch_96x170_to_144x256": dict(geom(96, 170, 144, 256), in_fmt=1),
+    "rgbin_convert_only_64x48": dict(geom(64, 48, 64, 48), in_fmt=1),
+}
 PATTERNS = ("random", "impulse", "zone")
 
 
@@ -64,6 +69,11 @@ def main():
             arrs["out_" + pat] = oracle.run_chain(g, src)[0]
         np.savez_compressed(os.path.join(HERE, name + ".npz"), **arrs)
         print(name, {k: v.shape for k, v in arrs.items() if k.startswith("out_")})
+    for name, g in RGBIN_CASES.items():
+        src = np.random.default_rng(synth.SEED).integers(0, 256, (1, g["in_w"] * g["in_h"] * 3), dtype=np.uint8)
+        np.savez_compressed(os.path.join(HERE, name + ".npz"), geom=np.array([g[k] for k in sorted(g)], np.int32),
+                            geom_keys=np.array(sorted(g)), out_rgbseed=oracle.run_chain(g, src)[0])
+        print(name)
     # coefficient tables of the headline geometries (first/last rows are where the border rules bite)
     tabs = {}
     for (s, d, one, alg) in [(1920, 3413, 1 << 14, 0), (1080, 1920, 1 << 12, 0), (960, 1707, 1 << 14, 0),

@@ -114,3 +114,54 @@ def test_rgb_unsupported_paths_say_so(tts):
     # unscaled converter on an odd width
     with pytest.raises(tts.TtsError, match="UNSUPPORTED"):
         tts.Plan.from_vf("format=rgb24", 63, 48)
+
+
+# ---- the other direction: packed rgb24 in, yuv420p out ---------------------------------------------------
+RGBIN_CASES = [
+    ("scale=w=720:h=1280", 480, 854),                  # scripts/processVideos.js:96 fed from an RGB source
+    (THUMB + ",format=yuv420p", 720, 1280),            # src/services/video.js:329-332: scale, then pad on yuv420p
+    (THUMB + ",format=yuv420p", 1280, 720),
+    (PORTRAIT, 1920, 1080),
+    (PORTRAIT, 1280, 720),
+    ("scale=320:568:flags=area", 1080, 1920),
+    ("scale=101:57", 64, 36),
+    ("scale=64:36", 102, 57),
+    ("crop=64:33:11:7,scale=128:96", 100, 60),         # a crop on RGB pixels: odd offsets, odd height
+    ("format=yuv420p", 64, 48),                        # conversion only
+    ("crop=32:21:5:3", 64, 48),                        # crop on RGB, then the conversion pass (odd height out)
+    ("scale=200:150,crop=100:74:34:20,pad=132:100:8:6:color=red", 100, 80),
+]
+
+
+def rgb_frames(pattern, w, h, n):
+    """Packed rgb24 test frames: the three planes of the yuv generator at full size, interleaved."""
+    y = synth.frames(pattern, 2 * w, 2 * h, n)         # gives planes of w x h as its chroma
+    out = np.empty((n, h, w, 3), np.uint8)
+    for i in range(n):
+        a, b, c = synth.split(y[i], 2 * w, 2 * h)
+        out[i, :, :, 0] = a[::2, ::2]; out[i, :, :, 1] = b; out[i, :, :, 2] = c
+    return out.reshape(n, -1)
+
+
+@pytest.mark.parametrize("vf,iw,ih", RGBIN_CASES)
+def test_rgb24_input_matches_oracle(tts, oracle, vf, iw, ih):
+    import torch
+    plan = tts.Plan.from_vf(vf, iw, ih, in_fmt="rgb24")
+    assert plan.geom.in_fmt == 1 and plan.in_bytes == iw * ih * 3 and plan.kernel_name(0).startswith("rgbin")
+    big = iw * ih > 1000 * 1000
+    for pat in (("random", "impulse") if big else synth.PATTERNS):
+        src = rgb_frames(pat, iw, ih, 1 if big else 3)
+        want = oracle.run_chain(plan.geom, src)
+        got = plan.run_batch(torch.from_numpy(src).cuda()).cpu().numpy()
+        bad = np.flatnonzero(got != want)
+        assert bad.size == 0, "%s %dx%d %s: %d bytes differ, first at %d (got %d want %d)" % (
+            vf, iw, ih, pat, bad.size, bad[0], got.ravel()[bad[0]], want.ravel()[bad[0]])
+
+
+def test_rgb24_input_host_path_and_rejections(tts, oracle):
+    plan = tts.Plan.from_vf("scale=96:54", 64, 36, in_fmt="rgb24")
+    src = rgb_frames("zone", 64, 36, 5)
+    assert np.array_equal(plan.run_host(src), oracle.run_chain(plan.geom, src))
+    for vf, iw in (("scale=96:54,format=rgb24", 64), ("scale=96:54", 63), ("pad=80:60", 64), ("format=yuvj420p", 64)):
+        with pytest.raises(tts.TtsError, match="UNSUPPORTED"):
+            tts.Plan.from_vf(vf, iw, 36, in_fmt="rgb24")

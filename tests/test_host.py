@@ -123,6 +123,17 @@ def test_product_tables_equal_oracle_tables(tts, oracle, src, dst):
             assert a[0].shape == b[0].shape and np.array_equal(a[0], b[0]) and np.array_equal(a[1], b[1])
 
 
+def test_parse_vf_rgb24_input(tts):
+    # a crop in front of the scale works on RGB pixels (no chroma grid); behind it the planes are yuv420p again
+    g = tts.parse_vf("crop=64:33:11:7,scale=128:96,pad=140:100:-1:-1", 100, 60, in_fmt="rgb24").as_dict()
+    assert (g["in_fmt"], g["pre_x"], g["pre_y"], g["pre_w"], g["pre_h"]) == (1, 11, 7, 64, 33)
+    assert (g["pad_x"], g["pad_y"], g["out_w"], g["out_h"], g["out_fmt"]) == (6, 2, 140, 100, 0)
+    with pytest.raises(tts.TtsError, match="UNSUPPORTED"):
+        tts.parse_vf("scale=10:10,format=rgb24", 64, 36, in_fmt="rgb24")
+    with pytest.raises(tts.TtsError, match="UNSUPPORTED"):
+        tts.parse_vf("crop=31:20", 64, 36, in_fmt="rgb24")              # odd width into the pair-averaging chroma reader
+
+
 def test_frame_bytes(tts):
     assert tts.frame_bytes(1920, 1080) == 3110400
     assert tts.frame_bytes(101, 57) == 101 * 57 + 2 * 51 * 29

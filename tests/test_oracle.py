@@ -88,7 +88,10 @@ def test_golden_vectors(oracle, path):
         return
     g = dict(zip([str(k) for k in z["geom_keys"]], [int(v) for v in z["geom"]]))
     for key in z.files:
-        if key.startswith("out_"):
+        if key == "out_rgbseed":                      # packed rgb24 in: seeded random bytes
+            src = np.random.default_rng(synth.SEED).integers(0, 256, (1, g["in_w"] * g["in_h"] * 3), dtype=np.uint8)
+            assert np.array_equal(oracle.run_chain(g, src)[0], z[key]), key
+        elif key.startswith("out_"):
             src = synth.frames(key[4:], g["in_w"], g["in_h"], 1)
             assert np.array_equal(oracle.run_chain(g, src)[0], z[key]), key
 

@@ -149,3 +149,21 @@ def test_rgb_scaled_path_agrees_with_scaling_then_converting_in_float(tts, oracl
     ref = np.clip(np.stack([yy + 1.596027 * vf_, yy - 0.391762 * uf - 0.812968 * vf_, yy + 2.017232 * uf], -1), 0, 255)
     d = np.abs(got - ref)[8:, 8:]                              # (first outputs of an enlarged axis: see above)
     assert d.max() <= 8.5 and d.mean() < 1.6, (d.max(), d.mean())
+
+
+def test_rgb24_input_is_bt601_within_a_level(tts, oracle):
+    """rgb24 in, yuv420p out, no scaling: Y = 16 + 219/255 (0.299 R + 0.587 G + 0.114 B) to a level; chroma = the
+    BT.601 difference signals of the average of two neighbouring pixels, resampled 2:1 down the rows by the cubic
+    (every RGB row carries chroma), within 2 levels of the float resampler."""
+    w, h = 64, 48
+    g = tts.parse_vf("format=yuv420p", w, h, in_fmt="rgb24")
+    rng = np.random.default_rng(3)
+    rgb = rng.integers(0, 256, (1, h, w, 3), dtype=np.uint8)
+    y, u, v = synth.split(oracle.run_chain(g, rgb.reshape(1, -1))[0], w, h)
+    r, gg, b = (rgb[0, :, :, k].astype(np.float64) for k in range(3))
+    assert np.abs(y - (16 + 219.0 / 255 * (0.299 * r + 0.587 * gg + 0.114 * b))).max() <= 1.0
+    pair = lambda p: (p[:, 0::2] + p[:, 1::2]) / 2
+    cb = 128 + 224.0 / 255 * (-0.169 * pair(r) - 0.331 * pair(gg) + 0.5 * pair(b))
+    cr = 128 + 224.0 / 255 * (0.5 * pair(r) - 0.419 * pair(gg) - 0.081 * pair(b))
+    vm = axis_matrix(h, h // 2, "bicubic")
+    assert np.abs(u - np.clip(vm @ cb, 0, 255)).max() <= 2.0 and np.abs(v - np.clip(vm @ cr, 0, 255)).max() <= 2.0

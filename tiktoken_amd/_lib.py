@@ -14,7 +14,7 @@ class Geom(ctypes.Structure):
     _fields_ = [(n, ctypes.c_int32) for n in (
         "in_w", "in_h", "pre_x", "pre_y", "pre_w", "pre_h", "do_scale", "alg", "sc_w", "sc_h",
         "crop_x", "crop_y", "crop_w", "crop_h", "do_pad", "pad_x", "pad_y", "out_w", "out_h",
-        "fill_y", "fill_u", "fill_v", "out_range", "out_fmt", "rgb_stage", "fill_rgb")]
+        "fill_y", "fill_u", "fill_v", "out_range", "out_fmt", "rgb_stage", "fill_rgb", "in_fmt")]
 
     def as_dict(self):
         return {n: getattr(self, n) for n, _ in self._fields_}
@@ -29,6 +29,7 @@ class Frame(ctypes.Structure):
 # every symbol include/ttscale.h declares: name -> (restype, argtypes)
 SYMBOLS = {
     "tts_parse_vf": (ctypes.c_int, [ctypes.c_char_p, ctypes.c_int, ctypes.c_int, ctypes.POINTER(Geom)]),
+    "tts_parse_vf_fmt": (ctypes.c_int, [ctypes.c_char_p, ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.POINTER(Geom)]),
     "tts_plan_create": (ctypes.c_int, [ctypes.POINTER(Geom), ctypes.POINTER(ctypes.c_void_p)]),
     "tts_plan_destroy": (None, [ctypes.c_void_p]),
     "tts_plan_geom": (ctypes.c_int, [ctypes.c_void_p, ctypes.POINTER(Geom)]),

@@ -33,6 +33,6 @@ void build_range_lut(int out_range, bool chroma, unsigned char lut[256]);
 bool range_affine(int out_range, bool chroma, int &mul, int &add, int &shift);   // the same step in closed form, verified against the table
 
 // "-vf" chain parser; err receives a one-line reason on failure.
-int  parse_vf(const char *vf, int iw, int ih, tts_geom &g, std::string &err);
+int  parse_vf(const char *vf, int iw, int ih, tts_geom &g, std::string &err, int in_fmt = TTS_FMT_YUV420P);
 
 }  // namespace tts

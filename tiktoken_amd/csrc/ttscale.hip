@@ -52,6 +52,17 @@ int tts_parse_vf(const char *vf, int iw, int ih, tts_geom *out)
     return rc;
 }
 
+int tts_parse_vf_fmt(const char *vf, int iw, int ih, int in_fmt, tts_geom *out)
+{
+    if (!out) return TTS_ERR_INVALID_INPUT;
+    std::string err;
+    tts_geom g;
+    const int rc = tts::parse_vf(vf, iw, ih, g, err, in_fmt);
+    g_last_error = err;
+    if (rc == TTS_OK) *out = g;
+    return rc;
+}
+
 int tts_plan_create(const tts_geom *g, tts_plan **out)
 {
     if (!g || !out) return TTS_ERR_INVALID_INPUT;
@@ -68,6 +79,12 @@ int tts_plan_create(const tts_geom *g, tts_plan **out)
     int cus = 0;
     if (hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) == hipSuccess && cus > 0) p->n_cus = cus;
     std::vector<uint32_t> tab;
+    if (g->in_fmt == TTS_FMT_RGB24) {
+        rc = tts::rgbin_plan_create(*g, &p->rgbin);            // (sets the error text itself)
+        if (rc) { tts_plan_destroy(p); return rc; }
+        *out = p;
+        return TTS_OK;
+    }
     if (g->out_fmt != TTS_FMT_YUV420P) {
         rc = tts::rgb_plan_create(*g, p->n_cus, &p->rgb);      // (sets the error text itself)
         if (rc) { tts_plan_destroy(p); return rc; }
@@ -107,6 +124,7 @@ void tts_plan_destroy(tts_plan *p)
     free_class(p->cls[0]); free_class(p->cls[1]);
     (void)hipFree(p->d_tab);
     tts::rgb_plan_destroy(p->rgb);
+    tts::rgbin_plan_destroy(p->rgbin);
     delete p;
 }
 
@@ -122,7 +140,7 @@ int tts_plan_device(const tts_plan *p) { return p ? p->device : TTS_ERR_INVALID_
 size_t tts_plan_frame_bytes(const tts_plan *p, int which)
 {
     if (!p) return 0;
-    if (which == 0) return tts_frame_bytes(p->g.in_w, p->g.in_h);
+    if (which == 0) return p->g.in_fmt == TTS_FMT_RGB24 ? size_t(p->g.in_w) * p->g.in_h * 3 : tts_frame_bytes(p->g.in_w, p->g.in_h);
     if (p->g.out_fmt == TTS_FMT_YUV420P) return tts_frame_bytes(p->g.out_w, p->g.out_h);
     return size_t(p->g.out_w) * p->g.out_h * (p->g.out_fmt >= TTS_FMT_RGBA ? 4 : 3);
 }
@@ -130,7 +148,7 @@ size_t tts_plan_frame_bytes(const tts_plan *p, int which)
 int tts_plan_filter(const tts_plan *p, int plane_class, int axis, int *taps, int *n_out, int16_t *coef, int32_t *pos)
 {
     if (!p || plane_class < 0 || plane_class > 1 || axis < 0 || axis > 1) return TTS_ERR_INVALID_INPUT;
-    if (p->rgb) return TTS_ERR_UNSUPPORTED;           // (the RGB path keeps four tables: luma and chroma of a dst_w x dst_h context)
+    if (p->rgb || p->rgbin) return TTS_ERR_UNSUPPORTED;   // (the RGB paths keep four tables: luma and chroma of one swscale context)
     const tts::AxisFilter &f = axis == 0 ? p->cls[plane_class].h : p->cls[plane_class].v;
     if (taps) *taps = f.size;
     if (n_out) *n_out = f.dst;
@@ -154,6 +172,7 @@ int tts_plan_kernel_kind(const tts_plan *p, int plane_class)
 {
     if (!p || plane_class < 0 || plane_class > 1) return TTS_ERR_INVALID_INPUT;
     if (p->rgb) return 6;
+    if (p->rgbin) return 7;
     const ClassPlan &c = p->cls[plane_class];
     if (c.kind == 0) return 0;
     if (c.kind == 2) return 3 + c.col_dmas;
@@ -166,6 +185,7 @@ const char *tts_plan_kernel_name(const tts_plan *p, int plane_class)
     static thread_local char buf[96];
     if (!p || plane_class < 0 || plane_class > 1) return "";
     if (p->rgb) return tts::rgb_plan_kernel_name(p->rgb);
+    if (p->rgbin) return tts::rgbin_plan_kernel_name(p->rgbin);
     const ClassPlan &c = p->cls[plane_class];
     if (c.kind == 0) std::snprintf(buf, sizeof buf, "generic");
     else if (c.kind == 2) std::snprintf(buf, sizeof buf, "column_lds<%d,%d,%d,%d,%d>", c.NTP, c.Rc, c.col_dmas, c.col_nc, column_depth(c.NTP));
@@ -209,6 +229,23 @@ int run_batch_impl(const tts_plan *p, const void *src, size_t src_pitch, const i
     if (n_frames == 0) return TTS_OK;
     if (!src || !dst) return TTS_ERR_INVALID_INPUT;
     const tts_geom &g = p->g;
+    if (p->rgbin) {
+        // packed rgb24 in (one plane, rows sstride[0] bytes apart), packed or strided I420 out; the kernel covers the canvas
+        if (sstride[0] < g.in_w * 3 || dstride[0] < g.out_w || dstride[1] < ceil_shift(g.out_w, 1)) return TTS_ERR_INVALID_INPUT;
+        const size_t sbytes = size_t(sstride[0]) * g.in_h;
+        const size_t dbytes = size_t(dstride[0]) * g.out_h + 2 * size_t(dstride[1]) * ceil_shift(g.out_h, 1);
+        if (src_pitch < sbytes || dst_pitch < dbytes) return TTS_ERR_INVALID_INPUT;
+        if (src_pitch >= (size_t(1) << 31) || dst_pitch >= (size_t(1) << 31)) return TTS_ERR_UNSUPPORTED;
+        if (const int rc = check_device(p)) return rc;
+        FrameAddr addr{};
+        addr.src_pitch = uint32_t(src_pitch); addr.dst_pitch = uint32_t(dst_pitch);
+        addr.src_plane[0] = uint32_t(g.pre_y) * uint32_t(sstride[0]) + uint32_t(g.pre_x) * 3u;
+        addr.dst_plane[0] = 0;
+        addr.dst_plane[1] = uint32_t(dstride[0]) * uint32_t(g.out_h);
+        addr.dst_plane[2] = addr.dst_plane[1] + uint32_t(dstride[1]) * uint32_t(ceil_shift(g.out_h, 1));
+        return tts::rgbin_launch(p->rgbin, static_cast<const uint8_t *>(src), static_cast<uint8_t *>(dst), n_frames, sstride[0], dstride,
+                                 addr, static_cast<hipStream_t>(hip_stream));
+    }
     const int bpp = g.out_fmt == TTS_FMT_YUV420P ? 0 : g.out_fmt >= TTS_FMT_RGBA ? 4 : 3;   // packed RGB out: one plane
     for (int ci = 0; ci < 2; ++ci)
         if (sstride[ci] < ceil_shift(g.in_w, ci) || (!bpp && dstride[ci] < ceil_shift(g.out_w, ci))) return TTS_ERR_INVALID_INPUT;
@@ -280,7 +317,7 @@ int tts_run_batch(const tts_plan *p, const void *src, size_t src_pitch, void *ds
 {
     if (!p) return TTS_ERR_INVALID_INPUT;
     const int bpp = p->g.out_fmt == TTS_FMT_YUV420P ? 1 : p->g.out_fmt >= TTS_FMT_RGBA ? 4 : 3;
-    const int sstride[2] = {p->g.in_w, ceil_shift(p->g.in_w, 1)}, dstride[2] = {p->g.out_w * bpp, ceil_shift(p->g.out_w, 1)};
+    const int sstride[2] = {p->g.in_fmt == TTS_FMT_RGB24 ? p->g.in_w * 3 : p->g.in_w, ceil_shift(p->g.in_w, 1)}, dstride[2] = {p->g.out_w * bpp, ceil_shift(p->g.out_w, 1)};
     return run_batch_impl(p, src, src_pitch, sstride, dst, dst_pitch, dstride, n_frames, hip_stream);
 }
 
@@ -299,6 +336,7 @@ int tts_run(const tts_plan *p, const tts_frame *src, const tts_frame *dst, int n
     if (n_frames == 0) return TTS_OK;
     if (!src || !dst) return TTS_ERR_INVALID_INPUT;
     const tts_geom &g = p->g;
+    if (p->rgbin) { g_last_error = "rgb24 in: use the batch entry points (packed frames)"; return TTS_ERR_UNSUPPORTED; }
     const int bpp = g.out_fmt == TTS_FMT_YUV420P ? 0 : g.out_fmt >= TTS_FMT_RGBA ? 4 : 3;
     const int ndp = bpp ? 1 : 3;                       // destination planes: packed RGB frames have one
     // Host frames (TTS_MEM_HOST, every frame of the call, both sides): staged through the per-device pool

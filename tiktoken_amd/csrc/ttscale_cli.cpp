@@ -3,7 +3,9 @@
 // The reference spawns `ffmpeg` with a filter chain (scripts/processVideos.js:71-108 through
 // fluent-ffmpeg, src/services/video.js:329-334 through ffmpeg-kit).  Decode/encode are out of
 // scope, so this CLI speaks rawvideo only:
-//   ttscale -s 1920x1080 [-pix_fmt yuv420p] [-f rawvideo] -i in.yuv -vf "<chain>" [-y] out.yuv
+//   ttscale -s 1920x1080 [-pix_fmt yuv420p|rgb24] [-f rawvideo] -i in.yuv -vf "<chain>" [-pix_fmt <fmt>] [-y] out.yuv
+// As with ffmpeg, -pix_fmt in front of -i names the input's format; behind it, the output's: yuv420p, yuvj420p,
+// rgb24, bgr24, rgba, bgra append a `format=` to the chain (packed RGB out).
 // Exit status 0 on success; otherwise one line on stderr and a non-zero status, like ffmpeg.
 #include <cstdio>
 #include <cstdlib>
@@ -21,14 +23,21 @@ static int fail(const char *what, int rc)
 
 int main(int argc, char **argv)
 {
-    std::string in, out, vf = "format=yuv420p", size;
+    std::string in, out, vf = "format=yuv420p", size, out_fmt;
+    int in_fmt = TTS_FMT_YUV420P;
     for (int i = 1; i < argc; ++i) {
         const std::string a = argv[i];
         auto next = [&]() -> const char * { return i + 1 < argc ? argv[++i] : ""; };
         if (a == "-s" || a == "-video_size") size = next();
         else if (a == "-i") in = next();
         else if (a == "-vf" || a == "-filter:v") vf = next();
-        else if (a == "-pix_fmt") { if (std::strcmp(next(), "yuv420p")) { std::fprintf(stderr, "ttscale: only -pix_fmt yuv420p\n"); return 1; } }
+        else if (a == "-pix_fmt") {
+            const std::string f = next();
+            if (in.empty()) {                                // in front of -i: the input
+                if (f == "rgb24") in_fmt = TTS_FMT_RGB24;
+                else if (f != "yuv420p") { std::fprintf(stderr, "ttscale: input -pix_fmt yuv420p or rgb24\n"); return 1; }
+            } else out_fmt = f;
+        }
         else if (a == "-f") { if (std::strcmp(next(), "rawvideo")) { std::fprintf(stderr, "ttscale: only -f rawvideo\n"); return 1; } }
         else if (a == "-y" || a == "-an" || a == "-hide_banner") {}
         else if (a == "-version") { std::printf("%s\n", tts_version()); return 0; }
@@ -40,8 +49,9 @@ int main(int argc, char **argv)
         std::fprintf(stderr, "usage: ttscale -s WxH -i in.yuv -vf \"<chain>\" out.yuv\n");
         return 1;
     }
+    if (!out_fmt.empty()) vf += ",format=" + out_fmt;
     tts_geom g;
-    int rc = tts_parse_vf(vf.c_str(), iw, ih, &g);
+    int rc = tts_parse_vf_fmt(vf.c_str(), iw, ih, in_fmt, &g);
     if (rc) return fail("filter chain", rc);
     tts_plan *plan = nullptr;
     rc = tts_plan_create(&g, &plan);

@@ -147,6 +147,7 @@ struct tts_plan {
     ClassPlan cls[2];
     uint32_t *d_tab = nullptr;        // strip tables of both classes
     tts::RgbPlan *rgb = nullptr;      // packed-RGB output (g.out_fmt != yuv420p): the plan of ttscale_rgb.hip; cls[] stay empty
+    tts::RgbInPlan *rgbin = nullptr;  // packed rgb24 input (g.in_fmt): likewise
     int device = 0;
     int n_cus = 256;
 };

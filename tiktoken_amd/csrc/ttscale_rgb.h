@@ -25,4 +25,14 @@ const char *rgb_plan_kernel_name(const RgbPlan *p);
 int rgb_launch(const RgbPlan *p, const uint8_t *src, uint8_t *dst, int n, const int src_stride[2], int dst_stride,
                uint64_t src_span, uint64_t dst_span, const FrameAddr &addr, hipStream_t st);
 
+// ---- packed rgb24 INPUT, yuv420p out (tts_geom.in_fmt == TTS_FMT_RGB24) ----------------------------------
+struct RgbInPlan;
+int  rgbin_plan_create(const tts_geom &g, RgbInPlan **out);
+void rgbin_plan_destroy(RgbInPlan *p);
+const char *rgbin_plan_kernel_name(const RgbInPlan *p);
+// frames [0, n): addr.src_plane[0] = the pre-cropped origin inside a source frame, addr.dst_plane[k] = the
+// origin of canvas plane k inside an output frame (packed mode only); src_stride = bytes between RGB rows
+int rgbin_launch(const RgbInPlan *p, const uint8_t *src, uint8_t *dst, int n, int src_stride, const int dst_stride[2],
+                 const FrameAddr &addr, hipStream_t st);
+
 }  // namespace tts

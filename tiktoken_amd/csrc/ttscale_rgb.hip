@@ -607,6 +607,70 @@ __global__ __launch_bounds__(kBlock, 4) void rgb_strip_kernel(const uint8_t *__r
 #endif
 }
 
+// ---- packed rgb24 in, yuv420p out: any tap counts, one lane per output sample ---------------------------
+// swscale's input side (input.c rgb24ToY_c / rgb24ToUV_half_c, BT.601 limited range, coefficients in 15
+// fractional bits) evaluated on the fly in front of the scaler's arithmetic: samples enter the horizontal
+// pass as 14-bit values (Y << 6, C << 6; chroma from the SUM of two neighbouring pixels), the pass is
+// hScale16To15_c's (>> 13, clip to 32767), the vertical pass the planar one.  Chroma has one row per SOURCE
+// row (RGB is not subsampled vertically), so its vertical filter maps src_h rows to ceil(dst_h / 2).
+struct RgbInArgs {
+    const uint8_t *src;
+    uint8_t       *dst;
+    const int32_t *lhpos, *lvpos, *chpos, *cvpos;
+    const int16_t *lhtaps, *lvtaps, *chtaps, *cvtaps;
+    int32_t lht, lvt, cht, cvt;
+    int32_t canvas_w[2], canvas_h[2];  // output planes, luma / chroma
+    int32_t px[2], py[2], pw[2], ph[2];   // picture rectangle inside them
+    int32_t ox[2], oy[2];              // its origin in the scaled plane (crop behind the scale)
+    int32_t dst_stride[2], src_stride;
+    int32_t fill[3];
+    int32_t frame0;
+    int32_t coef[9];                   // ry gy by, ru gu bu, rv gv bv
+    FrameAddr addr;
+};
+
+__global__ __launch_bounds__(kBlock) void rgbin_generic_kernel(const RgbInArgs a)
+{
+    const int plane = int(blockIdx.z) % 3, frame = a.frame0 + int(blockIdx.z) / 3;
+    const int ci = plane ? 1 : 0;
+    const int x = int(blockIdx.x) * 64 + int(threadIdx.x & 63);
+    const int y = int(blockIdx.y) * 4 + int(threadIdx.x >> 6);
+    if (x >= a.canvas_w[ci] || y >= a.canvas_h[ci]) return;
+    const uint8_t *sp = a.src + size_t(frame) * a.addr.src_pitch + a.addr.src_plane[0];
+    uint8_t *dp = a.dst + size_t(frame) * a.addr.dst_pitch + a.addr.dst_plane[plane];
+    int out = a.fill[plane];
+    if (y >= a.py[ci] && y < a.py[ci] + a.ph[ci] && x >= a.px[ci] && x < a.px[ci] + a.pw[ci]) {
+        const int vx = a.ox[ci] + x - a.px[ci], vy = a.oy[ci] + y - a.py[ci];
+        const int32_t *hpos = ci ? a.chpos : a.lhpos, *vpos = ci ? a.cvpos : a.lvpos;
+        const int ht = ci ? a.cht : a.lht, vt = ci ? a.cvt : a.lvt;
+        const int16_t *hc = (ci ? a.chtaps : a.lhtaps) + size_t(vx) * ht, *vc = (ci ? a.cvtaps : a.lvtaps) + size_t(vy) * vt;
+        const int hp = hpos[vx], vp = vpos[vy];
+        const int cr = a.coef[3 * plane], cg = a.coef[3 * plane + 1], cb = a.coef[3 * plane + 2];
+        int val = 64 << 12;
+        for (int j = 0; j < vt; ++j) {
+            const uint8_t *row = sp + size_t(vp + j) * size_t(a.src_stride);
+            int acc = 0;
+            for (int k = 0; k < ht; ++k) {
+                int s14;
+                if (ci == 0) {
+                    const uint8_t *q = row + 3 * (hp + k);
+                    s14 = (cr * q[0] + cg * q[1] + cb * q[2] + (32 << 14) + (1 << 8)) >> 9;
+                } else {
+                    const uint8_t *q = row + 6 * (hp + k);
+                    s14 = (cr * (q[0] + q[3]) + cg * (q[1] + q[4]) + cb * (q[2] + q[5]) + (256 << 15) + (1 << 9)) >> 10;
+                }
+                acc += s14 * int(hc[k]);
+            }
+            acc >>= 13;
+            acc = acc < 32767 ? acc : 32767;
+            val += acc * int(vc[j]);
+        }
+        val >>= 19;                                            // (a 1-tap vertical filter gives (t + 64) >> 7: the same value)
+        out = val < 0 ? 0 : val > 255 ? 255 : val;
+    }
+    dp[size_t(y) * size_t(a.dst_stride[ci]) + x] = uint8_t(out);
+}
+
 template <class T>
 bool upload_vec(T *&dptr, const std::vector<T> &host)
 {
@@ -919,6 +983,87 @@ int rgb_launch(const RgbPlan *p, const uint8_t *src, uint8_t *dst, int n, const 
             a.cox = p->cox; a.coy = p->coy;
             rc = launch_rgb("rgb_generic_kernel", rgb_generic_kernel, dim3((f.canvas_w + 63) / 64, (f.canvas_h + 3) / 4, nf), dim3(kBlock), 0, st, a);
         }
+    }
+    return rc;
+}
+
+}  // namespace tts
+
+namespace tts {
+
+struct RgbInPlan {
+    tts_geom g{};
+    AxisFilter lh, lv, ch, cv;
+    int32_t *d_pos[4] = {nullptr, nullptr, nullptr, nullptr};
+    int16_t *d_taps[4] = {nullptr, nullptr, nullptr, nullptr};
+    char name[96] = "";
+};
+
+int rgbin_plan_create(const tts_geom &g, RgbInPlan **out)
+{
+    *out = nullptr;
+    if (g.in_fmt != TTS_FMT_RGB24 || g.out_fmt != TTS_FMT_YUV420P || g.out_range != TTS_RANGE_KEEP || (g.pre_w & 1)) {
+        set_last_error("rgb24 in: the chain must hand out yuv420p (no range step) and read an even width");
+        return TTS_ERR_UNSUPPORTED;
+    }
+    RgbInPlan *p = new (std::nothrow) RgbInPlan();
+    if (!p) return TTS_ERR_INITIALIZATION_FAILED;
+    p->g = g;
+    int rc = TTS_OK;
+    if (!build_axis_filter(g.pre_w, g.sc_w, 1 << 14, g.alg, p->lh) || !build_axis_filter(g.pre_h, g.sc_h, 1 << 12, g.alg, p->lv) ||
+        !build_axis_filter(g.pre_w / 2, (g.sc_w + 1) >> 1, 1 << 14, g.alg, p->ch) || !build_axis_filter(g.pre_h, (g.sc_h + 1) >> 1, 1 << 12, g.alg, p->cv)) {
+        set_last_error("filter tables"); rc = TTS_ERR_INVALID_INPUT;
+    }
+    const AxisFilter *f[4] = {&p->lh, &p->lv, &p->ch, &p->cv};
+    for (int i = 0; i < 4 && !rc; ++i)
+        if (!upload_vec(p->d_pos[i], f[i]->pos) || !upload_vec(p->d_taps[i], f[i]->taps)) { set_last_error("table upload failed (hipMalloc / hipMemcpy)"); rc = TTS_ERR_INITIALIZATION_FAILED; }
+    std::snprintf(p->name, sizeof p->name, "rgbin_generic<%d,%d,%d,%d>", p->lh.size, p->lv.size, p->ch.size, p->cv.size);
+    if (rc) { rgbin_plan_destroy(p); return rc; }
+    *out = p;
+    return TTS_OK;
+}
+
+void rgbin_plan_destroy(RgbInPlan *p)
+{
+    if (!p) return;
+    for (int i = 0; i < 4; ++i) { (void)hipFree(p->d_pos[i]); (void)hipFree(p->d_taps[i]); }
+    delete p;
+}
+
+const char *rgbin_plan_kernel_name(const RgbInPlan *p) { return p ? p->name : ""; }
+
+int rgbin_launch(const RgbInPlan *p, const uint8_t *src, uint8_t *dst, int n, int src_stride, const int dst_stride[2],
+                 const FrameAddr &addr, hipStream_t st)
+{
+    if (addr.use_table) { set_last_error("rgb24 in: packed batches only"); return TTS_ERR_UNSUPPORTED; }
+    const tts_geom &g = p->g;
+    RgbInArgs a{};
+    a.src = src; a.dst = dst;
+    a.lhpos = p->d_pos[0]; a.lvpos = p->d_pos[1]; a.chpos = p->d_pos[2]; a.cvpos = p->d_pos[3];
+    a.lhtaps = p->d_taps[0]; a.lvtaps = p->d_taps[1]; a.chtaps = p->d_taps[2]; a.cvtaps = p->d_taps[3];
+    a.lht = p->lh.size; a.lvt = p->lv.size; a.cht = p->ch.size; a.cvt = p->cv.size;
+    const int content_w = g.do_pad ? (g.crop_w & ~1) : g.crop_w;     // vf_pad: an odd picture loses its last column to the fill
+    for (int k = 0; k < 2; ++k) {
+        a.canvas_w[k] = (g.out_w + k) >> k; a.canvas_h[k] = (g.out_h + k) >> k;
+        a.px[k] = g.do_pad ? g.pad_x >> k : 0; a.py[k] = g.do_pad ? g.pad_y >> k : 0;
+        a.pw[k] = (content_w + k) >> k; a.ph[k] = (g.crop_h + k) >> k;
+        a.ox[k] = g.crop_x >> k; a.oy[k] = g.crop_y >> k;
+        a.dst_stride[k] = dst_stride[k];
+    }
+    a.src_stride = src_stride;
+    a.fill[0] = g.fill_y; a.fill[1] = g.fill_u; a.fill[2] = g.fill_v;
+    // utils.c fill_rgb2yuv_table(): the default matrix's table, 15 fractional bits
+    const double S = 32768.0;
+    const int coef[9] = {int(0.299 * 219 / 255 * S + 0.5), int(0.587 * 219 / 255 * S + 0.5), int(0.114 * 219 / 255 * S + 0.5),
+                         -int(0.169 * 224 / 255 * S + 0.5), -int(0.331 * 224 / 255 * S + 0.5), int(0.500 * 224 / 255 * S + 0.5),
+                         int(0.500 * 224 / 255 * S + 0.5), -int(0.419 * 224 / 255 * S + 0.5), -int(0.081 * 224 / 255 * S + 0.5)};
+    for (int i = 0; i < 9; ++i) a.coef[i] = coef[i];
+    a.addr = addr;
+    int rc = TTS_OK;
+    for (int f0 = 0; f0 < n && !rc; f0 += 21845) {          // grid.z = frames x 3 planes
+        const int nf = std::min(21845, n - f0);
+        a.frame0 = f0;
+        rc = launch_rgb("rgbin_generic_kernel", rgbin_generic_kernel, dim3((g.out_w + 63) / 64, (g.out_h + 3) / 4, nf * 3), dim3(kBlock), 0, st, a);
     }
     return rc;
 }

@@ -18,10 +18,14 @@ def frame_bytes(w, h):
     return int(_lib.lib().tts_frame_bytes(w, h))
 
 
-def parse_vf(vf, iw, ih):
-    """Resolve a filter chain for an iw x ih input -> Geom (raises TtsError)."""
+FMT = {"yuv420p": 0, "rgb24": 1, "bgr24": 2, "rgba": 3, "bgra": 4}
+
+
+def parse_vf(vf, iw, ih, in_fmt="yuv420p"):
+    """Resolve a filter chain for an iw x ih input -> Geom (raises TtsError).  in_fmt: "yuv420p", or "rgb24"
+    for a chain fed with packed RGB (`-pix_fmt rgb24 -i ...`)."""
     g = Geom()
-    rc = _lib.lib().tts_parse_vf(vf.encode(), iw, ih, ctypes.byref(g))
+    rc = _lib.lib().tts_parse_vf_fmt(vf.encode(), iw, ih, FMT[in_fmt], ctypes.byref(g))
     check(rc, _lib.lib().tts_last_error().decode() if rc else "")
     return g
 
@@ -76,8 +80,8 @@ class Plan:
         check(rc, _lib.lib().tts_last_error().decode() if rc else "")
 
     @classmethod
-    def from_vf(cls, vf, iw, ih):
-        return cls(parse_vf(vf, iw, ih))
+    def from_vf(cls, vf, iw, ih, in_fmt="yuv420p"):
+        return cls(parse_vf(vf, iw, ih, in_fmt))
 
     def close(self):
         if self._h:
