@@ -781,6 +781,9 @@ __global__ __launch_bounds__(kBlock) void column_lds_kernel(const uint8_t *__res
     // rest they would fill whole XCDs by themselves and leave the scaler the others -- 4.5x slower thumbnails)
     if (blockIdx.x >= a.scaler_blocks) { pad_fill_blocks(a, dst, blockIdx.x - a.scaler_blocks); return; }
     uint32_t lb = xcd_remap(blockIdx.x, a.scaler_blocks);
+#ifdef TTS_EXPERIMENTS
+    if (a.dbg && threadIdx.x == 0) a.dbg[2 * blockIdx.x] = __builtin_amdgcn_s_memrealtime();
+#endif
     const int ci = lb >= a.c[0].nblocks ? 1 : 0;
     if (ci) lb -= a.c[0].nblocks;
     const StripClass &c = a.c[ci];
@@ -922,6 +925,9 @@ __global__ __launch_bounds__(kBlock) void column_lds_kernel(const uint8_t *__res
             hist[s % D] = cnt;
         }
     }
+#ifdef TTS_EXPERIMENTS
+    if (a.dbg && threadIdx.x == 0) a.dbg[2 * blockIdx.x + 1] = __builtin_amdgcn_s_memrealtime();
+#endif
 #endif
 }
 

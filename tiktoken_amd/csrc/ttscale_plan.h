@@ -767,6 +767,14 @@ int launch_all(const tts_plan *p, const uint8_t *src, uint8_t *dst, int n, const
         }
     }
 
+    // timing experiments (-DTTS_EXPERIMENTS builds; outputs are wrong): a zero-record descriptor makes the
+    // range check drop that buffer's traffic while the instruction stream stays
+    auto exp_knobs = [&](StripArgs &a) {
+        if (p->knobs.exp_nosrc) a.src_span = 0;
+        if (p->knobs.exp_srcpitch0) a.addr.src_pitch = 0;    // every frame reads frame 0: source stays in L2
+        if (p->knobs.exp_dstpitch0) a.addr.dst_pitch = 0;    // every frame writes frame 0: output stays in L2
+        if (p->knobs.exp_nodst) a.dst_span = 0;
+    };
     // strip classes: one launch when both classes run the same instantiation, else one each
     int strip_cls[2], ns = 0;
     for (int ci = 0; ci < 2; ++ci) if (p->cls[ci].kind == 1 && active(ci)) strip_cls[ns++] = ci;
@@ -778,12 +786,7 @@ int launch_all(const tts_plan *p, const uint8_t *src, uint8_t *dst, int n, const
     for (int k = 0; k < ns; ++k) {
         StripArgs a{};
         a.src_span = src_span; a.dst_span = dst_span; a.addr = addr;
-        // timing experiments (outputs are wrong): a zero-record descriptor makes the range check drop that
-        // buffer's traffic while the instruction stream stays
-        if (p->knobs.exp_nosrc) a.src_span = 0;
-        if (p->knobs.exp_srcpitch0) a.addr.src_pitch = 0;    // every frame reads frame 0: source stays in L2
-        if (p->knobs.exp_dstpitch0) a.addr.dst_pitch = 0;    // every frame writes frame 0: output stays in L2
-        if (p->knobs.exp_nodst) a.dst_span = 0;
+        exp_knobs(a);
         const int ci = strip_cls[k];
         StripChoice ch = strip_choice(p->cls[ci], p->knobs);
         // Per-frame plane pointers: a segment of the LDS-staged kernel must not hold both the first and
@@ -878,6 +881,7 @@ int launch_all(const tts_plan *p, const uint8_t *src, uint8_t *dst, int n, const
             if (!fn) return TTS_ERR_UNSUPPORTED;
             StripArgs a{};
             a.src_span = src_span; a.dst_span = dst_span; a.addr = addr;
+            exp_knobs(a);
             if (cmerged) {
                 int planes_each[2] = {nplanes(0), nplanes(1)};
                 const size_t si = choose_column_segs(p, col_cls, cm, 2, n, planes_each, fn, min_segs);
@@ -890,6 +894,9 @@ int launch_all(const tts_plan *p, const uint8_t *src, uint8_t *dst, int n, const
                 a.c[1] = a.c[0]; a.c[1].nblocks = 0;
             }
             a.scaler_blocks = a.c[0].nblocks + (cmerged ? a.c[1].nblocks : 0);
+#ifdef TTS_EXPERIMENTS
+            a.dbg = exp_dbg_buffer(a.scaler_blocks);
+#endif
             if (fuse_range) a.range = range;
             if (cmerged) { pad_class(0, kBlock, a.pad[0]); pad_class(1, kBlock, a.pad[1]); }
             else {
