@@ -234,10 +234,14 @@ def test_hip_matches_golden_vectors(tts, path):
     geom = tts.Geom(**g)
     plan = tts.Plan(geom)
     for key in z.files:
-        if key.startswith("out_"):
+        if key == "out_rgbseed":                          # packed rgb24 in: seeded random bytes (tests/golden/make_golden.py)
+            src = np.random.default_rng(synth.SEED).integers(0, 256, (1, g["in_w"] * g["in_h"] * 3), dtype=np.uint8)
+        elif key.startswith("out_"):
             src = synth.frames(key[4:], g["in_w"], g["in_h"], 1)
-            got = plan.run_batch(torch.from_numpy(src).cuda()).cpu().numpy()[0]
-            assert np.array_equal(got, z[key]), "%s %s" % (path, key)
+        else:
+            continue
+        got = plan.run_batch(torch.from_numpy(src).cuda()).cpu().numpy()[0]
+        assert np.array_equal(got, z[key]), "%s %s" % (path, key)
 
 
 def test_plan_tables_match_oracle(tts, oracle):
@@ -357,7 +361,8 @@ def test_lds_kernel_variants(tts, oracle, vf, iw, ih, n, kind):
 
 @pytest.mark.parametrize("knob,val", [("TTS_PACED", "1"), ("TTS_PACED", "0"), ("TTS_LDS_BLOCK", "64"), ("TTS_LDS_BLOCK", "704"),
                                       ("TTS_STRIP_D", "2"), ("TTS_NO_LDS", "1"), ("TTS_NO_G4", "1"), ("TTS_NO_G6", "1"), ("TTS_NO_MERGE", "1"), ("TTS_COL_NC", "1"), ("TTS_WAVE_BASE", "1"), ("TTS_NO_DMA4", "1"),
-                                      ("TTS_COL_FILL", "1"), ("TTS_COL_FILL", "80"), ("TTS_COL_NC_LAUNCH", "1"), ("TTS_COL_NC_LAUNCH", "2")])
+                                      ("TTS_COL_FILL", "1"), ("TTS_COL_FILL", "80"), ("TTS_COL_NC_LAUNCH", "1"), ("TTS_COL_NC_LAUNCH", "2"),
+                                      ("TTS_COL_D4", "0"), ("TTS_COL_D4", "2"), ("TTS_COL_MODEL", "0"), ("TTS_COL_MODEL", "2")])
 def test_tuning_knobs_do_not_change_pixels(tts, oracle, monkeypatch, knob, val):
     import torch
     monkeypatch.setenv(knob, val)
@@ -367,6 +372,38 @@ def test_tuning_knobs_do_not_change_pixels(tts, oracle, monkeypatch, knob, val):
         src = synth.frames("random", iw, ih, 21)
         got = plan.run_batch(torch.from_numpy(src).cuda()).cpu().numpy()
         assert np.array_equal(got, oracle.run_chain(plan.geom, src)), (knob, val, vf)
+
+
+D4_CASES = [
+    # the reference's thumbnail chain (src/services/video.js:329-332) on landscape, portrait and 4K sources
+    ("scale=320x180:force_original_aspect_ratio=decrease,pad=320x180:-1:-1:color=black,format=yuv420p", 1920, 1080, 2),
+    ("scale=320x180:force_original_aspect_ratio=decrease,pad=320x180:-1:-1:color=black,format=yuv420p", 1080, 1920, 2),
+    ("scale=320x180:force_original_aspect_ratio=decrease,pad=320x180:-1:-1:color=black,format=yuv420p", 3840, 2160, 1),
+    ("scale=1280:720", 3840, 2160, 1),                       # 13 taps, two columns per lane
+    ("scale=213:121", 1283, 721, 5),                         # odd everything: frames start at every byte phase, last strip slid
+    ("crop=1001:701:13:7,scale=167:117", 1283, 721, 3),      # odd pre-crop origin
+    ("scale=67:49", 200, 150, 21), ("scale=40:30", 200, 150, 21), ("scale=33:201", 333, 801, 4),
+    ("scale=320:180:flags=area", 3840, 2160, 1),             # 12x with 13 taps: adjacent windows lie 12 bytes apart, no shared span
+]
+
+
+@pytest.mark.parametrize("vf,iw,ih,n", D4_CASES)
+@pytest.mark.parametrize("nc_launch", ["0", "1", "2"])
+def test_column_walk_dot4_form(tts, oracle, monkeypatch, vf, iw, ih, n, nc_launch):
+    """column_lds_kernel's v_dot4 form (two signed-byte digits per tap, pixels biased by 128, byte phase folded
+    into the digit tables; TTS_COL_D4) against the oracle, bit for bit, at one and two columns per lane."""
+    import torch
+    monkeypatch.setenv("TTS_COL_D4", "2")                     # wherever the digit tables exist (the product: above 8 tap pairs)
+    monkeypatch.setenv("TTS_COL_NC_LAUNCH", nc_launch)
+    plan = tts.Plan.from_vf(vf, iw, ih)
+    if plan.kernel_kind(0) in (4, 5) and "area" not in vf:
+        assert "dot4" in plan.kernel_name(0), plan.kernel_name(0)
+    src = synth.frames("random", iw, ih, n)
+    got = plan.run_batch(torch.from_numpy(src).cuda()).cpu().numpy()
+    assert np.array_equal(got, oracle.run_chain(plan.geom, src))
+    src = synth.frames("impulse", iw, ih, n)                 # extreme pixels: 0 / 255 against the largest taps
+    got = plan.run_batch(torch.from_numpy(src).cuda()).cpu().numpy()
+    assert np.array_equal(got, oracle.run_chain(plan.geom, src))
 
 
 def test_pointer_api_shuffled_placements(tts, oracle):
@@ -498,7 +535,7 @@ def test_column_kernel_variants(tts, oracle, vf, iw, ih, n, kind):
     if vf in ("scale=213:121", "scale=1280:720", "scale=720:1280"):
         assert plan.kernel_name(0) == "column_lds<6,12,1,2,4>"      # 11-12 taps after trimming: 6 tap pairs, two columns per lane
     if vf == THUMB_REF and (iw, ih) == (1920, 1080):
-        assert plan.kernel_name(0) == "column_lds<12,24,1,2,4>"     # 23 taps after trimming; two columns per lane up to 12 tap pairs
+        assert plan.kernel_name(0) == "column_lds<12,24,1,2,4,dot4>"   # 23 taps after trimming; two columns per lane up to 12 tap pairs; v_dot4 form above 8
     for pat in ("random", "impulse"):
         src = synth.frames(pat, iw, ih, n)
         got = plan.run_batch(torch.from_numpy(src).cuda()).cpu().numpy()

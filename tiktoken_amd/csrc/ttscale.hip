@@ -188,7 +188,12 @@ const char *tts_plan_kernel_name(const tts_plan *p, int plane_class)
     if (p->rgbin) return tts::rgbin_plan_kernel_name(p->rgbin);
     const ClassPlan &c = p->cls[plane_class];
     if (c.kind == 0) std::snprintf(buf, sizeof buf, "generic");
-    else if (c.kind == 2) std::snprintf(buf, sizeof buf, "column_lds<%d,%d,%d,%d,%d>", c.NTP, c.Rc, c.col_dmas, c.col_nc, column_depth(c.NTP));
+    else if (c.kind == 2) {
+        bool d4 = true;                                  // (as launch_all decides: every column class of the launch)
+        for (int ci = 0; ci < 2; ++ci)
+            if (p->cls[ci].kind == 2) d4 &= column_dot4(p->cls[ci], p->knobs);
+        std::snprintf(buf, sizeof buf, "column_lds<%d,%d,%d,%d,%d%s>", c.NTP, c.Rc, c.col_dmas, c.col_nc, column_depth(c.NTP), d4 ? ",dot4" : "");
+    }
     else {
         const StripChoice ch = strip_choice(c, p->knobs);
         if (ch.lds) std::snprintf(buf, sizeof buf, "strip_lds<%d,%d,%s,%d,%d>", ch.LW, ch.R, ch.g12 == 2 ? "grouped2" : ch.g4 ? "grouped" : "percolumn", ch.lds, ch.depth);

@@ -765,15 +765,27 @@ __device__ __forceinline__ void lds_read_dwords(uint32_t (&w)[NDW], uint32_t p)
 // NC: adjacent output columns per lane (1, 2 or 4: the per-row bookkeeping -- DMA, waits, loop control,
 // the store -- is the same for 1 byte or 4, so small ratios, where it weighs most, take the widest
 // strip their registers allow; the last strip of a row is slid left like strip_lds_kernel's).
-template <int NTP, int R, int NDMA, int NC, int D = 1>
-__global__ __launch_bounds__(kBlock) void column_lds_kernel(const uint8_t *__restrict__ src, uint8_t *__restrict__ dst,
+//
+// D4: the horizontal sum through v_dot4_i32_i8 on the packed bytes themselves.  A 14-bit tap is split into two
+// signed-byte digits, t = 128 th + tl (tl in 0..127), and the pixels are biased to signed bytes (one v_xor
+// 0x80808080 per window dword; 128 * sum(taps) comes back through the accumulator's start value), so that
+// sum(p t) = 128 dot4(p', th) + dot4(p', tl) + bias -- an identity on integers, nothing is rounded.  The window's
+// byte phase in LDS is folded into the digit tables (one table per phase, picked once per walk), which removes
+// every v_perm: per window dword 1 xor + 2 dot4 for 4 taps where the v_dot2 form spends 2 v_perm + 2 v_dot2.
+// With NC = 2 both columns dot the SAME span of NDW + 2 dwords (adjacent windows overlap by three quarters at 6x):
+// one LDS read and one xor pass for both; column 1's digits sit `delta` bytes further on.  Its dword 0 holds
+// taps only where windows were folded at a row's edge: that pair of dot4 runs under a wave-uniform branch.
+template <int NTP, int R, int NDMA, int NC, int D = 1, bool D4 = false>
+__global__ __launch_bounds__(kBlock, (D4 && NC == 2 && NTP == 12 && NDMA == 1) ? 6 : 1) void column_lds_kernel(const uint8_t *__restrict__ src, uint8_t *__restrict__ dst,
                                                             const uint32_t *__restrict__ tab, const StripArgs a)
 {
     static_assert(NTP % 2 == 0 && R % 2 == 0 && (NDMA == 1 || NDMA == 2), "window is whole dwords; ring holds row pairs");
     static_assert(NC == 1 || NC == 2 || NC == 4, "one byte, short or dword store per lane and row");
     static_assert(D >= 1 && R % D == 0, "D source rows in flight, one LDS slot each, rotating with the ring");
+    static_assert(!D4 || NC <= 2, "digit tables exist for one and two columns per lane");
 #if defined(__HIP_DEVICE_COMPILE__)   // the LDS-DMA builtin exists in the device pass only
     constexpr int NDW = NTP / 2 + 1;                 // aligned dwords that hold a 2 * NTP-byte window at any byte phase
+    constexpr int NSP = NC == 2 ? NDW + 2 : NDW;     // D4: dwords of the span that holds every column's window (delta <= 9 bytes: host-checked)
     constexpr int kSlotBytes = NDMA * 1024 + 16;
     __shared__ __attribute__((aligned(16))) uint8_t lds[kBlock / 64][D][kSlotBytes];
 
@@ -808,12 +820,14 @@ __global__ __launch_bounds__(kBlock) void column_lds_kernel(const uint8_t *__res
     doff += uint32_t(col);
     if (!live) doff = kDiscard;                    // see strip_lds_kernel
 
-    uint32_t hc[NC][NTP];
+    [[maybe_unused]] uint32_t hc[D4 ? 1 : NC][D4 ? 1 : NTP];
     uint32_t off[NC];
 #pragma unroll
     for (int j = 0; j < NC; ++j) {
+        if constexpr (!D4) {
 #pragma unroll
-        for (int k = 0; k < NTP; ++k) hc[j][k] = tab[c.hcoef + (col + j) * NTP + k];
+            for (int k = 0; k < NTP; ++k) hc[j][k] = tab[c.hcoef + (col + j) * NTP + k];
+        }
         off[j] = tab[c.hoff + col + j] + soff;
     }
 
@@ -835,6 +849,26 @@ __global__ __launch_bounds__(kBlock) void column_lds_kernel(const uint8_t *__res
         // taps 2tp, 2tp+1 (as 16-bit lanes) sit at bytes o + 2 (tp % 2), +1 of dwords tp / 2, tp / 2 + 1
         psel[j][0] = 0x0c000c00u | o | ((o + 1u) << 16);
         psel[j][1] = 0x0c000c00u | (o + 2u) | ((o + 3u) << 16);
+    }
+
+    // D4: digit tables of this lane's strip for the byte phase its span has in LDS
+    //   NC = 1: [bias][th x NDW][tl x NDW]   NC = 2: [bias0][bias1][th0 x NDW][tl0 x NDW][th1 x NSP][tl1 x NSP]
+    [[maybe_unused]] uint32_t th[NC][D4 ? NSP : 1], tl[NC][D4 ? NSP : 1];
+    [[maybe_unused]] int bias[NC];
+    [[maybe_unused]] bool need0 = false;
+    if constexpr (D4) {
+        constexpr int ESZ = NC == 2 ? 2 + 2 * NDW + 2 * NSP : 1 + 2 * NDW;
+        const uint32_t o0 = (off[0] + row0_off + lbase + uint32_t(reinterpret_cast<uintptr_t>((lds_void_t *)&lds[wave][0][0]))) & 3u;
+        const uint32_t *e = tab + c.hcoef + (uint32_t(strip) * 4u + o0) * uint32_t(ESZ);
+#pragma unroll
+        for (int j = 0; j < NC; ++j) bias[j] = int(e[j]);
+#pragma unroll
+        for (int i = 0; i < NDW; ++i) { th[0][i] = e[NC + i]; tl[0][i] = e[NC + NDW + i]; }
+        if constexpr (NC == 2) {
+#pragma unroll
+            for (int i = 0; i < NSP; ++i) { th[1][i] = e[2 + 2 * NDW + i]; tl[1][i] = e[2 + 2 * NDW + NSP + i]; }
+            need0 = __builtin_amdgcn_ballot_w64((th[1][0] | tl[1][0]) != 0u) != 0ull;
+        }
     }
 
     uint32_t ring[NC][R / 2];
@@ -877,20 +911,42 @@ __global__ __launch_bounds__(kBlock) void column_lds_kernel(const uint8_t *__res
 #pragma unroll
             for (int r = 0; r < D; ++r) younger += hist[r];
             wait_vm_plus<(D - 1) * NDMA>(younger);
-            uint32_t w[NC][NDW];
+            [[maybe_unused]] uint32_t w[D4 ? 1 : NC][D4 ? 1 : NDW];
+            [[maybe_unused]] uint32_t ws[D4 ? NSP : 1];
+            if constexpr (D4) lds_read_dwords<NSP>(ws, lpos[0] + uint32_t(s % D) * uint32_t(kSlotBytes));
+            else {
 #pragma unroll
-            for (int j = 0; j < NC; ++j) lds_read_dwords<NDW>(w[j], lpos[j] + uint32_t(s % D) * uint32_t(kSlotBytes));
+                for (int j = 0; j < NC; ++j) lds_read_dwords<NDW>(w[j], lpos[j] + uint32_t(s % D) * uint32_t(kSlotBytes));
+            }
             // the slot is free again (its bytes sit in registers): request row k + D into it
 #pragma unroll
             for (int d = 0; d < NDMA; ++d)
                 __builtin_amdgcn_raw_ptr_buffer_load_lds(srs, (lds_void_t *)&lds[wave][s % D][d * 1024], 16, csrc[d],
                                                          min(k + D, nrows - 1) * src_stride, 0, 0);
+            if constexpr (D4) {
+#pragma unroll
+                for (int i = 0; i < NSP; ++i) ws[i] ^= 0x80808080u;
+            }
 #pragma unroll
             for (int j = 0; j < NC; ++j) {
                 int acc = 0;
+                if constexpr (D4) {
+                    int hi = 0, lo = bias[j];
+                    if (j == 1 && need0) {                      // wave-uniform: windows folded at a row's edge
+                        hi = __builtin_amdgcn_sdot4(int(ws[0]), int(th[1][0]), hi, false);
+                        lo = __builtin_amdgcn_sdot4(int(ws[0]), int(tl[1][0]), lo, false);
+                    }
 #pragma unroll
-                for (int tp = 0; tp < NTP; ++tp)
-                    acc = dot2(__builtin_amdgcn_perm(w[j][tp / 2 + 1], w[j][tp / 2], psel[j][tp % 2]), hc[j][tp], acc);
+                    for (int i = j; i < (j ? NSP : NDW); ++i) {
+                        hi = __builtin_amdgcn_sdot4(int(ws[i]), int(th[j][i]), hi, false);
+                        lo = __builtin_amdgcn_sdot4(int(ws[i]), int(tl[j][i]), lo, false);
+                    }
+                    acc = (hi << 7) + lo;
+                } else {
+#pragma unroll
+                    for (int tp = 0; tp < NTP; ++tp)
+                        acc = dot2(__builtin_amdgcn_perm(w[j][tp / 2 + 1], w[j][tp / 2], psel[j][tp % 2]), hc[j][tp], acc);
+                }
                 const uint32_t t = hfinish(acc);
                 ring[j][s / 2] = (s & 1) ? __builtin_amdgcn_perm(t, ring[j][s / 2], 0x05040100)
                                          : __builtin_amdgcn_perm(ring[j][s / 2], t, 0x07060100);

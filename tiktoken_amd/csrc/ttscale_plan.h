@@ -46,6 +46,7 @@ struct ClassPlan {
     int col_nc = 1;                    // output columns per lane (1, 2), the most a launch may take
     int col_dmas1 = 0;                 // LDS-DMAs per source row at one column per lane (what small launches take above 8 tap pairs)
     uint32_t hoff1 = 0, hcoef1 = 0;    // window start per column, taps per column [ow][NTP]
+    uint32_t d4tab[3] = {0, 0, 0};     // [nc]: digit tables of the v_dot4 form for nc columns per lane (0 = none: see build_d4_tables)
     HTables ht[2];                     // horizontal tables for N = 8 and N = 16 columns per lane
     std::vector<SegTables> segs;
     // generic tables
@@ -101,6 +102,8 @@ struct Knobs {
     int wave_base = 0;                // tts_run_batch: per-wave descriptors even when the batch fits one base (test knob)
     int col_nc_launch = 0;            // column walk above 8 tap pairs: 1 / 2 columns per lane whatever the launch's size (0 = by size)
     int col_fill = 0;                 // column walk: workgroups per resident slot (in tenths) a segment length must leave; 0 = by tap count
+    int col_d4 = 1;                   // column walk: v_dot4 on packed bytes with two-digit taps instead of v_perm + v_dot2: 0 never, 1 above 8 tap pairs, 2 wherever the tables exist
+    int col_model = 1;                // column walk segment length: 0 = fill rule, 1 = busiest-CU model above 8 tap pairs, 2 = everywhere
     int host_chunk_mb = 128;          // tts_run_host: bytes (source + output) of one pipelined chunk
     void read()
     {
@@ -115,6 +118,8 @@ struct Knobs {
         span_chunks = env_int("TTS_SPAN_CHUNKS", 0);
         wave_base = env_int("TTS_WAVE_BASE", 0);
         col_fill = std::max(0, env_int("TTS_COL_FILL", 0));
+        col_model = env_int("TTS_COL_MODEL", 1);
+        col_d4 = env_int("TTS_COL_D4", 1);
         col_nc_launch = env_int("TTS_COL_NC_LAUNCH", 0);
         host_chunk_mb = std::max(1, env_int("TTS_HOST_CHUNK_MB", 128));
     }
@@ -221,6 +226,51 @@ int lds_dmas(const ClassPlan &c, const HTables &t, int N, const int *lo, int nw,
     return worst <= 64u ? 1 : worst <= 128u ? 2 : (four && worst <= 256u) ? 4 : 0;
 }
 
+// Digit tables of column_lds_kernel's v_dot4 form, one entry per (strip, byte phase of its span in LDS):
+//   nc = 1: [bias][th x NDW][tl x NDW]      nc = 2: [bias0][bias1][th0 x NDW][tl0 x NDW][th1 x NSP][tl1 x NSP]
+// th / tl: the taps' signed-byte digits (t = 128 th + tl, tl in 0..127), byte (phase + k) of the span for tap k of
+// column 0's window, (phase + delta + k) for column 1's, delta = the distance of the two windows; bias = 128 x
+// the column's tap sum (the pixels enter as p - 128).  0 if some tap has no such digits or some delta is too wide.
+uint32_t build_d4_tables(const ClassPlan &c, int NTP, int nc, const std::vector<int> &lo, const std::vector<int16_t> &slots,
+                         std::vector<uint32_t> &tab)
+{
+    const int NDW = NTP / 2 + 1, NSP = nc == 2 ? NDW + 2 : NDW;
+    const int esz = nc == 2 ? 2 + 2 * NDW + 2 * NSP : 1 + 2 * NDW;
+    const int strips = (c.ow + nc - 1) / nc;
+    if (c.ow < nc) return 0;
+    std::vector<uint32_t> out(size_t(strips) * 4 * esz, 0);
+    for (int s = 0; s < strips; ++s) {
+        const int col0 = std::min(s * nc, c.ow - nc);
+        for (int o = 0; o < 4; ++o) {
+            uint32_t *e = out.data() + (size_t(s) * 4 + o) * esz;
+            for (int j = 0; j < nc; ++j) {
+                const int col = col0 + j;
+                const int shift = o + (lo[col] - lo[col0]);
+                const int ndw = j ? NSP : NDW;
+                if (shift < 0 || shift + 2 * NTP > 4 * ndw) return 0;
+                uint8_t hi[4 * 20] = {0}, lw[4 * 20] = {0};
+                int sum = 0;
+                for (int k = 0; k < 2 * NTP; ++k) {
+                    const int t = slots[size_t(col) * 64 + k];
+                    const int l = t & 127, h = (t - l) >> 7;
+                    if (h < -128 || h > 127) return 0;
+                    hi[shift + k] = uint8_t(int8_t(h)); lw[shift + k] = uint8_t(l);
+                    sum += t;
+                }
+                e[j] = uint32_t(128 * sum);
+                uint32_t *th = e + nc + (j ? 2 * NDW : 0), *tl = th + ndw;
+                for (int i = 0; i < ndw; ++i) {
+                    th[i] = uint32_t(hi[4 * i]) | uint32_t(hi[4 * i + 1]) << 8 | uint32_t(hi[4 * i + 2]) << 16 | uint32_t(hi[4 * i + 3]) << 24;
+                    tl[i] = uint32_t(lw[4 * i]) | uint32_t(lw[4 * i + 1]) << 8 | uint32_t(lw[4 * i + 2]) << 16 | uint32_t(lw[4 * i + 3]) << 24;
+                }
+            }
+        }
+    }
+    const uint32_t at = uint32_t(tab.size());
+    tab.insert(tab.end(), out.begin(), out.end());
+    return at;
+}
+
 // min_ntp: column walk only -- at least this many tap pairs (so that both classes of a chain can run the same
 // instantiation, i.e. one launch: see tts_plan_create)
 int build_class(const tts_geom &g, int sub, ClassPlan &c, std::vector<uint32_t> &tab, int min_ntp = 0)
@@ -258,6 +308,7 @@ int build_class(const tts_geom &g, int sub, ClassPlan &c, std::vector<uint32_t> 
         HTables t;                                     // (only `strips` is used by lds_dmas)
         t.strips = c.ow;
         std::vector<int> lo(static_cast<size_t>(c.ow));
+        std::vector<int16_t> slots(size_t(c.ow) * 64, 0);       // every column's window as taps per byte
         const uint32_t hoff1 = uint32_t(tab.size());
         tab.resize(tab.size() + c.ow);
         const uint32_t hcoef1 = uint32_t(tab.size());
@@ -269,6 +320,7 @@ int build_class(const tts_geom &g, int sub, ClassPlan &c, std::vector<uint32_t> 
             for (int j = 0; j < HT; ++j) slot[pos - lo[i] + j] = c.h.taps[size_t(vx) * HT + j];
             tab[hoff1 + i] = uint32_t(lo[i]);
             for (int k = 0; k < NTP; ++k) tab[hcoef1 + size_t(i) * NTP + k] = pack16(slot[2 * k], slot[2 * k + 1]);
+            std::copy(slot, slot + 64, slots.begin() + size_t(i) * 64);
         }
         // columns per lane: two up to 12 tap pairs (2160x3840 -> 720x1280: 25 -> 41 % of peak; four measured the
         // same there and 5 % slower on 4K -> 720p, at 110 VGPRs; at 10-12 tap pairs, with four rows in flight,
@@ -288,6 +340,8 @@ int build_class(const tts_geom &g, int sub, ClassPlan &c, std::vector<uint32_t> 
         c.kind = 2; c.NTP = NTP; c.Rc = Rc; c.col_dmas = dmas; c.col_nc = nc; c.hoff1 = hoff1; c.hcoef1 = hcoef1;
         c.col_dmas1 = dmas;
         if (nc == 2) { t.strips = c.ow; c.col_dmas1 = lds_dmas(c, t, 1, lo.data(), 1, 2 * NTP); }
+        c.d4tab[1] = build_d4_tables(c, NTP, 1, lo, slots, tab);
+        if (nc == 2) c.d4tab[2] = build_d4_tables(c, NTP, 2, lo, slots, tab);
         // Segment lengths on offer: the luma plane cut into 1..32 EQUAL parts (outputs here are small --
         // a ragged last segment would be most of the tail), the same list for both classes, ascending.
         std::vector<int> opts;
@@ -600,9 +654,19 @@ void choose_segs(const tts_plan *p, const int *cis, int ncls, int n, int N, stri
     out_idx[0] = out_idx[1] = best;
 }
 
+// The v_dot4 form (see column_lds_kernel) pays above 8 tap pairs -- 300 frames, A/B in one process: the 1080p
+// thumbnail chain 47.4 -> 49.9 % of the roofline, 1080x1920 -> 101x180 45.1 -> 48.6 %, the 4K chain 56.9 -> 59.5 % --
+// and costs below (a window of 5 dwords gains little from dropping v_perm and pays the xor and the second
+// column's two extra dwords: 4K -> 720p 54.5 -> 51.8 %, 2160x3840 -> 720x1280 52.7 -> 51.5 %).
+bool column_dot4(const ClassPlan &c, const Knobs &k)
+{
+    if (!(k.col_d4 == 2 || (k.col_d4 == 1 && c.NTP > 8))) return false;
+    return c.d4tab[1] && (c.col_nc != 2 || c.d4tab[2]);
+}
+
 constexpr int column_depth(int) { return 4; }    // source rows in flight per wave, every tap count (see pick_column)
 
-struct ColMode { int nc, dmas; };                  // columns per lane and LDS-DMAs per row of one launch (per class)
+struct ColMode { int nc, dmas, d4; };              // columns per lane, LDS-DMAs per row, v_dot4 form: of one launch (per class)
 
 strip_fn pick_column(const ClassPlan &c, const ColMode m)
 {
@@ -610,8 +674,10 @@ strip_fn pick_column(const ClassPlan &c, const ColMode m)
     // so four rows are kept in flight (four LDS slots): the 1080p thumbnail chain 35 -> 39-41 % of peak,
     // 4K -> 720p 46 -> 51 %, the 48-tap 4K thumbnail chain 48 -> 54 %.  Eight measured worse than four
     // (1080p chain 34 %, 4K chain 51 %).
-#define TTS_COL_PICK(NTP_, NC_) (m.dmas == 1 ? column_lds_kernel<NTP_, 2 * NTP_, 1, NC_, column_depth(NTP_)> \
-                                                  : column_lds_kernel<NTP_, 2 * NTP_, 2, NC_, column_depth(NTP_)>)
+#define TTS_COL_PICK(NTP_, NC_) (m.d4 ? (m.dmas == 1 ? column_lds_kernel<NTP_, 2 * NTP_, 1, NC_, column_depth(NTP_), true> \
+                                                            : column_lds_kernel<NTP_, 2 * NTP_, 2, NC_, column_depth(NTP_), true>) \
+                                       : (m.dmas == 1 ? column_lds_kernel<NTP_, 2 * NTP_, 1, NC_, column_depth(NTP_)> \
+                                                            : column_lds_kernel<NTP_, 2 * NTP_, 2, NC_, column_depth(NTP_)>))
     if (c.Rc != 2 * c.NTP) return nullptr;
     if (m.nc == 2)
         switch (c.NTP) {
@@ -646,7 +712,7 @@ void fill_column_class(const tts_plan *p, int ci, const ColMode m, int n, int sr
 {
     const ClassPlan &c = p->cls[ci];
     sc = StripClass{};
-    sc.hoff = c.hoff1; sc.hcoef = c.hcoef1;
+    sc.hoff = c.hoff1; sc.hcoef = m.d4 ? c.d4tab[m.nc] : c.hcoef1;
     sc.seginfo = st.seginfo; sc.emit = st.emit; sc.vcoef = st.vcoef;
     sc.maxrows = st.maxrows; sc.nseg = st.nseg; sc.seg_rows = st.seg_rows;
     sc.strips = (c.ow + m.nc - 1) / m.nc;              // nc columns per lane
@@ -673,11 +739,29 @@ size_t choose_column_segs(const tts_plan *p, const int *cis, const ColMode *cm, 
     const double slots = double(p->n_cus) * blocks_per_cu(fn, kBlock, 0);
     const double fill = p->knobs.col_fill ? 0.1 * p->knobs.col_fill : p->cls[cis[0]].NTP <= 8 ? 3.0 : 1.5;
     size_t best = 0;
+    double best_cost = 0;
     for (size_t i = 0; i < nopt; ++i) {
         double blocks = 0;
+        int rows = 0;
         for (int k = 0; k < ncls; ++k) {
             const ClassPlan &c = p->cls[cis[k]];
             blocks += double((int64_t(n) * planes_each[k] * ((c.ow + cm[cis[k]].nc - 1) / cm[cis[k]].nc) + kBlock - 1) / kBlock) * c.segs[i].nseg;
+            rows = std::max(rows, c.segs[i].maxrows);
+        }
+        if (p->knobs.col_model == 2 || (p->knobs.col_model == 1 && p->cls[cis[0]].NTP > 8)) {
+            // Many taps: the walk is bound by its own instruction stream (the 1080p thumbnail chain runs in 210 us
+            // with all memory traffic dropped, 261 us with it: tools/decompose.py), so a launch lasts about as long
+            // as the busiest CU's share of source rows, halo rows included: ceil(workgroups / CUs) x rows per
+            // segment.  At least 3 workgroups per CU (= waves per SIMD), or nothing covers the memory latency.
+            // Against the fill rule below, 300 frames: 1080x1920 -> 101x180 40.2 -> 48.9 % of the roofline.
+            const double per_cu = std::ceil(blocks / p->n_cus);
+            const double cost = per_cu * rows;
+            const bool ok = per_cu >= 3 && (p->cls[cis[0]].segs[i].nseg >= 2 || nopt == 1);
+#ifdef TTS_EXPERIMENTS
+            if (std::getenv("TTS_EXP_LOG_SEGS")) std::fprintf(stderr, "  seg option %zu: rows/seg %d nseg %d blocks %.0f per CU %.0f rows %d cost %.0f ok %d\n", i, p->cls[cis[0]].segs[i].seg_rows, p->cls[cis[0]].segs[i].nseg, blocks, per_cu, rows, cost, int(ok));
+#endif
+            if (i == 0 || (ok && (best_cost == 0 || cost <= best_cost))) { best = i; if (ok) best_cost = cost; }
+            continue;
         }
         if (i == 0 || (blocks >= fill * slots && p->cls[cis[0]].segs[i].nseg >= 2)) best = i;
     }
@@ -849,7 +933,10 @@ int launch_all(const tts_plan *p, const uint8_t *src, uint8_t *dst, int n, const
             if (!to_generic[ci]) col_cls[nc++] = ci;
         }
         const int min_segs = addr.use_table ? 2 : 1;
-        ColMode cm[2] = {{p->cls[0].col_nc, p->cls[0].col_dmas}, {p->cls[1].col_nc, p->cls[1].col_dmas}};
+        // the v_dot4 form where every class of the launch has its digit tables (for either column count)
+        int d4 = 1;
+        for (int k = 0; k < nc; ++k) d4 &= int(column_dot4(p->cls[col_cls[k]], p->knobs));
+        ColMode cm[2] = {{p->cls[0].col_nc, p->cls[0].col_dmas, d4}, {p->cls[1].col_nc, p->cls[1].col_dmas, d4}};
         auto cmerged_now = [&] { return nc == 2 && !p->knobs.no_merge && pick_column(p->cls[0], cm[0]) == pick_column(p->cls[1], cm[1]); };
         // Above 8 tap pairs two columns per lane pay only on large launches (1080p thumbnail chain: +2 % at
         // 300 frames, +8.5 % at 600, but -10 % at 120 and -5 % at 30): half as many workgroups want shorter
@@ -872,7 +959,7 @@ int launch_all(const tts_plan *p, const uint8_t *src, uint8_t *dst, int n, const
                 }
             }
             decided = two;
-            if (!two) cm[ci] = {1, c.col_dmas1};
+            if (!two) cm[ci] = {1, c.col_dmas1, d4};
         }
         const bool cmerged = cmerged_now();
         for (int k = 0; k < nc; ++k) {
