@@ -38,7 +38,7 @@ struct PadClass {
     int32_t w, h, stride;              // canvas of this plane class
     int32_t px, py, pw, ph;            // picture rectangle that is left alone
     int32_t planes, plane0;
-    int32_t chunks, rowgroups;         // 256-column chunks per row, groups of blockDim / 64 rows
+    int32_t chunks, rowgroups;         // 256-column chunks per row, groups of blockDim / 64 * kPadRowsPerWave rows
     uint32_t origin;                   // bytes from the canvas origin to the picture origin (frame offsets point at the picture)
     uint32_t nblocks;
     int32_t fill[3];
@@ -54,6 +54,7 @@ struct StripArgs {
     FrameAddr addr;
 };
 
+constexpr int kPadRowsPerWave = 8;     // canvas rows a wave of a pad workgroup fills (rowgroups of blockDim / 64 * 8 rows)
 __device__ __forceinline__ void pad_fill_blocks(const StripArgs &a, uint8_t *dst, uint32_t fb)
 {
     const int k = fb >= a.pad[0].nblocks ? 1 : 0;
@@ -63,16 +64,21 @@ __device__ __forceinline__ void pad_fill_blocks(const StripArgs &a, uint8_t *dst
     const uint32_t rest = fb / uint32_t(c.chunks);
     const int rg = int(rest % uint32_t(c.rowgroups)), fp = int(rest / uint32_t(c.rowgroups));
     const int x = chunk * 256 + int(threadIdx.x & 63) * 4;
-    const int y = rg * int(blockDim.x >> 6) + int(threadIdx.x >> 6);
-    if (x >= c.w || y >= c.h) return;
+    if (x >= c.w) return;
     const int plane = c.plane0 + fp % c.planes, frame = fp / c.planes;
     const size_t doff = (a.addr.use_table ? size_t(a.addr.dst_tab[plane][frame])
                                           : size_t(frame) * a.addr.dst_pitch + a.addr.dst_plane[plane]) - c.origin;
-    uint8_t *row = dst + doff + size_t(y) * size_t(c.stride);
     const uint8_t f = uint8_t(c.fill[plane]);
-    const bool in_rows = y >= c.py && y < c.py + c.ph;
-    for (int i = x; i < min(x + 4, c.w); ++i)
-        if (!(in_rows && i >= c.px && i < c.px + c.pw)) row[i] = f;
+    const int waves = int(blockDim.x >> 6);
+    // kPadRowsPerWave rows per wave: a 101x180 picture in a 320x180 canvas was 136 workgroups of 1 KiB per frame
+    for (int it = 0; it < kPadRowsPerWave; ++it) {
+        const int y = (rg * kPadRowsPerWave + it) * waves + int(threadIdx.x >> 6);
+        if (y >= c.h) return;
+        uint8_t *row = dst + doff + size_t(y) * size_t(c.stride);
+        const bool in_rows = y >= c.py && y < c.py + c.ph;
+        for (int i = x; i < min(x + 4, c.w); ++i)
+            if (!(in_rows && i >= c.px && i < c.px + c.pw)) row[i] = f;
+    }
 }
 
 // the range step on one finished byte / on four packed bytes ((p * mul + add) >> shift lies within int16:
@@ -773,8 +779,9 @@ __device__ __forceinline__ void lds_read_dwords(uint32_t (&w)[NDW], uint32_t p)
 // byte phase in LDS is folded into the digit tables (one table per phase, picked once per walk), which removes
 // every v_perm: per window dword 1 xor + 2 dot4 for 4 taps where the v_dot2 form spends 2 v_perm + 2 v_dot2.
 // With NC = 2 both columns dot the SAME span of NDW + 2 dwords (adjacent windows overlap by three quarters at 6x):
-// one LDS read and one xor pass for both; column 1's digits sit `delta` bytes further on.  Its dword 0 holds
-// taps only where windows were folded at a row's edge: that pair of dot4 runs under a wave-uniform branch.
+// one LDS read and one xor pass for both; column 1's digits sit `delta` bytes further on.  (Its dword 0 holds
+// taps only where swscale folded windows at a row's edge -- but two waves in five hold such a strip, a branch
+// around that pair of v_dot4 cost 50 % when taken, and if-converted it cost six instructions: it just runs.)
 template <int NTP, int R, int NDMA, int NC, int D = 1, bool D4 = false>
 __global__ __launch_bounds__(kBlock, (D4 && NC == 2 && NTP == 12 && NDMA == 1) ? 6 : 1) void column_lds_kernel(const uint8_t *__restrict__ src, uint8_t *__restrict__ dst,
                                                             const uint32_t *__restrict__ tab, const StripArgs a)
@@ -855,7 +862,6 @@ __global__ __launch_bounds__(kBlock, (D4 && NC == 2 && NTP == 12 && NDMA == 1) ?
     //   NC = 1: [bias][th x NDW][tl x NDW]   NC = 2: [bias0][bias1][th0 x NDW][tl0 x NDW][th1 x NSP][tl1 x NSP]
     [[maybe_unused]] uint32_t th[NC][D4 ? NSP : 1], tl[NC][D4 ? NSP : 1];
     [[maybe_unused]] int bias[NC];
-    [[maybe_unused]] bool need0 = false;
     if constexpr (D4) {
         constexpr int ESZ = NC == 2 ? 2 + 2 * NDW + 2 * NSP : 1 + 2 * NDW;
         const uint32_t o0 = (off[0] + row0_off + lbase + uint32_t(reinterpret_cast<uintptr_t>((lds_void_t *)&lds[wave][0][0]))) & 3u;
@@ -867,7 +873,6 @@ __global__ __launch_bounds__(kBlock, (D4 && NC == 2 && NTP == 12 && NDMA == 1) ?
         if constexpr (NC == 2) {
 #pragma unroll
             for (int i = 0; i < NSP; ++i) { th[1][i] = e[2 + 2 * NDW + i]; tl[1][i] = e[2 + 2 * NDW + NSP + i]; }
-            need0 = __builtin_amdgcn_ballot_w64((th[1][0] | tl[1][0]) != 0u) != 0ull;
         }
     }
 
@@ -931,13 +936,12 @@ __global__ __launch_bounds__(kBlock, (D4 && NC == 2 && NTP == 12 && NDMA == 1) ?
             for (int j = 0; j < NC; ++j) {
                 int acc = 0;
                 if constexpr (D4) {
-                    int hi = 0, lo = bias[j];
-                    if (j == 1 && need0) {                      // wave-uniform: windows folded at a row's edge
-                        hi = __builtin_amdgcn_sdot4(int(ws[0]), int(th[1][0]), hi, false);
-                        lo = __builtin_amdgcn_sdot4(int(ws[0]), int(tl[1][0]), lo, false);
-                    }
+                    // (the first v_dot4 of a chain in its VOP3P form -- clamp = true, as in dot2(): the sums stay far
+                    // from the int32 range -- whose accumulator input is a free operand: no v_mov of 0 / bias first)
+                    int hi = __builtin_amdgcn_sdot4(int(ws[0]), int(th[j][0]), 0, true);
+                    int lo = __builtin_amdgcn_sdot4(int(ws[0]), int(tl[j][0]), bias[j], true);
 #pragma unroll
-                    for (int i = j; i < (j ? NSP : NDW); ++i) {
+                    for (int i = 1; i < (j ? NSP : NDW); ++i) {
                         hi = __builtin_amdgcn_sdot4(int(ws[i]), int(th[j][i]), hi, false);
                         lo = __builtin_amdgcn_sdot4(int(ws[i]), int(tl[j][i]), lo, false);
                     }

@@ -818,7 +818,7 @@ int launch_all(const tts_plan *p, const uint8_t *src, uint8_t *dst, int n, const
         pc.w = c.canvas_w; pc.h = c.canvas_h; pc.stride = dst_stride[ci];
         pc.px = c.pad_x; pc.py = c.pad_y; pc.pw = c.ow; pc.ph = c.oh;
         pc.planes = nplanes(ci); pc.plane0 = plane0(ci);
-        pc.chunks = (c.canvas_w + 255) / 256; pc.rowgroups = (c.canvas_h + threads / 64 - 1) / (threads / 64);
+        pc.chunks = (c.canvas_w + 255) / 256; pc.rowgroups = (c.canvas_h + threads / 64 * kPadRowsPerWave - 1) / (threads / 64 * kPadRowsPerWave);
         pc.origin = uint32_t(c.pad_y) * uint32_t(dst_stride[ci]) + uint32_t(c.pad_x);
         const int fill[3] = {p->g.fill_y, p->g.fill_u, p->g.fill_v};
         for (int k = 0; k < 3; ++k) {
