@@ -158,6 +158,22 @@ def test_rgb24_input_matches_oracle(tts, oracle, vf, iw, ih):
             vf, iw, ih, pat, bad.size, bad[0], got.ravel()[bad[0]], want.ravel()[bad[0]])
 
 
+@pytest.mark.parametrize("vf,iw,ih", [RGBIN_CASES[0], RGBIN_CASES[7], RGBIN_CASES[8], RGBIN_CASES[11]])
+def test_rgb24_input_tiled_and_generic_kernels_agree(tts, oracle, monkeypatch, vf, iw, ih):
+    """rgbin_tile_kernel (a workgroup converts its tile's source samples once, into LDS) is what runs by default;
+    the one-lane-per-sample kernel stays behind it for tiles that do not fit: same bytes from both."""
+    import torch
+    src = rgb_frames("random", iw, ih, 4)
+    tiled = tts.Plan.from_vf(vf, iw, ih, in_fmt="rgb24")
+    assert tiled.kernel_name(0).startswith("rgbin_tile"), tiled.kernel_name(0)
+    monkeypatch.setenv("TTS_FORCE_GENERIC", "1")
+    generic = tts.Plan.from_vf(vf, iw, ih, in_fmt="rgb24")
+    assert generic.kernel_name(0).startswith("rgbin_generic"), generic.kernel_name(0)
+    d = torch.from_numpy(src).cuda()
+    a, b = tiled.run_batch(d).cpu().numpy(), generic.run_batch(d).cpu().numpy()
+    assert np.array_equal(a, b) and np.array_equal(a, oracle.run_chain(tiled.geom, src))
+
+
 def test_rgb24_input_host_path_and_rejections(tts, oracle):
     plan = tts.Plan.from_vf("scale=96:54", 64, 36, in_fmt="rgb24")
     src = rgb_frames("zone", 64, 36, 5)

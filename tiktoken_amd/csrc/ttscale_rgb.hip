@@ -626,6 +626,7 @@ struct RgbInArgs {
     int32_t fill[3];
     int32_t frame0;
     int32_t coef[9];                   // ry gy by, ru gu bu, rv gv bv
+    const uint8_t *src_lo, *src_hi;    // the batch's first source byte and one past its last (rgbin_tile_kernel's dword loads stay inside)
     FrameAddr addr;
 };
 
@@ -669,6 +670,148 @@ __global__ __launch_bounds__(kBlock) void rgbin_generic_kernel(const RgbInArgs a
         out = val < 0 ? 0 : val > 255 ? 255 : val;
     }
     dp[size_t(y) * size_t(a.dst_stride[ci]) + x] = uint8_t(out);
+}
+
+// ---- packed rgb24 in, tiled: a workgroup owns 64 x TH output samples of one plane ---------------------------
+// The kernel above converts every source pixel once per TAP PAIR that touches it (taps_h x taps_v times per
+// output sample).  Here a workgroup converts the source samples its tile needs ONCE into LDS (rgb24ToY_c /
+// rgb24ToUV_half_c, 14-bit values), runs hScale16To15_c over them into a second LDS array (one 15-bit row per
+// source row of the tile), and the vertical pass reads that: the same arithmetic in the same order per
+// sample, so the same bytes.  The host sizes the tile (rows `th`) so that both arrays fit `lds_bytes`, from
+// the worst tile of the plane class (`sx_max` source samples a row, `sy_max` source rows).
+struct RgbInTileArgs {
+    RgbInArgs g;
+    int32_t th[2];                     // output rows per tile, luma / chroma
+    int32_t sx_max[2], sy_max[2];      // LDS array extents
+    int32_t tiles_y[2];                // tiles down the canvas
+    int32_t raw_w[2];                  // bytes of a row of the raw-bytes LDS array (a multiple of 4)
+};
+
+// MAXT: an upper bound of every tap count known at compile time (loops unrolled under a predicate), 0 = any count
+template <int MAXT>
+__global__ __launch_bounds__(kBlock) void rgbin_tile_kernel(const RgbInTileArgs t)
+{
+    extern __shared__ __attribute__((aligned(16))) int16_t rgbin_lds[];
+    const RgbInArgs &a = t.g;
+    const int plane = int(blockIdx.z) % 3, frame = a.frame0 + int(blockIdx.z) / 3;
+    const int ci = plane ? 1 : 0;
+    if (int(blockIdx.y) >= t.tiles_y[ci]) return;                  // (the grid is sized for the luma class; whole workgroups leave)
+    const int x0 = int(blockIdx.x) * 64, y0 = int(blockIdx.y) * t.th[ci];
+    if (x0 >= a.canvas_w[ci]) return;
+    const int x1 = min(x0 + 64, a.canvas_w[ci]), y1 = min(y0 + t.th[ci], a.canvas_h[ci]);
+    const uint8_t *sp = a.src + size_t(frame) * a.addr.src_pitch + a.addr.src_plane[0];
+    uint8_t *dp = a.dst + size_t(frame) * a.addr.dst_pitch + a.addr.dst_plane[plane];
+    // the part of the tile that lies inside the picture (workgroup-uniform)
+    const int ix0 = max(x0, a.px[ci]), ix1 = min(x1, a.px[ci] + a.pw[ci]);
+    const int iy0 = max(y0, a.py[ci]), iy1 = min(y1, a.py[ci] + a.ph[ci]);
+    const bool any = ix0 < ix1 && iy0 < iy1;
+    const int32_t *hpos = ci ? a.chpos : a.lhpos, *vpos = ci ? a.cvpos : a.lvpos;
+    const int ht = ci ? a.cht : a.lht, vt = ci ? a.cvt : a.lvt;
+    const int16_t *htaps = ci ? a.chtaps : a.lhtaps, *vtaps = ci ? a.cvtaps : a.lvtaps;
+    const int sxm = t.sx_max[ci], sym = t.sy_max[ci], raww = t.raw_w[ci];
+    int16_t *s14 = rgbin_lds;                                      // [sy_max][sx_max]
+    int16_t *hres = s14 + sym * sxm;                               // [sy_max][64]
+    int16_t *vrow = hres + sym * 64;                               // [th][1 + vt]: first source row (tile-relative) and taps of each output row
+    uint8_t *raw = reinterpret_cast<uint8_t *>(rgbin_lds) + ((size_t(sym) * (sxm + 64) + size_t(t.th[ci]) * (vt + 1)) * 2 + 3 & ~size_t(3));   // [sy_max][raw_w] source bytes
+    const int wave = __builtin_amdgcn_readfirstlane(int(threadIdx.x >> 6)), lane = int(threadIdx.x & 63);
+    const int waves = int(blockDim.x >> 6);
+    const int nb = ci ? 6 : 3;                                      // bytes per source sample: a pixel, a pixel pair
+    int sxlo = 0, nsx = 0, sylo = 0, nsy = 0;
+    if (any) {
+        const int vxa = a.ox[ci] + ix0 - a.px[ci], vxb = a.ox[ci] + ix1 - 1 - a.px[ci];
+        const int vya = a.oy[ci] + iy0 - a.py[ci], vyb = a.oy[ci] + iy1 - 1 - a.py[ci];
+        sxlo = hpos[vxa]; nsx = hpos[vxb] + ht - sxlo;            // (positions do not decrease along an axis: host-checked)
+        sylo = vpos[vya]; nsy = vpos[vyb] + vt - sylo;
+        // the vertical taps of the tile's rows, for phase C
+        for (int yr = wave; yr < iy1 - iy0; yr += waves) {
+            const int vy = a.oy[ci] + iy0 + yr - a.py[ci];
+            for (int j = lane; j <= vt; j += 64) vrow[(iy0 - y0 + yr) * (vt + 1) + j] = j ? vtaps[size_t(vy) * vt + j - 1] : int16_t(vpos[vy] - sylo);
+        }
+        // A1: the tile's source bytes as aligned dwords, coalesced (byte loads of 3-byte pixels kept the texture
+        // addresser 60 % busy by themselves); a dword that would reach past the batch is assembled from bytes
+        for (int r = wave; r < nsy; r += waves) {
+            const uint8_t *g0 = sp + size_t(sylo + r) * size_t(a.src_stride) + nb * sxlo;
+            const int mis = int(reinterpret_cast<uintptr_t>(g0) & 3u);
+            const int ndw = (mis + nb * nsx + 3) >> 2;
+            uint32_t *lrow = reinterpret_cast<uint32_t *>(raw + r * raww);
+            for (int i = lane; i < ndw; i += 64) {
+                const uint8_t *q = g0 - mis + 4 * i;
+                uint32_t w;
+                if (q >= a.src_lo && q + 4 <= a.src_hi) w = *reinterpret_cast<const uint32_t *>(q);
+                else {
+                    w = 0;
+                    for (int k = 0; k < 4; ++k) if (q + k >= a.src_lo && q + k < a.src_hi) w |= uint32_t(q[k]) << (8 * k);
+                }
+                lrow[i] = w;
+            }
+        }
+    }
+    __syncthreads();
+    if (any) {
+        // A2: rgb24ToY_c / rgb24ToUV_half_c once per source sample of the tile
+        const int cr = a.coef[3 * plane], cg = a.coef[3 * plane + 1], cb = a.coef[3 * plane + 2];
+        for (int r = wave; r < nsy; r += waves) {
+            const uint8_t *g0 = sp + size_t(sylo + r) * size_t(a.src_stride) + nb * sxlo;
+            const uint8_t *q0 = raw + r * raww + int(reinterpret_cast<uintptr_t>(g0) & 3u);
+            for (int c = lane; c < nsx; c += 64) {
+                const uint8_t *q = q0 + nb * c;
+                const int v = ci == 0 ? (cr * q[0] + cg * q[1] + cb * q[2] + (32 << 14) + (1 << 8)) >> 9
+                                      : (cr * (q[0] + q[3]) + cg * (q[1] + q[4]) + cb * (q[2] + q[5]) + (256 << 15) + (1 << 9)) >> 10;
+                s14[r * sxm + c] = int16_t(v);
+            }
+        }
+    }
+    __syncthreads();
+    const int x = x0 + lane;
+    const bool inx = x >= ix0 && x < ix1;
+    if (any && inx) {
+        // B: hScale16To15_c for every (source row, output column) of the tile; a lane keeps its column and its taps
+        const int vx = a.ox[ci] + x - a.px[ci];
+        const int16_t *hc = htaps + size_t(vx) * ht;
+        const int hp = hpos[vx] - sxlo;
+        if constexpr (MAXT > 0) {
+            int tap[MAXT];
+#pragma unroll
+            for (int k = 0; k < MAXT; ++k) tap[k] = k < ht ? int(hc[k]) : 0;
+            for (int r = wave; r < nsy; r += waves) {
+                const int16_t *srow = s14 + r * sxm + hp;
+                int acc = 0;
+#pragma unroll
+                for (int k = 0; k < MAXT; ++k) if (k < ht) acc += int(srow[k]) * tap[k];      // (workgroup-uniform predicate)
+                acc >>= 13;
+                hres[r * 64 + lane] = int16_t(acc < 32767 ? acc : 32767);
+            }
+        } else {
+            for (int r = wave; r < nsy; r += waves) {
+                const int16_t *srow = s14 + r * sxm + hp;
+                int acc = 0;
+                for (int k = 0; k < ht; ++k) acc += int(srow[k]) * int(hc[k]);
+                acc >>= 13;
+                hres[r * 64 + lane] = int16_t(acc < 32767 ? acc : 32767);
+            }
+        }
+    }
+    __syncthreads();
+    // C: vertical pass, clip, store: a wave takes an output row; border samples take the pad colour
+    if (x < x1) {
+        for (int y = y0 + wave; y < y1; y += waves) {
+            int out = a.fill[plane];
+            if (inx && y >= iy0 && y < iy1) {
+                const int16_t *vc = vrow + (y - y0) * (vt + 1) + 1;
+                const int16_t *hcol = hres + int(vc[-1]) * 64 + lane;
+                int val = 64 << 12;
+                if constexpr (MAXT > 0) {
+#pragma unroll
+                    for (int j = 0; j < MAXT; ++j) if (j < vt) val += int(hcol[j * 64]) * int(vc[j]);
+                } else {
+                    for (int j = 0; j < vt; ++j) val += int(hcol[j * 64]) * int(vc[j]);
+                }
+                val >>= 19;
+                out = val < 0 ? 0 : val > 255 ? 255 : val;
+            }
+            dp[size_t(y) * size_t(a.dst_stride[ci]) + x] = uint8_t(out);
+        }
+    }
 }
 
 template <class T>
@@ -996,8 +1139,48 @@ struct RgbInPlan {
     AxisFilter lh, lv, ch, cv;
     int32_t *d_pos[4] = {nullptr, nullptr, nullptr, nullptr};
     int16_t *d_taps[4] = {nullptr, nullptr, nullptr, nullptr};
+    // rgbin_tile_kernel: output rows per tile and LDS extents per plane class; tiled == false: the generic kernel
+    bool tiled = false;
+    int th[2] = {0, 0}, sx_max[2] = {0, 0}, sy_max[2] = {0, 0}, tiles_y[2] = {0, 0};
+    size_t lds_bytes = 0;
     char name[96] = "";
 };
+
+// Picture rectangle of plane class k inside its canvas, and its origin in the scaled plane (as rgbin_launch fills them in)
+struct RgbInRect { int canvas_w, canvas_h, px, py, pw, ph, ox, oy; };
+static RgbInRect rgbin_rect(const tts_geom &g, int k)
+{
+    const int content_w = g.do_pad ? (g.crop_w & ~1) : g.crop_w;     // vf_pad: an odd picture loses its last column to the fill
+    return {(g.out_w + k) >> k, (g.out_h + k) >> k, g.do_pad ? g.pad_x >> k : 0, g.do_pad ? g.pad_y >> k : 0,
+            (content_w + k) >> k, (g.crop_h + k) >> k, g.crop_x >> k, g.crop_y >> k};
+}
+
+// Tile height of rgbin_tile_kernel for one plane class: the tallest of the heights on offer whose two LDS arrays
+// (converted source samples, horizontal results) fit `budget` bytes for the plane's worst tile.  false: none does.
+static int rgbin_raw_w(int sx_max, int nb) { return (nb * sx_max + 6) & ~3; }          // (up to 3 bytes of misalignment in front, rounded up to dwords)
+static size_t rgbin_tile_lds(int sy, int sx, int th, int vt, int nb)
+{
+    return (((size_t(sy) * size_t(sx + 64) + size_t(th) * size_t(vt + 1)) * 2 + 3) & ~size_t(3)) + size_t(sy) * size_t(rgbin_raw_w(sx, nb));
+}
+static bool rgbin_tile_shape(const RgbInRect &r, const AxisFilter &h, const AxisFilter &v, int nb, size_t budget, int &th, int &sx_max, int &sy_max)
+{
+    auto monotone = [](const std::vector<int32_t> &p) { for (size_t i = 1; i < p.size(); ++i) if (p[i] < p[i - 1]) return false; return true; };
+    if (!monotone(h.pos) || !monotone(v.pos) || r.pw < 1 || r.ph < 1) return false;
+    sx_max = 0;
+    for (int x0 = 0; x0 < r.canvas_w; x0 += 64) {
+        const int a = std::max(x0, r.px), b = std::min(std::min(x0 + 64, r.canvas_w), r.px + r.pw);
+        if (a < b) sx_max = std::max(sx_max, h.pos[r.ox + b - 1 - r.px] + h.size - h.pos[r.ox + a - r.px]);
+    }
+    for (int cand : {64, 48, 32, 24, 16, 12, 8, 6, 4, 3, 2, 1}) {
+        int sy = 0;
+        for (int y0 = 0; y0 < r.canvas_h; y0 += cand) {
+            const int a = std::max(y0, r.py), b = std::min(std::min(y0 + cand, r.canvas_h), r.py + r.ph);
+            if (a < b) sy = std::max(sy, v.pos[r.oy + b - 1 - r.py] + v.size - v.pos[r.oy + a - r.py]);
+        }
+        if (rgbin_tile_lds(sy, sx_max, cand, v.size, nb) <= budget) { th = cand; sy_max = sy; return true; }
+    }
+    return false;
+}
 
 int rgbin_plan_create(const tts_geom &g, RgbInPlan **out)
 {
@@ -1017,7 +1200,21 @@ int rgbin_plan_create(const tts_geom &g, RgbInPlan **out)
     const AxisFilter *f[4] = {&p->lh, &p->lv, &p->ch, &p->cv};
     for (int i = 0; i < 4 && !rc; ++i)
         if (!upload_vec(p->d_pos[i], f[i]->pos) || !upload_vec(p->d_taps[i], f[i]->taps)) { set_last_error("table upload failed (hipMalloc / hipMemcpy)"); rc = TTS_ERR_INITIALIZATION_FAILED; }
-    std::snprintf(p->name, sizeof p->name, "rgbin_generic<%d,%d,%d,%d>", p->lh.size, p->lv.size, p->ch.size, p->cv.size);
+    if (!rc && !std::getenv("TTS_FORCE_GENERIC")) {
+        // 32 KiB a workgroup if some tile height fits that (five workgroups on a CU's 160 KiB), else 64 KiB
+        const RgbInRect r0 = rgbin_rect(g, 0), r1 = rgbin_rect(g, 1);
+        for (size_t budget : {size_t(32768), size_t(65536)})        // (64 KiB: the most a workgroup gets without opting in)
+            if (!p->tiled)
+                p->tiled = rgbin_tile_shape(r0, p->lh, p->lv, 3, budget, p->th[0], p->sx_max[0], p->sy_max[0]) &&
+                           rgbin_tile_shape(r1, p->ch, p->cv, 6, budget, p->th[1], p->sx_max[1], p->sy_max[1]);
+        if (p->tiled) {
+            p->tiles_y[0] = (r0.canvas_h + p->th[0] - 1) / p->th[0]; p->tiles_y[1] = (r1.canvas_h + p->th[1] - 1) / p->th[1];
+            const AxisFilter *vf[2] = {&p->lv, &p->cv};
+            for (int k = 0; k < 2; ++k) p->lds_bytes = std::max(p->lds_bytes, rgbin_tile_lds(p->sy_max[k], p->sx_max[k], p->th[k], vf[k]->size, k ? 6 : 3));
+        }
+    }
+    if (p->tiled) std::snprintf(p->name, sizeof p->name, "rgbin_tile<%d,%d>", p->th[0], p->th[1]);
+    else std::snprintf(p->name, sizeof p->name, "rgbin_generic<%d,%d,%d,%d>", p->lh.size, p->lv.size, p->ch.size, p->cv.size);
     if (rc) { rgbin_plan_destroy(p); return rc; }
     *out = p;
     return TTS_OK;
@@ -1042,15 +1239,15 @@ int rgbin_launch(const RgbInPlan *p, const uint8_t *src, uint8_t *dst, int n, in
     a.lhpos = p->d_pos[0]; a.lvpos = p->d_pos[1]; a.chpos = p->d_pos[2]; a.cvpos = p->d_pos[3];
     a.lhtaps = p->d_taps[0]; a.lvtaps = p->d_taps[1]; a.chtaps = p->d_taps[2]; a.cvtaps = p->d_taps[3];
     a.lht = p->lh.size; a.lvt = p->lv.size; a.cht = p->ch.size; a.cvt = p->cv.size;
-    const int content_w = g.do_pad ? (g.crop_w & ~1) : g.crop_w;     // vf_pad: an odd picture loses its last column to the fill
     for (int k = 0; k < 2; ++k) {
-        a.canvas_w[k] = (g.out_w + k) >> k; a.canvas_h[k] = (g.out_h + k) >> k;
-        a.px[k] = g.do_pad ? g.pad_x >> k : 0; a.py[k] = g.do_pad ? g.pad_y >> k : 0;
-        a.pw[k] = (content_w + k) >> k; a.ph[k] = (g.crop_h + k) >> k;
-        a.ox[k] = g.crop_x >> k; a.oy[k] = g.crop_y >> k;
+        const RgbInRect r = rgbin_rect(g, k);
+        a.canvas_w[k] = r.canvas_w; a.canvas_h[k] = r.canvas_h;
+        a.px[k] = r.px; a.py[k] = r.py; a.pw[k] = r.pw; a.ph[k] = r.ph; a.ox[k] = r.ox; a.oy[k] = r.oy;
         a.dst_stride[k] = dst_stride[k];
     }
     a.src_stride = src_stride;
+    a.src_lo = src + addr.src_plane[0];
+    a.src_hi = a.src_lo + size_t(n - 1) * addr.src_pitch + size_t(g.in_h - 1) * size_t(src_stride) + size_t(g.in_w) * 3;
     a.fill[0] = g.fill_y; a.fill[1] = g.fill_u; a.fill[2] = g.fill_v;
     // utils.c fill_rgb2yuv_table(): the default matrix's table, 15 fractional bits
     const double S = 32768.0;
@@ -1063,7 +1260,16 @@ int rgbin_launch(const RgbInPlan *p, const uint8_t *src, uint8_t *dst, int n, in
     for (int f0 = 0; f0 < n && !rc; f0 += 21845) {          // grid.z = frames x 3 planes
         const int nf = std::min(21845, n - f0);
         a.frame0 = f0;
-        rc = launch_rgb("rgbin_generic_kernel", rgbin_generic_kernel, dim3((g.out_w + 63) / 64, (g.out_h + 3) / 4, nf * 3), dim3(kBlock), 0, st, a);
+        if (p->tiled) {
+            RgbInTileArgs t{};
+            t.g = a;
+            for (int k = 0; k < 2; ++k) { t.th[k] = p->th[k]; t.sx_max[k] = p->sx_max[k]; t.sy_max[k] = p->sy_max[k]; t.tiles_y[k] = p->tiles_y[k]; }
+            for (int k = 0; k < 2; ++k) t.raw_w[k] = rgbin_raw_w(p->sx_max[k], k ? 6 : 3);
+            const bool t8 = std::max(std::max(a.lht, a.lvt), std::max(a.cht, a.cvt)) <= 8;
+            rc = launch_rgb("rgbin_tile_kernel", t8 ? rgbin_tile_kernel<8> : rgbin_tile_kernel<0>,
+                            dim3((g.out_w + 63) / 64, std::max(p->tiles_y[0], p->tiles_y[1]), nf * 3), dim3(kBlock), p->lds_bytes, st, t);
+        } else
+            rc = launch_rgb("rgbin_generic_kernel", rgbin_generic_kernel, dim3((g.out_w + 63) / 64, (g.out_h + 3) / 4, nf * 3), dim3(kBlock), 0, st, a);
     }
     return rc;
 }

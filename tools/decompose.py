@@ -9,7 +9,7 @@ import sys
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch
 import tiktoken_amd as tts
-from sweep import CASES
+from sweep import CASES, plan_for
 
 case = sys.argv[1] if len(sys.argv) > 1 else "thumbref"
 frames = int(sys.argv[2]) if len(sys.argv) > 2 else 300
@@ -18,13 +18,13 @@ VARIANTS = [("as shipped", {}), ("no source traffic", {"TTS_EXP_NOSRC": "1"}), (
             ("neither (instruction stream alone)", {"TTS_EXP_NOSRC": "1", "TTS_EXP_NODST": "1"}),
             ("source in L2 (every frame reads frame 0)", {"TTS_EXP_SRCPITCH0": "1"}),
             ("destination in L2", {"TTS_EXP_DSTPITCH0": "1"})]
-src = torch.randint(0, 256, (frames, tts.frame_bytes(iw, ih)), dtype=torch.uint8, device="cuda")
 plans = []
 for name, env in VARIANTS:
     for k in ("TTS_EXP_NOSRC", "TTS_EXP_NODST", "TTS_EXP_SRCPITCH0", "TTS_EXP_DSTPITCH0"):
         os.environ.pop(k, None)
     os.environ.update(env)
-    plans.append((name, tts.Plan.from_vf(vf, iw, ih)))
+    plans.append((name, plan_for(case)))
+src = torch.randint(0, 256, (frames, plans[0][1].in_bytes), dtype=torch.uint8, device="cuda")
 dst = torch.empty((frames, plans[0][1].out_bytes), dtype=torch.uint8, device="cuda")
 for _ in range(30):
     plans[0][1].run_batch(src, dst)

@@ -6,13 +6,13 @@ import sys
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch
 import tiktoken_amd as tts
-from sweep import CASES
+from sweep import CASES, plan_for
 
 case = sys.argv[1] if len(sys.argv) > 1 else "portrait"
 frames = int(sys.argv[2]) if len(sys.argv) > 2 else 300
 iters = int(sys.argv[3]) if len(sys.argv) > 3 else 3
 vf, iw, ih, _ = CASES[case]
-plan = tts.Plan.from_vf(vf, iw, ih)
+plan = plan_for(case)
 src = torch.randint(0, 256, (frames, plan.in_bytes), dtype=torch.uint8, device="cuda")
 dst = torch.empty((frames, plan.out_bytes), dtype=torch.uint8, device="cuda")
 for _ in range(iters):

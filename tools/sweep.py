@@ -37,8 +37,20 @@ CASES = {
     "portrait_rgba": ("scale=1080:1920:force_original_aspect_ratio=increase,crop=1080:1920,format=rgba", 1920, 1080, 984960 + 8294400),
     "720p_rgb24": ("scale=1080:1920:force_original_aspect_ratio=increase,crop=1080:1920,format=rgb24", 1280, 720, 438480 + 6220800),
     "stretch_rgb24": ("scale=w=720:h=1280,format=rgb24", 480, 854, 614880 + 2764800),
+    # packed rgb24 IN, yuv420p out (the reverse of the above): 3 bytes a pixel read once + the planes written once
+    "portrait_rgbin": ("scale=1080:1920:force_original_aspect_ratio=increase,crop=1080:1920", 1920, 1080, 608 * 1080 * 3 + 3110400),
+    "stretch_rgbin": ("scale=w=720:h=1280", 480, 854, 480 * 854 * 3 + 1382400),
     "thumbref_rgb24": ("scale=320x180:force_original_aspect_ratio=decrease,pad=320x180:-1:-1:color=black,format=rgb24", 1920, 1080, 3110400 + 172800),
 }
+
+
+IN_FMT = {"portrait_rgbin": "rgb24", "stretch_rgbin": "rgb24"}
+
+
+def plan_for(case):
+    """The plan of a sweep case (packed-RGB input where the case says so)."""
+    vf, iw, ih, _ = CASES[case]
+    return tts.Plan.from_vf(vf, iw, ih, in_fmt=IN_FMT.get(case, "yuv420p"))
 
 
 def main():
@@ -63,7 +75,7 @@ def main():
     for combo in combos:
         for k, v in zip(names, combo):
             os.environ[k] = v
-        plans[combo] = tts.Plan.from_vf(vf, iw, ih)
+        plans[combo] = plan_for(args.case)
     p0 = plans[combos[0]]
     src = torch.randint(0, 256, (args.frames, p0.in_bytes), dtype=torch.uint8, device="cuda")
     dst = torch.empty((args.frames, p0.out_bytes), dtype=torch.uint8, device="cuda")
