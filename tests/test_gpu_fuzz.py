@@ -113,3 +113,73 @@ def test_random_geometries_larger_frames(tts, oracle, seed):
                 g = dp[i][k].cpu().numpy()
                 assert np.array_equal(g[:, : w.shape[1]], w), "pointer API: %s %dx%d n=%d frame %d plane %d [%s]" % (vf, iw, ih, n, i, k, plan.kernel_name(0))
                 assert (g[:, w.shape[1]:] == 9).all(), "wrote into the stride padding: %s" % vf
+
+
+def _rgb_case(rng):
+    """A chain that ends in packed RGB: mostly enlargements (the fused strip kernel: <= 4 taps an axis), some
+    shrinks and conversions without a scale (generic / unscaled kernels), crops and pads on either side."""
+    iw, ih = 2 * int(rng.integers(8, 260)), 2 * int(rng.integers(8, 200))
+    kind = rng.choice(["up", "up", "up", "down", "none"])
+    parts = []
+    if kind != "none":
+        if rng.random() < 0.25 and iw > 60 and ih > 60:
+            cw, chh = int(rng.integers(24, iw)), int(rng.integers(24, ih))
+            parts.append("crop=%d:%d:%d:%d" % (cw, chh, int(rng.integers(0, iw - cw + 1)), int(rng.integers(0, ih - chh + 1))))
+        f = rng.uniform(1.0, 3.2) if kind == "up" else 1.0 / rng.uniform(1.0, 5.0)
+        ow, oh = max(4, int(iw * f)), max(4, int(ih * f * rng.uniform(0.8, 1.25)))
+        parts.append("scale=%d:%d%s" % (ow, oh, rng.choice(["", "", ":flags=bilinear"])))
+        if rng.random() < 0.3 and ow > 24 and oh > 24:
+            parts.append("crop=%d:%d" % (int(rng.integers(8, ow)), int(rng.integers(8, oh))))
+        if rng.random() < 0.2:
+            parts.append("pad=iw+%d:ih+%d:-1:-1:color=%s" % (int(rng.integers(0, 30)), int(rng.integers(0, 30)), rng.choice(["black", "red", "white"])))
+    parts.append("format=%s" % rng.choice(["rgb24", "rgb24", "bgr24", "rgba", "bgra"]))
+    return ",".join(parts), iw, ih, int(rng.choice([1, 2, 5, 33]))
+
+
+@pytest.mark.parametrize("seed", range(int(__import__("os").environ.get("TTS_FUZZ_RGB_SEEDS", "12"))))
+def test_random_geometries_packed_rgb_out(tts, oracle, seed):
+    import torch
+    rng = np.random.default_rng(9000 + seed)
+    ran = 0
+    for _ in range(12):
+        vf, iw, ih, n = _rgb_case(rng)
+        try:
+            plan = tts.Plan.from_vf(vf, iw, ih)
+        except tts.TtsError:
+            continue                                           # crops that leave the frame, paths swscale takes that are not restated
+        src = synth.frames(str(rng.choice(["random", "impulse", "zone"])), iw, ih, n)
+        want = oracle.run_chain(plan.geom, src)
+        got = plan.run_batch(torch.from_numpy(src).cuda()).cpu().numpy()
+        bad = np.flatnonzero(got != want)
+        assert bad.size == 0, "%s %dx%d n=%d [%s]: %d bytes differ, first at %d (got %d want %d)" % (
+            vf, iw, ih, n, plan.kernel_name(0), bad.size, bad[0], got.ravel()[bad[0]], want.ravel()[bad[0]])
+        ran += 1
+    assert ran, "no case ran"
+
+
+@pytest.mark.parametrize("seed", range(int(__import__("os").environ.get("TTS_FUZZ_RGB_SEEDS", "12"))))
+def test_random_geometries_packed_rgb_in(tts, oracle, seed):
+    import torch
+    rng = np.random.default_rng(11000 + seed)
+    ran = 0
+    for _ in range(10):
+        iw, ih = 2 * int(rng.integers(8, 200)), int(rng.integers(12, 300))
+        f = float(rng.choice([rng.uniform(1.0, 3.0), 1.0 / rng.uniform(1.0, 8.0)]))
+        ow, oh = max(4, int(iw * f)), max(4, int(ih * f * rng.uniform(0.8, 1.25)))
+        vf = "scale=%d:%d%s" % (ow, oh, rng.choice(["", ":flags=area", ""]))
+        if rng.random() < 0.3 and ow > 24 and oh > 24:
+            vf += ",crop=%d:%d" % (int(rng.integers(8, ow)), int(rng.integers(8, oh)))
+        if rng.random() < 0.25:
+            vf += ",pad=iw+%d:ih+%d:-1:-1:color=black" % (2 * int(rng.integers(0, 12)), 2 * int(rng.integers(0, 12)))
+        n = int(rng.choice([1, 3, 17]))
+        try:
+            plan = tts.Plan.from_vf(vf, iw, ih, in_fmt="rgb24")
+        except tts.TtsError:
+            continue
+        src = np.random.default_rng(seed).integers(0, 256, (n, iw * ih * 3), dtype=np.uint8)
+        want = oracle.run_chain(plan.geom, src)
+        got = plan.run_batch(torch.from_numpy(src).cuda()).cpu().numpy()
+        bad = np.flatnonzero(got != want)
+        assert bad.size == 0, "%s %dx%d n=%d [%s]: %d bytes differ, first at %d" % (vf, iw, ih, n, plan.kernel_name(0), bad.size, bad[0])
+        ran += 1
+    assert ran, "no case ran"
