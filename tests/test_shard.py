@@ -141,3 +141,26 @@ def test_reduced_corpus_checksums_match_single_clip_runs():
         for name, v in run_shard(clips, shard, vf, make_frames, batch=3).items():
             merged[name] = merged.get(name, 0) + v
     assert merged == whole
+
+
+def test_numa_pinning_reads_sysfs_and_never_fails(tmp_path):
+    """pin_to_gpu_numa: the GPU's NUMA node from a sysfs-shaped tree; anything missing means "not pinned"."""
+    import os
+    from tiktoken_amd.shard import parse_cpulist, pin_to_gpu_numa
+    assert parse_cpulist("0-3,8,10-11\n") == [0, 1, 2, 3, 8, 10, 11] and parse_cpulist("") == []
+    before = os.sched_getaffinity(0)
+    try:
+        assert pin_to_gpu_numa("0000:05:00.0", sysfs=str(tmp_path)) == []            # no such device
+        dev = tmp_path / "bus/pci/devices/0000:05:00.0"
+        dev.mkdir(parents=True)
+        (dev / "numa_node").write_text("-1\n")
+        assert pin_to_gpu_numa("0000:05:00.0", sysfs=str(tmp_path)) == []            # the platform does not say
+        (dev / "numa_node").write_text("1\n")
+        node = tmp_path / "devices/system/node/node1"
+        node.mkdir(parents=True)
+        first = min(before)
+        (node / "cpulist").write_text("%d,100000-100001\n" % first)
+        assert pin_to_gpu_numa("0000:05:00.0", sysfs=str(tmp_path)) == [first]
+        assert os.sched_getaffinity(0) == {first}
+    finally:
+        os.sched_setaffinity(0, before)

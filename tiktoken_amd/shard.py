@@ -99,6 +99,52 @@ def imbalance(clips: Sequence[Clip], shards: List[List[int]], out_size: Tuple[in
     return max(loads) / mean if mean else 1.0
 
 
+def parse_cpulist(text: str) -> List[int]:
+    """'0-3,8,10-11' -> [0, 1, 2, 3, 8, 10, 11] (the format of /sys/devices/system/node/nodeN/cpulist)."""
+    cpus: List[int] = []
+    for part in text.strip().split(","):
+        if not part:
+            continue
+        lo, _, hi = part.partition("-")
+        cpus.extend(range(int(lo), int(hi or lo) + 1))
+    return cpus
+
+
+def pin_to_gpu_numa(pci_bus_id: str, sysfs: str = "/sys") -> List[int]:
+    """Keep this rank's host threads on the NUMA node its GPU hangs off: what matters for the
+    host path (tts_run_host stages through pinned buffers that should be local to the GPU's root complex), not
+    for HBM-resident batches.  `pci_bus_id` as torch.cuda.get_device_properties(i).pci_bus_id / hipDeviceGetPCIBusId
+    print it ('0000:05:00.0').  Returns the CPUs the process was bound to, or [] when the machine does not say
+    (no sysfs entry, node -1, not permitted): never an error -- an unpinned rank is only slower."""
+    import os
+    try:
+        with open(os.path.join(sysfs, "bus/pci/devices", pci_bus_id.lower(), "numa_node")) as f:
+            node = int(f.read().strip())
+        if node < 0:
+            return []
+        with open(os.path.join(sysfs, "devices/system/node/node%d/cpulist" % node)) as f:
+            cpus = parse_cpulist(f.read())
+        allowed = sorted(set(cpus) & set(os.sched_getaffinity(0)))
+        if not allowed:
+            return []
+        os.sched_setaffinity(0, allowed)
+        return allowed
+    except (OSError, ValueError):
+        return []
+
+
+def gpu_pci_address(index: int) -> str:
+    """'dddd:bb:dd.0' of visible GPU `index` from torch's device properties ('' if this torch does not tell)."""
+    import torch
+    pr = torch.cuda.get_device_properties(index)
+    bus, dev, dom = getattr(pr, "pci_bus_id", None), getattr(pr, "pci_device_id", None), getattr(pr, "pci_domain_id", 0)
+    if isinstance(bus, str):
+        return bus
+    if bus is None or dev is None:
+        return ""
+    return "%04x:%02x:%02x.0" % (dom or 0, bus, dev)
+
+
 def run_shard(clips: Sequence[Clip], my: Sequence, vf: str, make_frames, batch: int = 64, timing: Dict = None) -> Dict[str, int]:
     """Process this rank's share on the current GPU: `my` holds clip indices (assign) or Pieces
     (assign_pieces).  Returns {clip name: checksum of the output bytes this rank produced for it} -- the sum

@@ -76,6 +76,8 @@ def main():
     if world != args.gpus:
         raise SystemExit("corpus.py: WORLD_SIZE (%d) != --gpus (%d)" % (world, args.gpus))
     torch.cuda.set_device(local % torch.cuda.device_count())
+    from tiktoken_amd.shard import gpu_pci_address, pin_to_gpu_numa
+    pinned = pin_to_gpu_numa(gpu_pci_address(torch.cuda.current_device()))      # host threads next to the GPU's root complex
     if world > 1:
         dist.init_process_group("gloo")
 
@@ -105,7 +107,7 @@ def main():
     torch.cuda.synchronize()
     wall = time.perf_counter() - t0
     mine = {"rank": rank, "pieces": len(shards[rank]), "frames": timing.get("frames", 0),
-            "scale_s": round(timing.get("scale_s", 0.0), 6), "wall_s": round(wall, 4), "sums": sums}
+            "scale_s": round(timing.get("scale_s", 0.0), 6), "wall_s": round(wall, 4), "numa_cpus": len(pinned), "sums": sums}
     ranks = [mine]
     if world > 1:
         ranks = [None] * world
