@@ -124,6 +124,8 @@ size_t tts_plan_frame_bytes(const tts_plan *p, int which);
  * TTS_MEM_HOST frames (every frame of the call, both sides; any strides): copied plane by plane
  * through the staging pool of tts_run_host, synchronously -- hip_stream is not used, and the
  * frames are finished when the call returns.
+ * Packed formats: an RGB destination frame is plane[0] / stride[0] alone (>= out_w * bpp); an rgb24 SOURCE
+ * frame (tts_parse_vf_fmt) likewise (stride[0] >= in_w * 3; device frames only).
  */
 int tts_run(const tts_plan *p, const tts_frame *src, const tts_frame *dst, int n_frames, void *hip_stream);
 

@@ -174,6 +174,33 @@ def test_rgb24_input_tiled_and_generic_kernels_agree(tts, oracle, monkeypatch, v
     assert np.array_equal(a, b) and np.array_equal(a, oracle.run_chain(tiled.geom, src))
 
 
+@pytest.mark.parametrize("vf,iw,ih", [RGBIN_CASES[0], RGBIN_CASES[8], RGBIN_CASES[11], RGBIN_CASES[2]])
+def test_rgb24_input_through_frame_pointers(tts, oracle, vf, iw, ih):
+    """tts_run with packed-RGB source frames: one source plane per frame (rows padded), three destination planes,
+    every buffer its own allocation; padding is never written."""
+    import torch
+    n, pad_s, pad_d = 5, 7, 5
+    plan = tts.Plan.from_vf(vf, iw, ih, in_fmt="rgb24")
+    ow, oh = plan.out_size
+    src = rgb_frames("random", iw, ih, n)
+    want = oracle.run_chain(plan.geom, src)
+    keep, sp, ss, dp, ds = [], [], [], [], []
+    for i in range(n):
+        t = torch.zeros((ih, iw * 3 + pad_s), dtype=torch.uint8, device="cuda")
+        t[:, : iw * 3] = torch.from_numpy(src[i].reshape(ih, iw * 3)).cuda()
+        outs = [torch.full(((oh + 1) // 2 if k else oh, ((ow + 1) // 2 if k else ow) + pad_d), 9, dtype=torch.uint8, device="cuda") for k in (0, 1, 1)]
+        keep += [t] + outs
+        sp.append([t.data_ptr(), 0, 0]); ss.append([t.shape[1], 0, 0])
+        dp.append(outs); ds.append([o.shape[1] for o in outs])
+    plan.run_frames(sp, [[o.data_ptr() for o in f] for f in dp], ss, ds)
+    torch.cuda.synchronize()
+    for i in range(n):
+        for k, w in enumerate(synth.split(want[i], ow, oh)):
+            g = dp[i][k].cpu().numpy()
+            assert np.array_equal(g[:, : w.shape[1]], w), (vf, i, k)
+            assert (g[:, w.shape[1]:] == 9).all(), "wrote into the stride padding"
+
+
 def test_rgb24_input_host_path_and_rejections(tts, oracle):
     plan = tts.Plan.from_vf("scale=96:54", 64, 36, in_fmt="rgb24")
     src = rgb_frames("zone", 64, 36, 5)

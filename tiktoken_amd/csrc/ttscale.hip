@@ -244,7 +244,7 @@ int run_batch_impl(const tts_plan *p, const void *src, size_t src_pitch, const i
         if (const int rc = check_device(p)) return rc;
         FrameAddr addr{};
         addr.src_pitch = uint32_t(src_pitch); addr.dst_pitch = uint32_t(dst_pitch);
-        addr.src_plane[0] = uint32_t(g.pre_y) * uint32_t(sstride[0]) + uint32_t(g.pre_x) * 3u;
+        addr.src_plane[0] = 0;                         // (the pre-crop origin is rgbin_launch's business: it knows the stride)
         addr.dst_plane[0] = 0;
         addr.dst_plane[1] = uint32_t(dstride[0]) * uint32_t(g.out_h);
         addr.dst_plane[2] = addr.dst_plane[1] + uint32_t(dstride[1]) * uint32_t(ceil_shift(g.out_h, 1));
@@ -313,6 +313,55 @@ int run_batch_impl(const tts_plan *p, const void *src, size_t src_pitch, const i
     return TTS_OK;
 }
 
+// Packed rgb24 frames through per-frame pointers (tts_run): one source plane, rows stride[0] bytes apart, three
+// destination planes.  Frames are grouped like the planar path's: up to kMaxTableFrames whose planes lie within
+// kMaxSpan of a common base ride in one launch as 32-bit offsets.
+int run_rgbin_frames(const tts_plan *p, const tts_frame *src, const tts_frame *dst, int n_frames, void *hip_stream)
+{
+    const tts_geom &g = p->g;
+    for (int i = 0; i < n_frames; ++i) {
+        if (src[i].mem != TTS_MEM_DEVICE || dst[i].mem != TTS_MEM_DEVICE) { g_last_error = "rgb24 in: device frames only (host buffers: tts_run_host)"; return TTS_ERR_UNSUPPORTED; }
+        if (src[i].width != g.in_w || src[i].height != g.in_h || dst[i].width != g.out_w || dst[i].height != g.out_h) return TTS_ERR_INVALID_INPUT;
+        if (!src[i].plane[0] || src[i].stride[0] < g.in_w * 3) return TTS_ERR_INVALID_INPUT;
+        for (int k = 0; k < 3; ++k)
+            if (!dst[i].plane[k] || dst[i].stride[k] < ceil_shift(g.out_w, k ? 1 : 0)) return TTS_ERR_INVALID_INPUT;
+        if (dst[i].stride[1] != dst[i].stride[2]) return TTS_ERR_UNSUPPORTED;
+    }
+    if (const int drc = check_device(p)) return drc;
+    int f0 = 0;
+    while (f0 < n_frames) {
+        uintptr_t smin = UINTPTR_MAX, dmin = UINTPTR_MAX, smax = 0, dmax = 0;
+        int n = 0;
+        while (f0 + n < n_frames && n < kMaxTableFrames) {
+            const tts_frame &sf = src[f0 + n], &df = dst[f0 + n];
+            if (n && (sf.stride[0] != src[f0].stride[0] || df.stride[0] != dst[f0].stride[0] || df.stride[1] != dst[f0].stride[1])) break;
+            uintptr_t a = std::min(smin, uintptr_t(sf.plane[0])), b = std::max(smax, uintptr_t(sf.plane[0]) + size_t(g.in_h - 1) * size_t(sf.stride[0]) + size_t(g.in_w) * 3);
+            uintptr_t c2 = dmin, e = dmax;
+            for (int k = 0; k < 3; ++k) {
+                const int ci = k ? 1 : 0;
+                c2 = std::min(c2, uintptr_t(df.plane[k]));
+                e = std::max(e, uintptr_t(df.plane[k]) + size_t(df.stride[k]) * (ceil_shift(g.out_h, ci) - 1) + ceil_shift(g.out_w, ci));
+            }
+            if (b - a > kMaxSpan || e - c2 > kMaxSpan) break;
+            smin = a; smax = b; dmin = c2; dmax = e;
+            ++n;
+        }
+        if (n == 0) { g_last_error = "rgb24 in: the planes of a frame must lie within 4 GiB of each other"; return TTS_ERR_UNSUPPORTED; }
+        FrameAddr addr{};
+        addr.use_table = 1;
+        for (int i = 0; i < n; ++i) {
+            addr.src_tab[0][i] = uint32_t(uintptr_t(src[f0 + i].plane[0]) - smin);
+            for (int k = 0; k < 3; ++k) addr.dst_tab[k][i] = uint32_t(uintptr_t(dst[f0 + i].plane[k]) - dmin);
+        }
+        const int dstride[2] = {dst[f0].stride[0], dst[f0].stride[1]};
+        const int rc = tts::rgbin_launch(p->rgbin, reinterpret_cast<const uint8_t *>(smin), reinterpret_cast<uint8_t *>(dmin), n,
+                                         src[f0].stride[0], dstride, addr, static_cast<hipStream_t>(hip_stream));
+        if (rc) return rc;
+        f0 += n;
+    }
+    return TTS_OK;
+}
+
 }  // namespace
 
 extern "C" {
@@ -341,7 +390,7 @@ int tts_run(const tts_plan *p, const tts_frame *src, const tts_frame *dst, int n
     if (n_frames == 0) return TTS_OK;
     if (!src || !dst) return TTS_ERR_INVALID_INPUT;
     const tts_geom &g = p->g;
-    if (p->rgbin) { g_last_error = "rgb24 in: use the batch entry points (packed frames)"; return TTS_ERR_UNSUPPORTED; }
+    if (p->rgbin) return run_rgbin_frames(p, src, dst, n_frames, hip_stream);
     const int bpp = g.out_fmt == TTS_FMT_YUV420P ? 0 : g.out_fmt >= TTS_FMT_RGBA ? 4 : 3;
     const int ndp = bpp ? 1 : 3;                       // destination planes: packed RGB frames have one
     // Host frames (TTS_MEM_HOST, every frame of the call, both sides): staged through the per-device pool

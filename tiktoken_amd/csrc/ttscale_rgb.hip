@@ -626,9 +626,22 @@ struct RgbInArgs {
     int32_t fill[3];
     int32_t frame0;
     int32_t coef[9];                   // ry gy by, ru gu bu, rv gv bv
-    const uint8_t *src_lo, *src_hi;    // the batch's first source byte and one past its last (rgbin_tile_kernel's dword loads stay inside)
+    uint32_t src_origin, src_extent;   // bytes from a frame's first byte to the pre-cropped origin / to one past its last byte
     FrameAddr addr;
 };
+
+// Where frame `frame` lies: its first source byte (dword loads must stay inside [fb, fb + src_extent)) and plane
+// `plane` of its output -- at a fixed pitch from the bases, or through the launch's offset tables (tts_run).
+__device__ __forceinline__ void rgbin_frame(const RgbInArgs &a, int frame, int plane, const uint8_t *&fb, uint8_t *&dp)
+{
+    if (a.addr.use_table) {
+        fb = a.src + a.addr.src_tab[0][frame];                  // (at most kMaxTableFrames a launch: frame0 is 0)
+        dp = a.dst + a.addr.dst_tab[plane][frame];
+    } else {
+        fb = a.src + size_t(frame) * a.addr.src_pitch + a.addr.src_plane[0];
+        dp = a.dst + size_t(frame) * a.addr.dst_pitch + a.addr.dst_plane[plane];
+    }
+}
 
 __global__ __launch_bounds__(kBlock) void rgbin_generic_kernel(const RgbInArgs a)
 {
@@ -637,8 +650,10 @@ __global__ __launch_bounds__(kBlock) void rgbin_generic_kernel(const RgbInArgs a
     const int x = int(blockIdx.x) * 64 + int(threadIdx.x & 63);
     const int y = int(blockIdx.y) * 4 + int(threadIdx.x >> 6);
     if (x >= a.canvas_w[ci] || y >= a.canvas_h[ci]) return;
-    const uint8_t *sp = a.src + size_t(frame) * a.addr.src_pitch + a.addr.src_plane[0];
-    uint8_t *dp = a.dst + size_t(frame) * a.addr.dst_pitch + a.addr.dst_plane[plane];
+    const uint8_t *fb;
+    uint8_t *dp;
+    rgbin_frame(a, frame, plane, fb, dp);
+    const uint8_t *sp = fb + a.src_origin;
     int out = a.fill[plane];
     if (y >= a.py[ci] && y < a.py[ci] + a.ph[ci] && x >= a.px[ci] && x < a.px[ci] + a.pw[ci]) {
         const int vx = a.ox[ci] + x - a.px[ci], vy = a.oy[ci] + y - a.py[ci];
@@ -699,8 +714,10 @@ __global__ __launch_bounds__(kBlock) void rgbin_tile_kernel(const RgbInTileArgs 
     const int x0 = int(blockIdx.x) * 64, y0 = int(blockIdx.y) * t.th[ci];
     if (x0 >= a.canvas_w[ci]) return;
     const int x1 = min(x0 + 64, a.canvas_w[ci]), y1 = min(y0 + t.th[ci], a.canvas_h[ci]);
-    const uint8_t *sp = a.src + size_t(frame) * a.addr.src_pitch + a.addr.src_plane[0];
-    uint8_t *dp = a.dst + size_t(frame) * a.addr.dst_pitch + a.addr.dst_plane[plane];
+    const uint8_t *fb;
+    uint8_t *dp;
+    rgbin_frame(a, frame, plane, fb, dp);
+    const uint8_t *sp = fb + a.src_origin, *src_lo = fb, *src_hi = fb + a.src_extent;
     // the part of the tile that lies inside the picture (workgroup-uniform)
     const int ix0 = max(x0, a.px[ci]), ix1 = min(x1, a.px[ci] + a.pw[ci]);
     const int iy0 = max(y0, a.py[ci]), iy1 = min(y1, a.py[ci] + a.ph[ci]);
@@ -728,7 +745,7 @@ __global__ __launch_bounds__(kBlock) void rgbin_tile_kernel(const RgbInTileArgs 
             for (int j = lane; j <= vt; j += 64) vrow[(iy0 - y0 + yr) * (vt + 1) + j] = j ? vtaps[size_t(vy) * vt + j - 1] : int16_t(vpos[vy] - sylo);
         }
         // A1: the tile's source bytes as aligned dwords, coalesced (byte loads of 3-byte pixels kept the texture
-        // addresser 60 % busy by themselves); a dword that would reach past the batch is assembled from bytes
+        // addresser 60 % busy by themselves); a dword that would reach outside the frame is assembled from bytes
         for (int r = wave; r < nsy; r += waves) {
             const uint8_t *g0 = sp + size_t(sylo + r) * size_t(a.src_stride) + nb * sxlo;
             const int mis = int(reinterpret_cast<uintptr_t>(g0) & 3u);
@@ -737,10 +754,10 @@ __global__ __launch_bounds__(kBlock) void rgbin_tile_kernel(const RgbInTileArgs 
             for (int i = lane; i < ndw; i += 64) {
                 const uint8_t *q = g0 - mis + 4 * i;
                 uint32_t w;
-                if (q >= a.src_lo && q + 4 <= a.src_hi) w = *reinterpret_cast<const uint32_t *>(q);
+                if (q >= src_lo && q + 4 <= src_hi) w = *reinterpret_cast<const uint32_t *>(q);
                 else {
                     w = 0;
-                    for (int k = 0; k < 4; ++k) if (q + k >= a.src_lo && q + k < a.src_hi) w |= uint32_t(q[k]) << (8 * k);
+                    for (int k = 0; k < 4; ++k) if (q + k >= src_lo && q + k < src_hi) w |= uint32_t(q[k]) << (8 * k);
                 }
                 lrow[i] = w;
             }
@@ -1232,7 +1249,6 @@ const char *rgbin_plan_kernel_name(const RgbInPlan *p) { return p ? p->name : ""
 int rgbin_launch(const RgbInPlan *p, const uint8_t *src, uint8_t *dst, int n, int src_stride, const int dst_stride[2],
                  const FrameAddr &addr, hipStream_t st)
 {
-    if (addr.use_table) { set_last_error("rgb24 in: packed batches only"); return TTS_ERR_UNSUPPORTED; }
     const tts_geom &g = p->g;
     RgbInArgs a{};
     a.src = src; a.dst = dst;
@@ -1246,8 +1262,8 @@ int rgbin_launch(const RgbInPlan *p, const uint8_t *src, uint8_t *dst, int n, in
         a.dst_stride[k] = dst_stride[k];
     }
     a.src_stride = src_stride;
-    a.src_lo = src + addr.src_plane[0];
-    a.src_hi = a.src_lo + size_t(n - 1) * addr.src_pitch + size_t(g.in_h - 1) * size_t(src_stride) + size_t(g.in_w) * 3;
+    a.src_origin = uint32_t(g.pre_y) * uint32_t(src_stride) + uint32_t(g.pre_x) * 3u;
+    a.src_extent = uint32_t(size_t(g.in_h - 1) * size_t(src_stride) + size_t(g.in_w) * 3);
     a.fill[0] = g.fill_y; a.fill[1] = g.fill_u; a.fill[2] = g.fill_v;
     // utils.c fill_rgb2yuv_table(): the default matrix's table, 15 fractional bits
     const double S = 32768.0;
