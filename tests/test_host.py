@@ -137,3 +137,25 @@ def test_parse_vf_rgb24_input(tts):
 def test_frame_bytes(tts):
     assert tts.frame_bytes(1920, 1080) == 3110400
     assert tts.frame_bytes(101, 57) == 101 * 57 + 2 * 51 * 29
+
+
+def test_sizes_out_of_any_frames_range_are_refused(tts):
+    """Found by tools/hostfuzz (ASan + UBSan over the parser): `scale=-2147483648:...` negated INT_MIN, and a pad
+    canvas had no upper limit.  Both are plain INVALID_INPUT now."""
+    for vf in ("scale=-2147483648:180", "scale=320:-2147483648", "scale=99999999999:180",
+               "scale=320:180,pad=332520:180:-1:-1", "scale=320:180,pad=320:70000"):
+        with pytest.raises(tts.TtsError):
+            tts.parse_vf(vf, 1920, 1080)
+
+
+def test_host_fuzz_under_sanitizers():
+    """tools/hostfuzz/run.sh: 20,000 mutated filter strings through parse_vf / check_geom / build_axis_filter in a
+    g++ -fsanitize=address,undefined build (host code only; the GPU pool offers no device sanitizer)."""
+    import os
+    import shutil
+    import subprocess
+    if shutil.which("g++") is None:
+        pytest.skip("no g++")
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    r = subprocess.run([os.path.join(root, "tools", "hostfuzz", "run.sh"), "20000"], capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0 and "no finding" in r.stdout, (r.stdout[-500:], r.stderr[-1500:])

@@ -179,6 +179,9 @@ bool build_axis_filter(int src, int dst, int one, int alg, AxisFilter &out)
 bool scale_output_size(int iw, int ih, int w, int h, int foar, int fdb, int &ow, int &oh)
 {
     auto rescale = [](i64 a, i64 b, i64 c) { return (a * b + c / 2) / c; };   // round half up, positives
+    // (sizes far outside anything a frame can be: refused here, before -w, w * fdb or the casts below can overflow)
+    constexpr int kLimit = 1 << 20;
+    if (iw < 1 || ih < 1 || iw > kLimit || ih > kLimit || w < -kLimit || w > kLimit || h < -kLimit || h > kLimit || fdb > kLimit) return false;
     if (w == 0) w = iw;
     if (h == 0) h = ih;
     const int fw = w < -1 ? -w : 1, fh = h < -1 ? -h : 1;
@@ -239,6 +242,7 @@ int check_geom(const tts_geom &g)
         g.crop_x + g.crop_w > g.sc_w || g.crop_y + g.crop_h > g.sc_h) return TTS_ERR_INVALID_INPUT;
     const bool has_crop = g.crop_x || g.crop_y || g.crop_w != g.sc_w || g.crop_h != g.sc_h;
     if (has_crop && !(even(g.crop_x) && even(g.crop_y) && even(g.crop_w) && even(g.crop_h))) return TTS_ERR_INVALID_INPUT;
+    if (g.out_w > 16384 || g.out_h > 16384) return TTS_ERR_INVALID_INPUT;     // (a pad canvas: the same limit as every other size here)
     if (g.do_pad) {
         if (!(even(g.pad_x) && even(g.pad_y) && even(g.out_w) && even(g.out_h))) return TTS_ERR_INVALID_INPUT;
         if (g.pad_x < 0 || g.pad_y < 0 || g.pad_x + g.crop_w > g.out_w + 1 || g.pad_y + g.crop_h > g.out_h + 1 ||
