@@ -70,3 +70,11 @@ def test_scaler_consumes_a_loop_order(tts, oracle, vf, iw, ih):
     assert np.array_equal(got, oracle.run_chain(plan.geom, src[rnd]))
     with pytest.raises(tts.TtsError):
         plan.run_batch_order(torch.from_numpy(src).cuda(), np.array([0, n], np.int32))
+
+
+def test_trim_range_takes_infinite_and_absurd_times(tts):
+    """-ss / -t far past the clip (or infinite): an empty range at the clip's end, never an out-of-range cast."""
+    for start, dur in ((float("inf"), 1.0), (1e300, 1e300), (0.0, float("inf")), (3.0, 1e308)):
+        first, count = tts.trim_range(100, 30, start, dur)
+        assert 0 <= first <= 100 and 0 <= count <= 100 - first
+    assert tts.trim_range(100, 30, 0.0, float("inf")) == (0, 100)

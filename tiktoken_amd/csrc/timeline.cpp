@@ -19,6 +19,7 @@ int64_t first_frame_at(double t, int num, int den)
 {
     if (t <= 0) return 0;
     const double x = t * double(num) / double(den);
+    if (!(x < 4e18)) return INT64_MAX;                         // (infinite or absurd times: past any clip, and no out-of-range cast)
     return int64_t(std::ceil(x - 1e-9));
 }
 
