@@ -78,6 +78,41 @@ def test_rgb_fast_and_generic_kernels_agree(tts, oracle, monkeypatch):
     assert np.array_equal(a, b) and np.array_equal(a, oracle.run_chain(plan.geom, src))
 
 
+SCRATCH_CASES = [
+    (THUMB, 1920, 1080, "rgb24"),                      # src/services/video.js:329-334 on 1080p
+    (THUMB, 1080, 1920, "rgb24"),                      # 101 x 180 picture in the 320 x 180 canvas: pad border on RGB pixels
+    (THUMB, 3840, 2160, "bgra"),
+    ("scale=160:90", 1920, 1080, "bgr24"),
+    ("scale=213:121", 1283, 721, "rgba"),              # odd picture: the planes only fit a 4-byte-a-pixel frame
+    ("scale=214:120,crop=200:100:6:10", 1283, 721, "rgb24"),
+    ("scale=96:54,pad=128:72:-1:-1:color=red", 640, 360, "rgb24"),
+]
+
+
+@pytest.mark.parametrize("vf,iw,ih,fmt", SCRATCH_CASES)
+def test_rgb_thumbnails_column_walk_and_in_place_conversion(tts, oracle, monkeypatch, vf, iw, ih, fmt):
+    """Many-tap shrinks written as packed RGB: the planar column walk leaves unclipped 16-bit luma and chroma at
+    ceil(w / 2) x h in the destination frame, one workgroup per frame converts in place -- same bytes as the
+    one-lane-per-pixel kernel (TTS_NO_RGB_SCRATCH=1) and as the oracle, for batches too."""
+    import torch
+    chain = vf + ",format=" + fmt
+    n = 1 if iw * ih > 4_000_000 else 5
+    src = synth.frames("random", iw, ih, n)
+    fast = tts.Plan.from_vf(chain, iw, ih)
+    assert fast.kernel_name(0).endswith("+rgb_convert"), fast.kernel_name(0)
+    monkeypatch.setenv("TTS_NO_RGB_SCRATCH", "1")
+    slow = tts.Plan.from_vf(chain, iw, ih)
+    assert slow.kernel_name(0).startswith("rgb_generic"), slow.kernel_name(0)
+    d = torch.from_numpy(src).cuda()
+    a, b = fast.run_batch(d).cpu().numpy(), slow.run_batch(d).cpu().numpy()
+    want = oracle.run_chain(fast.geom, src)
+    assert np.array_equal(b, want), "generic kernel differs from the oracle"
+    bad = np.flatnonzero(a != want)
+    assert bad.size == 0, "%s: %d bytes differ, first at %d (got %d want %d)" % (chain, bad.size, bad[0], a.ravel()[bad[0]], want.ravel()[bad[0]])
+    src = synth.frames("impulse", iw, ih, 1)
+    assert np.array_equal(fast.run_batch(torch.from_numpy(src).cuda()).cpu().numpy(), oracle.run_chain(fast.geom, src))
+
+
 def test_rgb_strided_rows_and_frame_pointers(tts, oracle):
     """Padded RGB rows (tts_run_batch_strided) and per-frame pointers (tts_run: plane[0] / stride[0] alone)."""
     import torch

@@ -63,6 +63,32 @@ int tts_parse_vf_fmt(const char *vf, int iw, int ih, int in_fmt, tts_geom *out)
     return rc;
 }
 
+// The two plane classes of a planar plan and their table buffer.  full_v: see build_class.
+static int build_classes(tts_plan *p, const tts_geom &g, bool full_v)
+{
+    std::vector<uint32_t> tab;
+    int rc = TTS_OK;
+    for (int ci = 0; ci < 2 && rc == TTS_OK; ++ci) rc = build_class(g, ci, p->cls[ci], tab, 0, full_v && ci);
+    // Column walk: luma and chroma ratios differ by a rounding, so their tap counts may straddle an
+    // instantiation boundary (720x1280 -> 101x180: 16 tap pairs luma, 14 chroma) and the chain would take two
+    // launches.  The class with fewer is rebuilt with the other's window: a seventh more arithmetic on a third
+    // of the samples against one launch less on a path that is one thumbnail per call in the reference.
+    if (rc == TTS_OK && p->cls[0].kind == 2 && p->cls[1].kind == 2 && p->cls[0].NTP != p->cls[1].NTP &&
+        std::abs(p->cls[0].NTP - p->cls[1].NTP) <= 2 && !p->knobs.no_merge) {
+        const int lo = p->cls[0].NTP < p->cls[1].NTP ? 0 : 1, want = p->cls[1 - lo].NTP;
+        free_class(p->cls[lo]);
+        p->cls[lo] = ClassPlan();
+        rc = build_class(g, lo, p->cls[lo], tab, want, full_v && lo);
+        if (rc == TTS_OK && p->cls[lo].kind != 2) {         // (the wider window does not fit this class's rows: as it was)
+            free_class(p->cls[lo]);
+            p->cls[lo] = ClassPlan();
+            rc = build_class(g, lo, p->cls[lo], tab, 0, full_v && lo);
+        }
+    }
+    if (rc == TTS_OK && !upload(p->d_tab, tab)) rc = TTS_ERR_INITIALIZATION_FAILED;
+    return rc;
+}
+
 int tts_plan_create(const tts_geom *g, tts_plan **out)
 {
     if (!g || !out) return TTS_ERR_INVALID_INPUT;
@@ -78,7 +104,6 @@ int tts_plan_create(const tts_geom *g, tts_plan **out)
     p->knobs.read();
     int cus = 0;
     if (hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) == hipSuccess && cus > 0) p->n_cus = cus;
-    std::vector<uint32_t> tab;
     if (g->in_fmt == TTS_FMT_RGB24) {
         rc = tts::rgbin_plan_create(*g, &p->rgbin);            // (sets the error text itself)
         if (rc) { tts_plan_destroy(p); return rc; }
@@ -88,27 +113,25 @@ int tts_plan_create(const tts_geom *g, tts_plan **out)
     if (g->out_fmt != TTS_FMT_YUV420P) {
         rc = tts::rgb_plan_create(*g, p->n_cus, &p->rgb);      // (sets the error text itself)
         if (rc) { tts_plan_destroy(p); return rc; }
+        // Thumbnail-sized pictures written as RGB by a many-tap scale: a planar plan of the same scale (chroma at
+        // every output row, luma unclipped) whose column walk writes into the RGB frame, converted in place.
+        // Anything that does not qualify -- or whose classes do not both take the column walk -- stays with p->rgb.
+        tts::RgbScratchLayout lay;
+        if (!p->knobs.no_rgb_scratch && tts::rgb_scratch_layout(*g, lay)) {
+            tts_plan *sp = new (std::nothrow) tts_plan();
+            if (sp) {
+                tts_geom gp = *g;
+                gp.out_fmt = TTS_FMT_YUV420P; gp.rgb_stage = TTS_RGB_NONE; gp.fill_rgb = 0;
+                gp.do_pad = 0; gp.pad_x = gp.pad_y = 0; gp.out_w = g->crop_w; gp.out_h = g->crop_h;
+                sp->g = gp; sp->device = dev; sp->knobs = p->knobs; sp->n_cus = p->n_cus; sp->y16 = true;
+                if (build_classes(sp, gp, true) == TTS_OK && sp->cls[0].kind == 2 && sp->cls[1].kind == 2) p->scratch = sp;
+                else tts_plan_destroy(sp);
+            }
+        }
         *out = p;
         return TTS_OK;
     }
-    for (int ci = 0; ci < 2 && rc == TTS_OK; ++ci) rc = build_class(*g, ci, p->cls[ci], tab);
-    // Column walk: luma and chroma ratios differ by a rounding, so their tap counts may straddle an
-    // instantiation boundary (720x1280 -> 101x180: 16 tap pairs luma, 14 chroma) and the chain would take two
-    // launches.  The class with fewer is rebuilt with the other's window: a seventh more arithmetic on a third
-    // of the samples against one launch less on a path that is one thumbnail per call in the reference.
-    if (rc == TTS_OK && p->cls[0].kind == 2 && p->cls[1].kind == 2 && p->cls[0].NTP != p->cls[1].NTP &&
-        std::abs(p->cls[0].NTP - p->cls[1].NTP) <= 2 && !p->knobs.no_merge) {
-        const int lo = p->cls[0].NTP < p->cls[1].NTP ? 0 : 1, want = p->cls[1 - lo].NTP;
-        free_class(p->cls[lo]);
-        p->cls[lo] = ClassPlan();
-        rc = build_class(*g, lo, p->cls[lo], tab, want);
-        if (rc == TTS_OK && p->cls[lo].kind != 2) {         // (the wider window does not fit this class's rows: as it was)
-            free_class(p->cls[lo]);
-            p->cls[lo] = ClassPlan();
-            rc = build_class(*g, lo, p->cls[lo], tab);
-        }
-    }
-    if (rc == TTS_OK && !upload(p->d_tab, tab)) rc = TTS_ERR_INITIALIZATION_FAILED;
+    rc = build_classes(p, *g, false);
     if (rc) {
         if (rc == TTS_ERR_INITIALIZATION_FAILED) g_last_error = "table upload failed (hipMalloc / hipMemcpy)";
         tts_plan_destroy(p);
@@ -125,6 +148,7 @@ void tts_plan_destroy(tts_plan *p)
     (void)hipFree(p->d_tab);
     tts::rgb_plan_destroy(p->rgb);
     tts::rgbin_plan_destroy(p->rgbin);
+    tts_plan_destroy(p->scratch);
     delete p;
 }
 
@@ -184,6 +208,11 @@ const char *tts_plan_kernel_name(const tts_plan *p, int plane_class)
 {
     static thread_local char buf[96];
     if (!p || plane_class < 0 || plane_class > 1) return "";
+    if (p->scratch) {                                       // (what packed batches run; pointers and padded rows: the generic kernel)
+        static thread_local char sbuf[128];
+        std::snprintf(sbuf, sizeof sbuf, "%s+rgb_convert", tts_plan_kernel_name(p->scratch, plane_class));
+        return sbuf;
+    }
     if (p->rgb) return tts::rgb_plan_kernel_name(p->rgb);
     if (p->rgbin) return tts::rgbin_plan_kernel_name(p->rgbin);
     const ClassPlan &c = p->cls[plane_class];
@@ -261,7 +290,9 @@ int run_batch_impl(const tts_plan *p, const void *src, size_t src_pitch, const i
     if (src_pitch >= (size_t(1) << 31) || dst_pitch >= (size_t(1) << 31)) return TTS_ERR_UNSUPPORTED;
     if (const int rc = check_device(p)) return rc;
     hipStream_t st = static_cast<hipStream_t>(hip_stream);
-    if (p->rgb) {
+    tts::RgbScratchLayout lay{};
+    const bool use_scratch = p->rgb && p->scratch && dstride[0] == g.out_w * bpp && tts::rgb_scratch_layout(g, lay);
+    if (p->rgb && !use_scratch) {
         // The RGB kernels cover the whole canvas (borders included) and address every frame from its own base
         // (per workgroup or per wave), so one launch set takes the batch whatever its span.
         if (sbytes > kMaxSpan || dbytes > kMaxSpan) return TTS_ERR_UNSUPPORTED;
@@ -277,14 +308,17 @@ int run_batch_impl(const tts_plan *p, const void *src, size_t src_pitch, const i
                           uint64_t(n_frames - 1) * src_pitch + sbytes, uint64_t(n_frames - 1) * dst_pitch + dbytes, addr, st);
     }
 
+    // (packed-RGB thumbnails: the planar pass of p->scratch writes its planes into the RGB frames, see tts_plan)
+    const tts_plan *pp = use_scratch ? p->scratch : p;
+    const int pds[2] = {use_scratch ? lay.stride[0] : dstride[0], use_scratch ? lay.stride[1] : dstride[1]};
     FrameAddr addr{};
     addr.src_pitch = uint32_t(src_pitch); addr.dst_pitch = uint32_t(dst_pitch);
     uint32_t splane = 0, dplane = 0;
     for (int k = 0; k < 3; ++k) {
         const int ci = k ? 1 : 0;
-        const ClassPlan &c = p->cls[ci];
+        const ClassPlan &c = pp->cls[ci];
         addr.src_plane[k] = splane + uint32_t(g.pre_y >> ci) * sstride[ci] + uint32_t(g.pre_x >> ci);
-        addr.dst_plane[k] = dplane + uint32_t(c.pad_y) * dstride[ci] + uint32_t(c.pad_x);
+        addr.dst_plane[k] = use_scratch ? lay.off[k] : dplane + uint32_t(c.pad_y) * dstride[ci] + uint32_t(c.pad_x);
         splane += uint32_t(sstride[ci]) * ceil_shift(g.in_h, ci);
         dplane += uint32_t(dstride[ci]) * ceil_shift(g.out_h, ci);
     }
@@ -293,11 +327,11 @@ int run_batch_impl(const tts_plan *p, const void *src, size_t src_pitch, const i
     // kMaxSpan: a wave holds 64 items, a frame at least `ipf` of them.  (Pitches so large that they do
     // not -- hundreds of megabytes between frames -- fall back to launches whose whole span fits.)
     if (sbytes > kMaxSpan || dbytes > kMaxSpan) return TTS_ERR_UNSUPPORTED;
-    const int ipf = std::max(1, (std::min(p->cls[0].ow, p->cls[1].ow) + 15) / 16);
+    const int ipf = std::max(1, (std::min(pp->cls[0].ow, pp->cls[1].ow) + 15) / 16);
     const size_t wave_frames = size_t(63 / ipf + 2);
     const bool any_size = wave_frames * src_pitch + sbytes <= kMaxSpan && wave_frames * dst_pitch + dbytes <= kMaxSpan && !p->knobs.span_chunks;
     // items and workgroups are counted in 32 bits: at most 2^30 output columns a launch
-    const size_t cols_per_frame = size_t(p->cls[0].ow) + 2 * size_t(p->cls[1].ow);
+    const size_t cols_per_frame = size_t(pp->cls[0].ow) + 2 * size_t(pp->cls[1].ow);
     const size_t max_frames = std::max<size_t>(1, (size_t(1) << 30) / std::max<size_t>(cols_per_frame, 1));
     const size_t by_span = 1 + std::min((kMaxSpan - sbytes) / src_pitch, (kMaxSpan - dbytes) / dst_pitch);
     const int chunk = int(std::min(any_size ? max_frames : std::min(by_span, max_frames), size_t(1) << 30));
@@ -307,9 +341,10 @@ int run_batch_impl(const tts_plan *p, const void *src, size_t src_pitch, const i
         uint8_t *d = static_cast<uint8_t *>(dst) + size_t(f0) * dst_pitch;
         const uint64_t sspan = uint64_t(n - 1) * src_pitch + sbytes, dspan = uint64_t(n - 1) * dst_pitch + dbytes;
         addr.wave_base = sspan > kMaxSpan || dspan > kMaxSpan || p->knobs.wave_base;
-        const int rc = launch_all(p, s, d, n, sstride, dstride, sspan, dspan, addr, st);
+        const int rc = launch_all(pp, s, d, n, sstride, pds, sspan, dspan, addr, st);
         if (rc) return rc;
     }
+    if (use_scratch) return tts::rgb_scratch_convert(p->rgb, static_cast<uint8_t *>(dst), dst_pitch, n_frames, st);
     return TTS_OK;
 }
 

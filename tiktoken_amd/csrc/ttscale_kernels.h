@@ -50,6 +50,8 @@ struct StripArgs {
     RangeStep range;
     PadClass pad[2];
     uint32_t scaler_blocks;        // logical blocks [0, scaler_blocks) scale, the rest fill pad borders
+    int32_t  y16;                  // column walk only: class 0 (luma) stores its UNCLIPPED vertical sums as int16 (2 bytes a column): the
+                                   // intermediate of the packed-RGB thumbnail path (ttscale_rgb.hip rgb_scratch_convert_kernel)
     uint64_t *dbg;                 // -DTTS_EXPERIMENTS builds: (start, end) clock of every workgroup of strip_lds_kernel; else null, unused
     FrameAddr addr;
 };
@@ -824,7 +826,8 @@ __global__ __launch_bounds__(kBlock, (D4 && NC == 2 && NTP == 12 && NDMA == 1) ?
     const uint8_t *wsrc = src;                       // this wave's bases
     uint8_t *wdst = dst;
     frame_offsets(a, plane, frame, wsrc, wdst, src_rec, dst_rec, soff, doff);
-    doff += uint32_t(col);
+    const bool y16 = a.y16 != 0 && ci == 0;        // (wave-uniform)
+    doff += uint32_t(col) << (y16 ? 1 : 0);
     if (!live) doff = kDiscard;                    // see strip_lds_kernel
 
     [[maybe_unused]] uint32_t hc[D4 ? 1 : NC][D4 ? 1 : NTP];
@@ -966,6 +969,12 @@ __global__ __launch_bounds__(kBlock, (D4 && NC == 2 && NTP == 12 && NDMA == 1) ?
                     for (int j = 0; j < NC; ++j) v[j] = dot2(ring[j][q], vk, v[j]);
                 }
                 const int yoff = int(uni(uint32_t(y * dst_stride)));
+                if (y16) {                                      // wave-uniform: unclipped 16-bit sums for the RGB conversion pass
+                    if constexpr (NC == 2) store_b32((uint32_t(v[0] >> 19) & 0xffffu) | (uint32_t(v[1] >> 19) << 16), drs, doff, yoff);
+                    else if constexpr (NC == 1) store_b16(uint32_t(v[0] >> 19), drs, doff, yoff);
+                    ++y;
+                    continue;
+                }
                 if constexpr (NC == 4) {
                     uint32_t o4 = pack4(v[0], v[1], v[2], v[3]);
                     if (rng) o4 = range_bytes4(o4, rmul, radd, rsh);

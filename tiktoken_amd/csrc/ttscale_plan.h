@@ -102,6 +102,7 @@ struct Knobs {
     int wave_base = 0;                // tts_run_batch: per-wave descriptors even when the batch fits one base (test knob)
     int col_nc_launch = 0;            // column walk above 8 tap pairs: 1 / 2 columns per lane whatever the launch's size (0 = by size)
     int col_fill = 0;                 // column walk: workgroups per resident slot (in tenths) a segment length must leave; 0 = by tap count
+    int no_rgb_scratch = 0;           // packed-RGB thumbnails through the generic kernel instead of column walk + in-place conversion (A/B, tests)
     int col_d4 = 1;                   // column walk: v_dot4 on packed bytes with two-digit taps instead of v_perm + v_dot2: 0 never, 1 above 8 tap pairs, 2 wherever the tables exist
     int col_model = 1;                // column walk segment length: 0 = fill rule, 1 = busiest-CU model above 8 tap pairs, 2 = everywhere
     int host_chunk_mb = 128;          // tts_run_host: bytes (source + output) of one pipelined chunk
@@ -120,6 +121,7 @@ struct Knobs {
         col_fill = std::max(0, env_int("TTS_COL_FILL", 0));
         col_model = env_int("TTS_COL_MODEL", 1);
         col_d4 = env_int("TTS_COL_D4", 1);
+        no_rgb_scratch = env_int("TTS_NO_RGB_SCRATCH", 0);
         col_nc_launch = env_int("TTS_COL_NC_LAUNCH", 0);
         host_chunk_mb = std::max(1, env_int("TTS_HOST_CHUNK_MB", 128));
     }
@@ -153,6 +155,12 @@ struct tts_plan {
     uint32_t *d_tab = nullptr;        // strip tables of both classes
     tts::RgbPlan *rgb = nullptr;      // packed-RGB output (g.out_fmt != yuv420p): the plan of ttscale_rgb.hip; cls[] stay empty
     tts::RgbInPlan *rgbin = nullptr;  // packed rgb24 input (g.in_fmt): likewise
+    // Packed-RGB thumbnails (many-tap shrinks written as RGB by the chain's scale): a planar plan of the same
+    // scale whose column walk leaves unclipped 16-bit luma and chroma at ceil(w / 2) x h in the destination frame
+    // itself, converted in place by rgb_scratch_convert_kernel (tts_run_batch on packed rows; `rgb` stays the
+    // path of everything else).  Null when the geometry does not qualify.
+    tts_plan *scratch = nullptr;
+    bool y16 = false;                 // this IS such a scratch plan: luma class stores int16
     int device = 0;
     int n_cus = 256;
 };
@@ -273,18 +281,21 @@ uint32_t build_d4_tables(const ClassPlan &c, int NTP, int nc, const std::vector<
 
 // min_ntp: column walk only -- at least this many tap pairs (so that both classes of a chain can run the same
 // instantiation, i.e. one launch: see tts_plan_create)
-int build_class(const tts_geom &g, int sub, ClassPlan &c, std::vector<uint32_t> &tab, int min_ntp = 0)
+// full_v: the chroma class keeps every OUTPUT row (its source rows are still subsampled): what a swscale context
+// that writes packed RGB computes (chroma at ceil(w / 2) x h) -- the scratch planes of the RGB thumbnail path.
+int build_class(const tts_geom &g, int sub, ClassPlan &c, std::vector<uint32_t> &tab, int min_ntp = 0, bool full_v = false)
 {
     c.sub = sub;
+    const int vsub = full_v ? 0 : sub;                 // subsampling of the output rows
     c.src_w = ceil_shift(g.pre_w, sub); c.src_h = ceil_shift(g.pre_h, sub);
-    const int vw = ceil_shift(g.sc_w, sub), vh = ceil_shift(g.sc_h, sub);
+    const int vw = ceil_shift(g.sc_w, sub), vh = ceil_shift(g.sc_h, vsub);
     if (!tts::build_axis_filter(c.src_w, vw, 1 << 14, g.alg, c.h)) return TTS_ERR_INVALID_INPUT;
     if (!tts::build_axis_filter(c.src_h, vh, 1 << 12, g.alg, c.v)) return TTS_ERR_INVALID_INPUT;
     const int content_w = g.do_pad ? (g.crop_w & ~1) : g.crop_w;   // pad's right border eats an odd last column
-    c.x0 = g.crop_x >> sub; c.y0 = g.crop_y >> sub;
-    c.ow = ceil_shift(content_w, sub); c.oh = ceil_shift(g.crop_h, sub);
-    c.canvas_w = ceil_shift(g.out_w, sub); c.canvas_h = ceil_shift(g.out_h, sub);
-    c.pad_x = g.do_pad ? g.pad_x >> sub : 0; c.pad_y = g.do_pad ? g.pad_y >> sub : 0;
+    c.x0 = g.crop_x >> sub; c.y0 = g.crop_y >> vsub;
+    c.ow = ceil_shift(content_w, sub); c.oh = ceil_shift(g.crop_h, vsub);
+    c.canvas_w = ceil_shift(g.out_w, sub); c.canvas_h = ceil_shift(g.out_h, vsub);
+    c.pad_x = g.do_pad ? g.pad_x >> sub : 0; c.pad_y = g.do_pad ? g.pad_y >> vsub : 0;
     if (c.ow < 1 || c.oh < 1) return TTS_ERR_INVALID_INPUT;
 
     // generic tables (also what tts_plan_filter reports)
@@ -981,6 +992,7 @@ int launch_all(const tts_plan *p, const uint8_t *src, uint8_t *dst, int n, const
                 a.c[1] = a.c[0]; a.c[1].nblocks = 0;
             }
             a.scaler_blocks = a.c[0].nblocks + (cmerged ? a.c[1].nblocks : 0);
+            a.y16 = p->y16 && (cmerged || ci == 0);
 #ifdef TTS_EXPERIMENTS
             a.dbg = exp_dbg_buffer(a.scaler_blocks);
 #endif

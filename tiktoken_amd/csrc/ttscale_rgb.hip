@@ -607,6 +607,68 @@ __global__ __launch_bounds__(kBlock, 4) void rgb_strip_kernel(const uint8_t *__r
 #endif
 }
 
+// ---- packed-RGB thumbnails: in-place conversion of the planes the column walk left in the frame ------------
+// The many-tap shrinks of the reference's thumbnail chain (src/services/video.js:329-334 ends in an image
+// encoder) ran through rgb_generic_kernel at taps^2 multiply-adds per plane and pixel (29 k frames/s for
+// 1080p -> 320x180 -> rgb24).  Instead the planar column walk (column_lds_kernel, luma stored unclipped as
+// int16, chroma at ceil(w / 2) x h as the RGB-writing context computes it) writes its three planes into the
+// destination frame itself -- 2 w h + 2 ceil(w / 2) h bytes, never more than the 3 w h the frame has -- and one
+// workgroup per frame turns them into pixels in place: every thread reads its share of all three planes (luma
+// into registers, chroma into LDS), the workgroup meets at a barrier, and only then is anything written.
+struct RgbScratchArgs {
+    uint8_t *dst;
+    uint64_t dst_pitch;
+    int32_t  pw, ph, cw;               // picture, chroma columns
+    int32_t  canvas_w, canvas_h, px, py, dst_stride;
+    uint32_t off_u, off_v;             // byte offsets of the chroma planes inside a frame (luma at 0)
+    int32_t  bpp, swap;
+    int32_t  border[3];
+    RgbCoef  coef;
+};
+
+constexpr int kScratchThreads = 1024, kScratchMaxPix = 65536, kScratchMaxChroma = 65536;
+
+__global__ __launch_bounds__(kScratchThreads) void rgb_scratch_convert_kernel(const RgbScratchArgs a)
+{
+    __shared__ __attribute__((aligned(16))) uint8_t uv[kScratchMaxChroma];
+    uint8_t *fb = a.dst + size_t(blockIdx.x) * a.dst_pitch;
+    const int t = int(threadIdx.x);
+    const int npix = a.pw * a.ph;
+    const int cb = int(a.off_v - a.off_u) + a.cw * a.ph;           // chroma bytes, U first
+    for (int i = t; i < cb; i += kScratchThreads) uv[i] = fb[a.off_u + i];
+    int yv[kScratchMaxPix / kScratchThreads];
+#pragma unroll
+    for (int it = 0; it < kScratchMaxPix / kScratchThreads; ++it) {
+        const int idx = it * kScratchThreads + t;                  // consecutive lanes, consecutive pixels
+        int v = 0;
+        if (idx < npix) {
+            const uint8_t *q = fb + 2 * size_t(idx);               // (a frame may start at an odd address: two byte loads)
+            v = int(int16_t(uint16_t(q[0]) | uint16_t(q[1]) << 8));
+        }
+        yv[it] = v;
+    }
+    __syncthreads();                                               // every load of the workgroup has landed: the frame may be overwritten
+    const int voff = int(a.off_v - a.off_u);
+#pragma unroll
+    for (int it = 0; it < kScratchMaxPix / kScratchThreads; ++it) {
+        const int idx = it * kScratchThreads + t;
+        if (idx < npix) {
+            const int y = idx / a.pw, x = idx - y * a.pw;
+            const int U = uv[y * a.cw + (x >> 1)], V = uv[voff + y * a.cw + (x >> 1)];
+            int r, g, b;
+            tts::rgb_pixel(a.coef, yv[it], U, V, r, g, b);
+            rgb_store_pixel(fb + size_t(y + a.py) * a.dst_stride + size_t(x + a.px) * a.bpp, a.bpp, a.swap, r, g, b);
+        }
+    }
+    if (a.canvas_w != a.pw || a.canvas_h != a.ph) {                // the pad border
+        for (int i = t; i < a.canvas_w * a.canvas_h; i += kScratchThreads) {
+            const int y = i / a.canvas_w, x = i - y * a.canvas_w;
+            if (y >= a.py && y < a.py + a.ph && x >= a.px && x < a.px + a.pw) continue;
+            rgb_store_pixel(fb + size_t(y) * a.dst_stride + size_t(x) * a.bpp, a.bpp, a.swap, a.border[0], a.border[1], a.border[2]);
+        }
+    }
+}
+
 // ---- packed rgb24 in, yuv420p out: any tap counts, one lane per output sample ---------------------------
 // swscale's input side (input.c rgb24ToY_c / rgb24ToUV_half_c, BT.601 limited range, coefficients in 15
 // fractional bits) evaluated on the fly in front of the scaler's arithmetic: samples enter the horizontal
@@ -1145,6 +1207,37 @@ int rgb_launch(const RgbPlan *p, const uint8_t *src, uint8_t *dst, int n, const 
         }
     }
     return rc;
+}
+
+}  // namespace tts
+
+namespace tts {
+
+bool rgb_scratch_layout(const tts_geom &g, RgbScratchLayout &out)
+{
+    if (g.out_fmt == TTS_FMT_YUV420P || g.rgb_stage != TTS_RGB_AT_SCALE || !g.do_scale || ((g.crop_x | g.crop_y) & 1)) return false;
+    const int pw = g.crop_w, ph = g.crop_h, cw = (pw + 1) >> 1, bpp = g.out_fmt >= TTS_FMT_RGBA ? 4 : 3;
+    if (int64_t(pw) * ph > kScratchMaxPix) return false;
+    auto align4 = [](uint32_t v) { return (v + 3u) & ~3u; };
+    out.off[0] = 0; out.off[1] = align4(2u * uint32_t(pw) * uint32_t(ph)); out.off[2] = out.off[1] + align4(uint32_t(cw) * uint32_t(ph));
+    out.stride[0] = 2 * pw; out.stride[1] = cw;
+    if (out.off[2] - out.off[1] + uint32_t(cw) * uint32_t(ph) > uint32_t(kScratchMaxChroma)) return false;
+    return uint64_t(out.off[2]) + uint64_t(cw) * ph <= uint64_t(g.out_w) * g.out_h * bpp;       // the planes fit the frame they are written into
+}
+
+int rgb_scratch_convert(const RgbPlan *p, uint8_t *dst, size_t dst_pitch, int n, hipStream_t st)
+{
+    RgbScratchLayout L;
+    if (!rgb_scratch_layout(p->g, L)) { set_last_error("rgb_scratch_convert: geometry does not qualify"); return TTS_ERR_PROCESSING_FAILED; }
+    RgbScratchArgs a{};
+    a.dst = dst; a.dst_pitch = dst_pitch;
+    a.pw = p->pw; a.ph = p->ph; a.cw = (p->pw + 1) >> 1;
+    a.canvas_w = p->g.out_w; a.canvas_h = p->g.out_h; a.px = p->px; a.py = p->py; a.dst_stride = p->g.out_w * p->bpp;
+    a.off_u = L.off[1]; a.off_v = L.off[2];
+    a.bpp = p->bpp; a.swap = p->swap ? 1 : 0;
+    for (int i = 0; i < 3; ++i) a.border[i] = p->border[i];
+    a.coef = p->coef;
+    return launch_rgb("rgb_scratch_convert_kernel", rgb_scratch_convert_kernel, dim3(unsigned(n)), dim3(kScratchThreads), 0, st, a);
 }
 
 }  // namespace tts
