@@ -113,6 +113,17 @@ def test_rgb_thumbnails_column_walk_and_in_place_conversion(tts, oracle, monkeyp
     assert np.array_equal(fast.run_batch(torch.from_numpy(src).cuda()).cpu().numpy(), oracle.run_chain(fast.geom, src))
 
 
+@pytest.mark.parametrize("vf,iw,ih,n", [("scale=20:12", 60, 40, 1), ("scale=20:12", 60, 40, 9), ("scale=16:10", 48, 30, 2), ("scale=24:16", 100, 64, 1)])
+def test_rgb_tiny_shrinks_fall_back(tts, oracle, vf, iw, ih, n):
+    """Sources under 4 KiB run the one-lane-per-sample kernels (no 16-bit luma store there): the RGB thumbnail
+    path must not send them through the scratch pass."""
+    import torch
+    plan = tts.Plan.from_vf(vf + ",format=rgb24", iw, ih)
+    src = synth.frames("random", iw, ih, n)
+    got = plan.run_batch(torch.from_numpy(src).cuda()).cpu().numpy()
+    assert np.array_equal(got, oracle.run_chain(plan.geom, src)), plan.kernel_name(0)
+
+
 def test_rgb_strided_rows_and_frame_pointers(tts, oracle):
     """Padded RGB rows (tts_run_batch_strided) and per-frame pointers (tts_run: plane[0] / stride[0] alone)."""
     import torch
@@ -209,12 +220,14 @@ def test_rgb24_input_tiled_and_generic_kernels_agree(tts, oracle, monkeypatch, v
     assert np.array_equal(a, b) and np.array_equal(a, oracle.run_chain(tiled.geom, src))
 
 
+@pytest.mark.parametrize("planewise", ["0", "1"])
 @pytest.mark.parametrize("vf,iw,ih", [RGBIN_CASES[0], RGBIN_CASES[8], RGBIN_CASES[11], RGBIN_CASES[2]])
-def test_rgb24_input_through_frame_pointers(tts, oracle, vf, iw, ih):
+def test_rgb24_input_through_frame_pointers(tts, oracle, monkeypatch, vf, iw, ih, planewise):
     """tts_run with packed-RGB source frames: one source plane per frame (rows padded), three destination planes,
     every buffer its own allocation; padding is never written."""
     import torch
     n, pad_s, pad_d = 5, 7, 5
+    monkeypatch.setenv("TTS_PLANEWISE", planewise)       # "1": one destination plane per launch (planes further than 4 GiB apart)
     plan = tts.Plan.from_vf(vf, iw, ih, in_fmt="rgb24")
     ow, oh = plan.out_size
     src = rgb_frames("random", iw, ih, n)

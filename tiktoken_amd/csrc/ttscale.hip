@@ -291,7 +291,9 @@ int run_batch_impl(const tts_plan *p, const void *src, size_t src_pitch, const i
     if (const int rc = check_device(p)) return rc;
     hipStream_t st = static_cast<hipStream_t>(hip_stream);
     tts::RgbScratchLayout lay{};
-    const bool use_scratch = p->rgb && p->scratch && dstride[0] == g.out_w * bpp && tts::rgb_scratch_layout(g, lay);
+    // (sources under 4 KiB go to the one-lane-per-sample kernel, which has no 16-bit store: not through the scratch pass)
+    bool use_scratch = p->rgb && p->scratch && dstride[0] == g.out_w * bpp && sbytes >= 4096 && tts::rgb_scratch_layout(g, lay);
+rgb_generic:
     if (p->rgb && !use_scratch) {
         // The RGB kernels cover the whole canvas (borders included) and address every frame from its own base
         // (per workgroup or per wave), so one launch set takes the batch whatever its span.
@@ -342,6 +344,7 @@ int run_batch_impl(const tts_plan *p, const void *src, size_t src_pitch, const i
         const uint64_t sspan = uint64_t(n - 1) * src_pitch + sbytes, dspan = uint64_t(n - 1) * dst_pitch + dbytes;
         addr.wave_base = sspan > kMaxSpan || dspan > kMaxSpan || p->knobs.wave_base;
         const int rc = launch_all(pp, s, d, n, sstride, pds, sspan, dspan, addr, st);
+        if (rc == TTS_ERR_UNSUPPORTED && use_scratch) { use_scratch = false; goto rgb_generic; }   // (whatever the pass wrote, the generic kernel overwrites)
         if (rc) return rc;
     }
     if (use_scratch) return tts::rgb_scratch_convert(p->rgb, static_cast<uint8_t *>(dst), dst_pitch, n_frames, st);
@@ -363,38 +366,49 @@ int run_rgbin_frames(const tts_plan *p, const tts_frame *src, const tts_frame *d
         if (dst[i].stride[1] != dst[i].stride[2]) return TTS_ERR_UNSUPPORTED;
     }
     if (const int drc = check_device(p)) return drc;
-    int f0 = 0;
-    while (f0 < n_frames) {
-        uintptr_t smin = UINTPTR_MAX, dmin = UINTPTR_MAX, smax = 0, dmax = 0;
-        int n = 0;
-        while (f0 + n < n_frames && n < kMaxTableFrames) {
-            const tts_frame &sf = src[f0 + n], &df = dst[f0 + n];
-            if (n && (sf.stride[0] != src[f0].stride[0] || df.stride[0] != dst[f0].stride[0] || df.stride[1] != dst[f0].stride[1])) break;
-            uintptr_t a = std::min(smin, uintptr_t(sf.plane[0])), b = std::max(smax, uintptr_t(sf.plane[0]) + size_t(g.in_h - 1) * size_t(sf.stride[0]) + size_t(g.in_w) * 3);
-            uintptr_t c2 = dmin, e = dmax;
-            for (int k = 0; k < 3; ++k) {
-                const int ci = k ? 1 : 0;
-                c2 = std::min(c2, uintptr_t(df.plane[k]));
-                e = std::max(e, uintptr_t(df.plane[k]) + size_t(df.stride[k]) * (ceil_shift(g.out_h, ci) - 1) + ceil_shift(g.out_w, ci));
+    // `only` < 0: the three destination planes of a frame share one base; `only` = k: plane k alone (planes that lie
+    // more than kMaxSpan apart -- every plane its own far-away allocation -- go one plane class of work at a time)
+    auto run_groups = [&](int only) -> int {
+        const int k0 = only < 0 ? 0 : only, k1 = only < 0 ? 3 : only + 1;
+        int f0 = 0;
+        while (f0 < n_frames) {
+            uintptr_t smin = UINTPTR_MAX, dmin = UINTPTR_MAX, smax = 0, dmax = 0;
+            int n = 0;
+            while (f0 + n < n_frames && n < kMaxTableFrames) {
+                const tts_frame &sf = src[f0 + n], &df = dst[f0 + n];
+                if (n && (sf.stride[0] != src[f0].stride[0] || df.stride[0] != dst[f0].stride[0] || df.stride[1] != dst[f0].stride[1])) break;
+                const uintptr_t a = std::min(smin, uintptr_t(sf.plane[0]));
+                const uintptr_t b = std::max(smax, uintptr_t(sf.plane[0]) + size_t(g.in_h - 1) * size_t(sf.stride[0]) + size_t(g.in_w) * 3);
+                uintptr_t c2 = dmin, e = dmax;
+                for (int k = k0; k < k1; ++k) {
+                    const int ci = k ? 1 : 0;
+                    c2 = std::min(c2, uintptr_t(df.plane[k]));
+                    e = std::max(e, uintptr_t(df.plane[k]) + size_t(df.stride[k]) * (ceil_shift(g.out_h, ci) - 1) + ceil_shift(g.out_w, ci));
+                }
+                if (b - a > kMaxSpan || e - c2 > kMaxSpan) break;
+                smin = a; smax = b; dmin = c2; dmax = e;
+                ++n;
             }
-            if (b - a > kMaxSpan || e - c2 > kMaxSpan) break;
-            smin = a; smax = b; dmin = c2; dmax = e;
-            ++n;
+            if (n == 0) return TTS_ERR_UNSUPPORTED;
+            FrameAddr addr{};
+            addr.use_table = 1;
+            for (int i = 0; i < n; ++i) {
+                addr.src_tab[0][i] = uint32_t(uintptr_t(src[f0 + i].plane[0]) - smin);
+                for (int k = k0; k < k1; ++k) addr.dst_tab[k][i] = uint32_t(uintptr_t(dst[f0 + i].plane[k]) - dmin);
+            }
+            const int dstride[2] = {dst[f0].stride[0], dst[f0].stride[1]};
+            const int rc = tts::rgbin_launch(p->rgbin, reinterpret_cast<const uint8_t *>(smin), reinterpret_cast<uint8_t *>(dmin), n,
+                                             src[f0].stride[0], dstride, addr, static_cast<hipStream_t>(hip_stream), only);
+            if (rc) return rc;
+            f0 += n;
         }
-        if (n == 0) { g_last_error = "rgb24 in: the planes of a frame must lie within 4 GiB of each other"; return TTS_ERR_UNSUPPORTED; }
-        FrameAddr addr{};
-        addr.use_table = 1;
-        for (int i = 0; i < n; ++i) {
-            addr.src_tab[0][i] = uint32_t(uintptr_t(src[f0 + i].plane[0]) - smin);
-            for (int k = 0; k < 3; ++k) addr.dst_tab[k][i] = uint32_t(uintptr_t(dst[f0 + i].plane[k]) - dmin);
-        }
-        const int dstride[2] = {dst[f0].stride[0], dst[f0].stride[1]};
-        const int rc = tts::rgbin_launch(p->rgbin, reinterpret_cast<const uint8_t *>(smin), reinterpret_cast<uint8_t *>(dmin), n,
-                                         src[f0].stride[0], dstride, addr, static_cast<hipStream_t>(hip_stream));
-        if (rc) return rc;
-        f0 += n;
-    }
-    return TTS_OK;
+        return TTS_OK;
+    };
+    int rc = p->knobs.planewise ? TTS_ERR_UNSUPPORTED : run_groups(-1);   // (TTS_PLANEWISE: tests force the fallback)
+    if (rc == TTS_ERR_UNSUPPORTED)                       // (a repeat of frames already done is harmless: same inputs, same outputs)
+        for (int k = 0; k < 3 && (rc == TTS_ERR_UNSUPPORTED || rc == TTS_OK); ++k) rc = run_groups(k);
+    if (rc == TTS_ERR_UNSUPPORTED) g_last_error = "rgb24 in: a plane does not fit 32-bit offsets from a common base";
+    return rc;
 }
 
 }  // namespace

@@ -813,6 +813,8 @@ int launch_all(const tts_plan *p, const uint8_t *src, uint8_t *dst, int n, const
         const ClassPlan &c = p->cls[ci];
         if (c.kind == 0) to_generic[ci] = true;
         if (c.kind == 2 && (src_span < 4096u || (addr.use_table && (c.segs[0].nseg < 2 || c.segs[0].spans_plane || c.src_w < 48 || c.src_h < 32)))) to_generic[ci] = true;
+        // (the scratch plan of the packed-RGB thumbnail path: only the column walk stores int16 luma; the caller falls back)
+        if (p->y16 && (c.kind != 2 || to_generic[ci]) && active(ci)) { g_last_error = "scratch pass needs the column walk"; return TTS_ERR_UNSUPPORTED; }
     }
     RangeStep range{};
     if (p->g.out_range != TTS_RANGE_KEEP) {

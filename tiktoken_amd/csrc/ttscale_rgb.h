@@ -43,7 +43,8 @@ void rgbin_plan_destroy(RgbInPlan *p);
 const char *rgbin_plan_kernel_name(const RgbInPlan *p);
 // frames [0, n): addr.src_plane[0] = the pre-cropped origin inside a source frame, addr.dst_plane[k] = the
 // origin of canvas plane k inside an output frame (packed mode only); src_stride = bytes between RGB rows
+// only_plane >= 0: that destination plane alone (dst and the tables then belong to it)
 int rgbin_launch(const RgbInPlan *p, const uint8_t *src, uint8_t *dst, int n, int src_stride, const int dst_stride[2],
-                 const FrameAddr &addr, hipStream_t st);
+                 const FrameAddr &addr, hipStream_t st, int only_plane = -1);
 
 }  // namespace tts

@@ -688,6 +688,7 @@ struct RgbInArgs {
     int32_t fill[3];
     int32_t frame0;
     int32_t coef[9];                   // ry gy by, ru gu bu, rv gv bv
+    int32_t  only_plane;               // >= 0: the launch produces this destination plane alone
     uint32_t src_origin, src_extent;   // bytes from a frame's first byte to the pre-cropped origin / to one past its last byte
     FrameAddr addr;
 };
@@ -708,6 +709,7 @@ __device__ __forceinline__ void rgbin_frame(const RgbInArgs &a, int frame, int p
 __global__ __launch_bounds__(kBlock) void rgbin_generic_kernel(const RgbInArgs a)
 {
     const int plane = int(blockIdx.z) % 3, frame = a.frame0 + int(blockIdx.z) / 3;
+    if (a.only_plane >= 0 && plane != a.only_plane) return;
     const int ci = plane ? 1 : 0;
     const int x = int(blockIdx.x) * 64 + int(threadIdx.x & 63);
     const int y = int(blockIdx.y) * 4 + int(threadIdx.x >> 6);
@@ -771,6 +773,7 @@ __global__ __launch_bounds__(kBlock) void rgbin_tile_kernel(const RgbInTileArgs 
     extern __shared__ __attribute__((aligned(16))) int16_t rgbin_lds[];
     const RgbInArgs &a = t.g;
     const int plane = int(blockIdx.z) % 3, frame = a.frame0 + int(blockIdx.z) / 3;
+    if (a.only_plane >= 0 && plane != a.only_plane) return;        // (whole workgroups)
     const int ci = plane ? 1 : 0;
     if (int(blockIdx.y) >= t.tiles_y[ci]) return;                  // (the grid is sized for the luma class; whole workgroups leave)
     const int x0 = int(blockIdx.x) * 64, y0 = int(blockIdx.y) * t.th[ci];
@@ -1340,7 +1343,7 @@ void rgbin_plan_destroy(RgbInPlan *p)
 const char *rgbin_plan_kernel_name(const RgbInPlan *p) { return p ? p->name : ""; }
 
 int rgbin_launch(const RgbInPlan *p, const uint8_t *src, uint8_t *dst, int n, int src_stride, const int dst_stride[2],
-                 const FrameAddr &addr, hipStream_t st)
+                 const FrameAddr &addr, hipStream_t st, int only_plane)
 {
     const tts_geom &g = p->g;
     RgbInArgs a{};
@@ -1355,6 +1358,7 @@ int rgbin_launch(const RgbInPlan *p, const uint8_t *src, uint8_t *dst, int n, in
         a.dst_stride[k] = dst_stride[k];
     }
     a.src_stride = src_stride;
+    a.only_plane = only_plane;
     a.src_origin = uint32_t(g.pre_y) * uint32_t(src_stride) + uint32_t(g.pre_x) * 3u;
     a.src_extent = uint32_t(size_t(g.in_h - 1) * size_t(src_stride) + size_t(g.in_w) * 3);
     a.fill[0] = g.fill_y; a.fill[1] = g.fill_u; a.fill[2] = g.fill_v;
