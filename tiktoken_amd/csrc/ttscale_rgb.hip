@@ -635,30 +635,44 @@ __global__ __launch_bounds__(kScratchThreads) void rgb_scratch_convert_kernel(co
     const int t = int(threadIdx.x);
     const int npix = a.pw * a.ph;
     const int cb = int(a.off_v - a.off_u) + a.cw * a.ph;           // chroma bytes, U first
-    for (int i = t; i < cb; i += kScratchThreads) uv[i] = fb[a.off_u + i];
+    const bool aligned = (reinterpret_cast<uintptr_t>(fb) & 3u) == 0;  // (workgroup-uniform; off_u is a multiple of 4)
+    if (aligned) {
+        const uint32_t *cs = reinterpret_cast<const uint32_t *>(fb + a.off_u);
+        for (int i = t; i < (cb >> 2); i += kScratchThreads) reinterpret_cast<uint32_t *>(uv)[i] = cs[i];
+        for (int i = (cb & ~3) + t; i < cb; i += kScratchThreads) uv[i] = fb[a.off_u + i];
+    } else {
+        for (int i = t; i < cb; i += kScratchThreads) uv[i] = fb[a.off_u + i];
+    }
     int yv[kScratchMaxPix / kScratchThreads];
 #pragma unroll
     for (int it = 0; it < kScratchMaxPix / kScratchThreads; ++it) {
         const int idx = it * kScratchThreads + t;                  // consecutive lanes, consecutive pixels
         int v = 0;
         if (idx < npix) {
-            const uint8_t *q = fb + 2 * size_t(idx);               // (a frame may start at an odd address: two byte loads)
-            v = int(int16_t(uint16_t(q[0]) | uint16_t(q[1]) << 8));
+            const uint8_t *q = fb + 2 * size_t(idx);
+            if (aligned) v = int(*reinterpret_cast<const int16_t *>(q));
+            else v = int(int16_t(uint16_t(q[0]) | uint16_t(q[1]) << 8));   // (a frame may start at an odd address)
         }
         yv[it] = v;
     }
     __syncthreads();                                               // every load of the workgroup has landed: the frame may be overwritten
     const int voff = int(a.off_v - a.off_u);
+    // pixel idx = it * 1024 + t: its row and column advance by constants from one iteration to the next (no division a pixel)
+    const int dy = kScratchThreads / a.pw, dx = kScratchThreads - dy * a.pw;
+    int y = t / a.pw, x = t - y * a.pw;
 #pragma unroll
     for (int it = 0; it < kScratchMaxPix / kScratchThreads; ++it) {
         const int idx = it * kScratchThreads + t;
         if (idx < npix) {
-            const int y = idx / a.pw, x = idx - y * a.pw;
             const int U = uv[y * a.cw + (x >> 1)], V = uv[voff + y * a.cw + (x >> 1)];
             int r, g, b;
             tts::rgb_pixel(a.coef, yv[it], U, V, r, g, b);
-            rgb_store_pixel(fb + size_t(y + a.py) * a.dst_stride + size_t(x + a.px) * a.bpp, a.bpp, a.swap, r, g, b);
+            uint8_t *d = fb + size_t(y + a.py) * a.dst_stride + size_t(x + a.px) * a.bpp;
+            if (a.bpp == 4 && aligned) *reinterpret_cast<uint32_t *>(d) = uint32_t(a.swap ? b : r) | uint32_t(g) << 8 | uint32_t(a.swap ? r : b) << 16 | 0xff000000u;
+            else rgb_store_pixel(d, a.bpp, a.swap, r, g, b);
         }
+        x += dx; y += dy;
+        if (x >= a.pw) { x -= a.pw; ++y; }
     }
     if (a.canvas_w != a.pw || a.canvas_h != a.ph) {                // the pad border
         for (int i = t; i < a.canvas_w * a.canvas_h; i += kScratchThreads) {
