@@ -86,6 +86,8 @@ SCRATCH_CASES = [
     ("scale=213:121", 1283, 721, "rgba"),              # odd picture: the planes only fit a 4-byte-a-pixel frame
     ("scale=214:120,crop=200:100:6:10", 1283, 721, "rgb24"),
     ("scale=96:54,pad=128:72:-1:-1:color=red", 640, 360, "rgb24"),
+    ("scale=1280:720", 3840, 2160, "rgb24"),           # no picture-size limit: rows are converted independently
+    ("scale=640:360", 1920, 1080, "bgra"),
 ]
 
 
@@ -111,6 +113,60 @@ def test_rgb_thumbnails_column_walk_and_in_place_conversion(tts, oracle, monkeyp
     assert bad.size == 0, "%s: %d bytes differ, first at %d (got %d want %d)" % (chain, bad.size, bad[0], a.ravel()[bad[0]], want.ravel()[bad[0]])
     src = synth.frames("impulse", iw, ih, 1)
     assert np.array_equal(fast.run_batch(torch.from_numpy(src).cuda()).cpu().numpy(), oracle.run_chain(fast.geom, src))
+
+
+def test_rgb_thumbnails_padded_rows(tts, oracle):
+    """The same path into rows with padding (tts_run_batch_strided): the scratch of a row lives in the bytes of its
+    own pixels, so the padding is never written."""
+    import torch
+    iw, ih, n = 1280, 720, 4
+    plan = tts.Plan.from_vf(THUMB + ",format=rgb24", iw, ih)
+    assert plan.kernel_name(0).endswith("+rgb_convert")
+    ow, oh = plan.out_size
+    src = synth.frames("random", iw, ih, n)
+    want = oracle.run_chain(plan.geom, src).reshape(n, oh, ow * 3)
+    dstride = ow * 3 + 11
+    d = torch.full((n, oh * dstride), 0xA5, dtype=torch.uint8, device="cuda")
+    plan.run_batch_strided(torch.from_numpy(src).cuda(), (iw, (iw + 1) // 2), d, (dstride, 0), n)
+    got = d.cpu().numpy().reshape(n, oh, dstride)
+    assert np.array_equal(got[:, :, : ow * 3], want) and (got[:, :, ow * 3:] == 0xA5).all()
+
+
+@pytest.mark.parametrize("vf,iw,ih,fmt", [(THUMB, 1280, 720, "rgb24"), (THUMB, 720, 1280, "bgra"), ("scale=40:30", 200, 150, "rgb24")])
+def test_rgb_thumbnails_through_frame_pointers(tts, oracle, vf, iw, ih, fmt):
+    """tts_run: every source plane and every RGB frame its own allocation, padded RGB rows.  (The last case has planes
+    too small for the column walk's per-frame-pointer mode: it must fall back, not break.)"""
+    import torch
+    n, pad = 4, 9
+    bpp = 4 if fmt.endswith("a") else 3
+    plan = tts.Plan.from_vf(vf + ",format=" + fmt, iw, ih)
+    ow, oh = plan.out_size
+    src = synth.frames("random", iw, ih, n)
+    want = oracle.run_chain(plan.geom, src).reshape(n, oh, ow * bpp)
+    cw = (iw + 1) // 2
+    # (a frame's planes are carved out of one allocation, in scrambled order with gaps: packed-RGB output wants the
+    # planes of a FRAME within 4 GiB of each other, which separate allocations do not promise)
+    outs, sp, dp, ss, ds = [], [], [], [], []
+    for i in range(n):
+        planes = synth.split(src[i], iw, ih)
+        sizes = [p.size for p in planes] + [oh * (ow * bpp + pad)]
+        arena = torch.full((sum(sizes) + 4 * 333,), 0x5A, dtype=torch.uint8, device="cuda")
+        offs, at = {}, 0
+        for k in (2, 3, 0, 1):
+            offs[k] = at + 333 - (i % 3)
+            at = offs[k] + sizes[k]
+        for k in range(3):
+            arena[offs[k]: offs[k] + sizes[k]] = torch.from_numpy(np.ascontiguousarray(planes[k]).ravel()).cuda()
+        outs.append((arena, offs[3], sizes[3]))
+        sp.append([arena.data_ptr() + offs[k] for k in range(3)]); dp.append([arena.data_ptr() + offs[3], 0, 0])
+        ss.append([iw, cw, cw]); ds.append([ow * bpp + pad, 0, 0])
+    plan.run_frames(sp, dp, ss, ds)
+    torch.cuda.synchronize()
+    for i in range(n):
+        arena, o, sz = outs[i]
+        got = arena[o: o + sz].cpu().numpy().reshape(oh, ow * bpp + pad)
+        assert np.array_equal(got[:, : ow * bpp], want[i]), (vf, fmt, i)
+        assert (got[:, ow * bpp:] == 0x5A).all(), "wrote into the stride padding"
 
 
 @pytest.mark.parametrize("vf,iw,ih,n", [("scale=20:12", 60, 40, 1), ("scale=20:12", 60, 40, 9), ("scale=16:10", 48, 30, 2), ("scale=24:16", 100, 64, 1)])

@@ -117,7 +117,7 @@ int tts_plan_create(const tts_geom *g, tts_plan **out)
         // every output row, luma unclipped) whose column walk writes into the RGB frame, converted in place.
         // Anything that does not qualify -- or whose classes do not both take the column walk -- stays with p->rgb.
         tts::RgbScratchLayout lay;
-        if (!p->knobs.no_rgb_scratch && tts::rgb_scratch_layout(*g, lay)) {
+        if (!p->knobs.no_rgb_scratch && tts::rgb_scratch_layout(*g, g->out_w * (g->out_fmt >= TTS_FMT_RGBA ? 4 : 3), lay)) {
             tts_plan *sp = new (std::nothrow) tts_plan();
             if (sp) {
                 tts_geom gp = *g;
@@ -292,7 +292,7 @@ int run_batch_impl(const tts_plan *p, const void *src, size_t src_pitch, const i
     hipStream_t st = static_cast<hipStream_t>(hip_stream);
     tts::RgbScratchLayout lay{};
     // (sources under 4 KiB go to the one-lane-per-sample kernel, which has no 16-bit store: not through the scratch pass)
-    bool use_scratch = p->rgb && p->scratch && dstride[0] == g.out_w * bpp && sbytes >= 4096 && tts::rgb_scratch_layout(g, lay);
+    bool use_scratch = p->rgb && p->scratch && sbytes >= 4096 && tts::rgb_scratch_layout(g, dstride[0], lay);
 rgb_generic:
     if (p->rgb && !use_scratch) {
         // The RGB kernels cover the whole canvas (borders included) and address every frame from its own base
@@ -347,7 +347,11 @@ rgb_generic:
         if (rc == TTS_ERR_UNSUPPORTED && use_scratch) { use_scratch = false; goto rgb_generic; }   // (whatever the pass wrote, the generic kernel overwrites)
         if (rc) return rc;
     }
-    if (use_scratch) return tts::rgb_scratch_convert(p->rgb, static_cast<uint8_t *>(dst), dst_pitch, n_frames, st);
+    if (use_scratch) {
+        FrameAddr ca{};
+        ca.dst_pitch = uint32_t(dst_pitch);
+        return tts::rgb_scratch_convert(p->rgb, static_cast<uint8_t *>(dst), dstride[0], n_frames, ca, st);
+    }
     return TTS_OK;
 }
 
@@ -502,6 +506,19 @@ int tts_run(const tts_plan *p, const tts_frame *src, const tts_frame *dst, int n
                     const size_t dof = size_t(uintptr_t(dst[f0 + i].plane[k]) - dmin);
                     addr.dst_tab[k][i] = bpp ? uint32_t(dof) : uint32_t(dof) + uint32_t(c.pad_y) * dstride[ci] + uint32_t(c.pad_x);
                 }
+            // packed-RGB shrinks: the planar pass of p->scratch into the frames' own rows, then the in-place conversion
+            // (see tts_plan); planes the column walk cannot stage through per-frame pointers fall back below
+            tts::RgbScratchLayout lay{};
+            if (p->rgb && p->scratch && only < 0 && tts::rgb_scratch_layout(g, dstride[0], lay)) {
+                FrameAddr sa = addr;
+                for (int i = 0; i < n; ++i)
+                    for (int k = 0; k < 3; ++k) sa.dst_tab[k][i] = addr.dst_tab[0][i] + lay.off[k];
+                const int pds[2] = {lay.stride[0], lay.stride[1]};
+                int rc = launch_all(p->scratch, reinterpret_cast<const uint8_t *>(smin), reinterpret_cast<uint8_t *>(dmin), n,
+                                    sstride, pds, uint32_t(smax - smin), uint32_t(dmax - dmin), sa, st, -1);
+                if (rc == TTS_OK) rc = tts::rgb_scratch_convert(p->rgb, reinterpret_cast<uint8_t *>(dmin), dstride[0], n, addr, st);
+                if (rc != TTS_ERR_UNSUPPORTED) { if (rc) return rc; f0 += n; continue; }
+            }
             const int rc = launch_all(p, reinterpret_cast<const uint8_t *>(smin), reinterpret_cast<uint8_t *>(dmin), n,
                                       sstride, dstride, uint32_t(smax - smin), uint32_t(dmax - dmin), addr, st, only);
             if (rc) return rc;

@@ -25,16 +25,16 @@ const char *rgb_plan_kernel_name(const RgbPlan *p);
 int rgb_launch(const RgbPlan *p, const uint8_t *src, uint8_t *dst, int n, const int src_stride[2], int dst_stride,
                uint64_t src_span, uint64_t dst_span, const FrameAddr &addr, hipStream_t st);
 
-// ---- packed-RGB thumbnails: planar column walk into the destination frame, converted in place -------------
-// Where the planar pass leaves its planes inside an RGB frame of the geometry: unclipped int16 luma (crop_w x
-// crop_h, rows 2 crop_w bytes apart), then U and V as bytes (ceil(crop_w / 2) x crop_h).  false: the geometry
-// does not qualify (conversion not inside the chain's scale, picture too large for one workgroup, planes that
-// do not fit the frame, a crop at an odd offset).
+// ---- packed-RGB shrinks: planar column walk into the destination frame, converted in place ---------------
+// Where the planar pass leaves its rows inside an RGB frame whose rows are dst_stride bytes apart (offsets from
+// the frame's canvas origin): picture row y holds, in the bytes its pixels will take, crop_w int16 of unclipped
+// luma, then ceil(crop_w / 2) bytes of U and of V.  false: the geometry does not qualify (conversion not inside
+// the chain's scale, a crop at an odd offset, an odd width at 3 bytes a pixel with no border to its right).
 struct RgbScratchLayout { uint32_t off[3]; int stride[2]; };
-bool rgb_scratch_layout(const tts_geom &g, RgbScratchLayout &out);
-// frames [0, n) of packed rows, dst_pitch bytes apart: one workgroup per frame reads the three planes (all of
-// them, before anything is written) and writes the canvas, border included.  Asynchronous on st.
-int rgb_scratch_convert(const RgbPlan *p, uint8_t *dst, size_t dst_pitch, int n, hipStream_t st);
+bool rgb_scratch_layout(const tts_geom &g, int dst_stride, RgbScratchLayout &out);
+// frames [0, n) addressed by addr's destination side (dst_plane[0] / dst_tab[0] = a frame's canvas origin): one
+// workgroup per canvas row reads the row's planes, then writes its pixels and border.  Asynchronous on st.
+int rgb_scratch_convert(const RgbPlan *p, uint8_t *dst, int dst_stride, int n, const FrameAddr &addr, hipStream_t st);
 
 // ---- packed rgb24 INPUT, yuv420p out (tts_geom.in_fmt == TTS_FMT_RGB24) ----------------------------------
 struct RgbInPlan;

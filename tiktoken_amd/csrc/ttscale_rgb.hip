@@ -607,80 +607,141 @@ __global__ __launch_bounds__(kBlock, 4) void rgb_strip_kernel(const uint8_t *__r
 #endif
 }
 
-// ---- packed-RGB thumbnails: in-place conversion of the planes the column walk left in the frame ------------
+// ---- packed-RGB shrinks: in-place conversion of the rows the column walk left in the frame ----------------
 // The many-tap shrinks of the reference's thumbnail chain (src/services/video.js:329-334 ends in an image
 // encoder) ran through rgb_generic_kernel at taps^2 multiply-adds per plane and pixel (29 k frames/s for
 // 1080p -> 320x180 -> rgb24).  Instead the planar column walk (column_lds_kernel, luma stored unclipped as
-// int16, chroma at ceil(w / 2) x h as the RGB-writing context computes it) writes its three planes into the
-// destination frame itself -- 2 w h + 2 ceil(w / 2) h bytes, never more than the 3 w h the frame has -- and one
-// workgroup per frame turns them into pixels in place: every thread reads its share of all three planes (luma
-// into registers, chroma into LDS), the workgroup meets at a barrier, and only then is anything written.
+// int16, chroma at ceil(w / 2) x h as the RGB-writing context computes it) writes into the destination frame
+// itself, ROW BY ROW where the pixels of that row will stand: the w * bpp bytes of picture row y hold
+// [w int16 luma | ceil(w / 2) U | ceil(w / 2) V] -- 3 w bytes for an even w.  A row is then converted by one
+// workgroup that reads all of it (every thread its pixels' luma and chroma, into registers), meets at a
+// barrier, and only then writes: nothing outside the row is touched, so rows and frames are independent
+// workgroups, the picture may be any size, rows may be padded, and no memory beyond the output frame is used.
 struct RgbScratchArgs {
     uint8_t *dst;
-    uint64_t dst_pitch;
     int32_t  pw, ph, cw;               // picture, chroma columns
     int32_t  canvas_w, canvas_h, px, py, dst_stride;
-    uint32_t off_u, off_v;             // byte offsets of the chroma planes inside a frame (luma at 0)
     int32_t  bpp, swap;
     int32_t  border[3];
+    int32_t  frame0;
+    int32_t  tpr;                      // threads per canvas row: 64, 128 or 256
     RgbCoef  coef;
+    FrameAddr addr;                    // dst side: frame f's canvas origin (dst_plane[0] / dst_tab[0])
 };
 
-constexpr int kScratchThreads = 1024, kScratchMaxPix = 65536, kScratchMaxChroma = 65536;
+constexpr int kScratchThreads = 256, kScratchMaxPerThread = 64;     // pictures up to 16,384 columns
 
 __global__ __launch_bounds__(kScratchThreads) void rgb_scratch_convert_kernel(const RgbScratchArgs a)
 {
-    __shared__ __attribute__((aligned(16))) uint8_t uv[kScratchMaxChroma];
-    uint8_t *fb = a.dst + size_t(blockIdx.x) * a.dst_pitch;
-    const int t = int(threadIdx.x);
-    const int npix = a.pw * a.ph;
-    const int cb = int(a.off_v - a.off_u) + a.cw * a.ph;           // chroma bytes, U first
-    const bool aligned = (reinterpret_cast<uintptr_t>(fb) & 3u) == 0;  // (workgroup-uniform; off_u is a multiple of 4)
-    if (aligned) {
-        const uint32_t *cs = reinterpret_cast<const uint32_t *>(fb + a.off_u);
-        for (int i = t; i < (cb >> 2); i += kScratchThreads) reinterpret_cast<uint32_t *>(uv)[i] = cs[i];
-        for (int i = (cb & ~3) + t; i < cb; i += kScratchThreads) uv[i] = fb[a.off_u + i];
-    } else {
-        for (int i = t; i < cb; i += kScratchThreads) uv[i] = fb[a.off_u + i];
-    }
-    int yv[kScratchMaxPix / kScratchThreads];
+    // a.tpr threads (64, 128 or 256: the host picks by the picture's width) share a canvas row, so a workgroup takes
+    // 256 / tpr rows (one tiny workgroup per 320-pixel row was twice as slow as one per four rows)
+    const int frame = a.frame0 + int(blockIdx.y), t = int(threadIdx.x) & (a.tpr - 1);
+    uint8_t *fb = a.dst + (a.addr.use_table ? size_t(a.addr.dst_tab[0][frame]) : size_t(frame) * a.addr.dst_pitch + a.addr.dst_plane[0]);
+    const int cy = int(blockIdx.x) * (kScratchThreads / a.tpr) + int(threadIdx.x) / a.tpr;   // canvas row
+    const bool row_ok = cy < a.canvas_h;
+    uint8_t *crow = fb + size_t(row_ok ? cy : 0) * a.dst_stride;
+    const bool in_rows = row_ok && cy >= a.py && cy < a.py + a.ph;
+    uint8_t *prow = crow + size_t(a.px) * a.bpp;                   // the picture's bytes of this row: its scratch, then its pixels
+    const uint8_t *urow = prow + 2 * size_t(a.pw), *vrow = urow + a.cw;
+    const bool aligned = (reinterpret_cast<uintptr_t>(prow) & 1u) == 0;
+    int yv[kScratchMaxPerThread], uv[kScratchMaxPerThread];
 #pragma unroll
-    for (int it = 0; it < kScratchMaxPix / kScratchThreads; ++it) {
-        const int idx = it * kScratchThreads + t;                  // consecutive lanes, consecutive pixels
-        int v = 0;
-        if (idx < npix) {
-            const uint8_t *q = fb + 2 * size_t(idx);
-            if (aligned) v = int(*reinterpret_cast<const int16_t *>(q));
-            else v = int(int16_t(uint16_t(q[0]) | uint16_t(q[1]) << 8));   // (a frame may start at an odd address)
+    for (int it = 0; it < kScratchMaxPerThread; ++it) {
+        if (it * a.tpr >= a.pw) break;                             // (uniform)
+        const int x = it * a.tpr + t;                              // consecutive lanes, consecutive pixels
+        int v = 0, c = 0;
+        if (in_rows && x < a.pw) {
+            const uint8_t *q = prow + 2 * size_t(x);
+            v = aligned ? int(*reinterpret_cast<const int16_t *>(q)) : int(int16_t(uint16_t(q[0]) | uint16_t(q[1]) << 8));
+            c = int(urow[x >> 1]) | int(vrow[x >> 1]) << 8;
         }
-        yv[it] = v;
+        yv[it] = v; uv[it] = c;
     }
-    __syncthreads();                                               // every load of the workgroup has landed: the frame may be overwritten
-    const int voff = int(a.off_v - a.off_u);
-    // pixel idx = it * 1024 + t: its row and column advance by constants from one iteration to the next (no division a pixel)
-    const int dy = kScratchThreads / a.pw, dx = kScratchThreads - dy * a.pw;
-    int y = t / a.pw, x = t - y * a.pw;
+    __syncthreads();                                               // the workgroup's rows sit in registers: they may be overwritten
+    if (!row_ok) return;
+    if (in_rows) {
 #pragma unroll
-    for (int it = 0; it < kScratchMaxPix / kScratchThreads; ++it) {
-        const int idx = it * kScratchThreads + t;
-        if (idx < npix) {
-            const int U = uv[y * a.cw + (x >> 1)], V = uv[voff + y * a.cw + (x >> 1)];
-            int r, g, b;
-            tts::rgb_pixel(a.coef, yv[it], U, V, r, g, b);
-            uint8_t *d = fb + size_t(y + a.py) * a.dst_stride + size_t(x + a.px) * a.bpp;
-            if (a.bpp == 4 && aligned) *reinterpret_cast<uint32_t *>(d) = uint32_t(a.swap ? b : r) | uint32_t(g) << 8 | uint32_t(a.swap ? r : b) << 16 | 0xff000000u;
-            else rgb_store_pixel(d, a.bpp, a.swap, r, g, b);
-        }
-        x += dx; y += dy;
-        if (x >= a.pw) { x -= a.pw; ++y; }
-    }
-    if (a.canvas_w != a.pw || a.canvas_h != a.ph) {                // the pad border
-        for (int i = t; i < a.canvas_w * a.canvas_h; i += kScratchThreads) {
-            const int y = i / a.canvas_w, x = i - y * a.canvas_w;
-            if (y >= a.py && y < a.py + a.ph && x >= a.px && x < a.px + a.pw) continue;
-            rgb_store_pixel(fb + size_t(y) * a.dst_stride + size_t(x) * a.bpp, a.bpp, a.swap, a.border[0], a.border[1], a.border[2]);
+        for (int it = 0; it < kScratchMaxPerThread; ++it) {
+            if (it * a.tpr >= a.pw) break;
+            const int x = it * a.tpr + t;
+            if (x < a.pw) {
+                int r, g, b;
+                tts::rgb_pixel(a.coef, yv[it], uv[it] & 255, uv[it] >> 8, r, g, b);
+                uint8_t *d = prow + size_t(x) * a.bpp;
+                if (a.bpp == 4 && (reinterpret_cast<uintptr_t>(prow) & 3u) == 0)
+                    *reinterpret_cast<uint32_t *>(d) = uint32_t(a.swap ? b : r) | uint32_t(g) << 8 | uint32_t(a.swap ? r : b) << 16 | 0xff000000u;
+                else rgb_store_pixel(d, a.bpp, a.swap, r, g, b);
+            }
         }
     }
+    // the pad border of this canvas row
+    if (a.canvas_w != a.pw || !in_rows)
+        for (int x = t; x < a.canvas_w; x += a.tpr)
+            if (!in_rows || x < a.px || x >= a.px + a.pw) rgb_store_pixel(crow + size_t(x) * a.bpp, a.bpp, a.swap, a.border[0], a.border[1], a.border[2]);
+}
+
+// The same for rows whose picture bytes start on a dword and hold a multiple of four pixels (the host checks:
+// the thumbnail chain does): a thread takes FOUR adjacent pixels -- 8 bytes of luma, 2 + 2 of chroma in, 12 or 16
+// bytes of pixels out, as dwords -- instead of one pixel through byte and halfword accesses, which kept the
+// texture addresser busier than the memory (82 -> 3x fewer memory instructions).
+__global__ __launch_bounds__(kScratchThreads) void rgb_scratch_convert4_kernel(const RgbScratchArgs a)
+{
+    const int frame = a.frame0 + int(blockIdx.y), t = int(threadIdx.x) & (a.tpr - 1);
+    uint8_t *fb = a.dst + size_t(frame) * a.addr.dst_pitch + a.addr.dst_plane[0];
+    const int cy = int(blockIdx.x) * (kScratchThreads / a.tpr) + int(threadIdx.x) / a.tpr;   // canvas row
+    const bool row_ok = cy < a.canvas_h;
+    uint8_t *crow = fb + size_t(row_ok ? cy : 0) * a.dst_stride;
+    const bool in_rows = row_ok && cy >= a.py && cy < a.py + a.ph;
+    uint8_t *prow = crow + size_t(a.px) * a.bpp;
+    const uint8_t *urow = prow + 2 * size_t(a.pw), *vrow = urow + a.cw;
+    const int quads = a.pw >> 2;
+    constexpr int kIters = kScratchMaxPerThread / 4;
+    uint32_t y01[kIters], y23[kIters], uv[kIters];
+#pragma unroll
+    for (int it = 0; it < kIters; ++it) {
+        if (it * a.tpr >= quads) break;                            // (uniform)
+        const int q = it * a.tpr + t;
+        uint32_t l0 = 0, l1 = 0, c = 0;
+        if (in_rows && q < quads) {
+            const uint32_t *yp = reinterpret_cast<const uint32_t *>(prow + 8 * size_t(q));
+            l0 = yp[0]; l1 = yp[1];
+            c = uint32_t(*reinterpret_cast<const uint16_t *>(urow + 2 * size_t(q))) | uint32_t(*reinterpret_cast<const uint16_t *>(vrow + 2 * size_t(q))) << 16;
+        }
+        y01[it] = l0; y23[it] = l1; uv[it] = c;
+    }
+    __syncthreads();                                               // the workgroup's rows sit in registers: they may be overwritten
+    if (!row_ok) return;
+    if (in_rows) {
+#pragma unroll
+        for (int it = 0; it < kIters; ++it) {
+            if (it * a.tpr >= quads) break;
+            const int q = it * a.tpr + t;
+            if (q < quads) {
+                int r[4], g[4], b[4];
+#pragma unroll
+                for (int i = 0; i < 4; ++i) {
+                    const uint32_t yw = i < 2 ? y01[it] : y23[it];
+                    const int Y = int(int16_t(i & 1 ? yw >> 16 : yw & 0xffffu));
+                    const int U = int((uv[it] >> (8 * (i >> 1))) & 255u), V = int((uv[it] >> (16 + 8 * (i >> 1))) & 255u);
+                    tts::rgb_pixel(a.coef, Y, U, V, r[i], g[i], b[i]);
+                    if (a.swap) { const int s = r[i]; r[i] = b[i]; b[i] = s; }
+                }
+                if (a.bpp == 4) {
+                    uint32_t *d = reinterpret_cast<uint32_t *>(prow + 16 * size_t(q));
+#pragma unroll
+                    for (int i = 0; i < 4; ++i) d[i] = uint32_t(r[i]) | uint32_t(g[i]) << 8 | uint32_t(b[i]) << 16 | 0xff000000u;
+                } else {
+                    uint32_t *d = reinterpret_cast<uint32_t *>(prow + 12 * size_t(q));
+                    d[0] = uint32_t(r[0]) | uint32_t(g[0]) << 8 | uint32_t(b[0]) << 16 | uint32_t(r[1]) << 24;
+                    d[1] = uint32_t(g[1]) | uint32_t(b[1]) << 8 | uint32_t(r[2]) << 16 | uint32_t(g[2]) << 24;
+                    d[2] = uint32_t(b[2]) | uint32_t(r[3]) << 8 | uint32_t(g[3]) << 16 | uint32_t(b[3]) << 24;
+                }
+            }
+        }
+    }
+    if (a.canvas_w != a.pw || !in_rows)
+        for (int x = t; x < a.canvas_w; x += a.tpr)
+            if (!in_rows || x < a.px || x >= a.px + a.pw) rgb_store_pixel(crow + size_t(x) * a.bpp, a.bpp, a.swap, a.border[0], a.border[1], a.border[2]);
 }
 
 // ---- packed rgb24 in, yuv420p out: any tap counts, one lane per output sample ---------------------------
@@ -1230,31 +1291,44 @@ int rgb_launch(const RgbPlan *p, const uint8_t *src, uint8_t *dst, int n, const 
 
 namespace tts {
 
-bool rgb_scratch_layout(const tts_geom &g, RgbScratchLayout &out)
+bool rgb_scratch_layout(const tts_geom &g, int dst_stride, RgbScratchLayout &out)
 {
     if (g.out_fmt == TTS_FMT_YUV420P || g.rgb_stage != TTS_RGB_AT_SCALE || !g.do_scale || ((g.crop_x | g.crop_y) & 1)) return false;
-    const int pw = g.crop_w, ph = g.crop_h, cw = (pw + 1) >> 1, bpp = g.out_fmt >= TTS_FMT_RGBA ? 4 : 3;
-    if (int64_t(pw) * ph > kScratchMaxPix) return false;
-    auto align4 = [](uint32_t v) { return (v + 3u) & ~3u; };
-    out.off[0] = 0; out.off[1] = align4(2u * uint32_t(pw) * uint32_t(ph)); out.off[2] = out.off[1] + align4(uint32_t(cw) * uint32_t(ph));
-    out.stride[0] = 2 * pw; out.stride[1] = cw;
-    if (out.off[2] - out.off[1] + uint32_t(cw) * uint32_t(ph) > uint32_t(kScratchMaxChroma)) return false;
-    return uint64_t(out.off[2]) + uint64_t(cw) * ph <= uint64_t(g.out_w) * g.out_h * bpp;       // the planes fit the frame they are written into
+    const int pw = g.crop_w, cw = (pw + 1) >> 1, bpp = g.out_fmt >= TTS_FMT_RGBA ? 4 : 3;
+    // (an odd width at 3 bytes a pixel is one byte short: it may borrow from the border pixels to its right in the
+    // same canvas row, which the row's workgroup writes after its barrier like everything else)
+    const int right = g.do_pad ? g.out_w - g.pad_x - pw : 0;
+    if (2 * pw + 2 * cw > (pw + right) * bpp || pw > kScratchThreads * kScratchMaxPerThread) return false;
+    const uint32_t origin = uint32_t(g.do_pad ? g.pad_y : 0) * uint32_t(dst_stride) + uint32_t(g.do_pad ? g.pad_x : 0) * uint32_t(bpp);
+    out.off[0] = origin; out.off[1] = origin + 2u * uint32_t(pw); out.off[2] = out.off[1] + uint32_t(cw);
+    out.stride[0] = out.stride[1] = dst_stride;                    // every plane has one row per canvas row
+    return true;
 }
 
-int rgb_scratch_convert(const RgbPlan *p, uint8_t *dst, size_t dst_pitch, int n, hipStream_t st)
+// frames [0, n): addr.dst_plane[0] / dst_tab[0] = a frame's canvas origin
+int rgb_scratch_convert(const RgbPlan *p, uint8_t *dst, int dst_stride, int n, const FrameAddr &addr, hipStream_t st)
 {
-    RgbScratchLayout L;
-    if (!rgb_scratch_layout(p->g, L)) { set_last_error("rgb_scratch_convert: geometry does not qualify"); return TTS_ERR_PROCESSING_FAILED; }
     RgbScratchArgs a{};
-    a.dst = dst; a.dst_pitch = dst_pitch;
+    a.dst = dst;
     a.pw = p->pw; a.ph = p->ph; a.cw = (p->pw + 1) >> 1;
-    a.canvas_w = p->g.out_w; a.canvas_h = p->g.out_h; a.px = p->px; a.py = p->py; a.dst_stride = p->g.out_w * p->bpp;
-    a.off_u = L.off[1]; a.off_v = L.off[2];
+    a.canvas_w = p->g.out_w; a.canvas_h = p->g.out_h; a.px = p->px; a.py = p->py; a.dst_stride = dst_stride;
     a.bpp = p->bpp; a.swap = p->swap ? 1 : 0;
     for (int i = 0; i < 3; ++i) a.border[i] = p->border[i];
     a.coef = p->coef;
-    return launch_rgb("rgb_scratch_convert_kernel", rgb_scratch_convert_kernel, dim3(unsigned(n)), dim3(kScratchThreads), 0, st, a);
+    a.addr = addr;
+    // four pixels a thread through dword accesses where every picture row starts on a dword and holds whole quads
+    const bool quad = !addr.use_table && p->pw % 4 == 0 && (reinterpret_cast<uintptr_t>(dst) & 3u) == 0 && addr.dst_pitch % 4 == 0 &&
+                      addr.dst_plane[0] % 4 == 0 && dst_stride % 4 == 0 && (p->px * p->bpp) % 4 == 0;
+    const int units = quad ? p->pw / 4 : p->pw;                   // per row; about two quads / six pixels a thread on narrow pictures
+    a.tpr = units <= 64 * (quad ? 2 : 6) ? 64 : units <= 128 * (quad ? 2 : 6) ? 128 : 256;
+    const int rows_per_wg = kScratchThreads / a.tpr;
+    int rc = TTS_OK;
+    for (int f0 = 0; f0 < n && !rc; f0 += 65535) {               // grid.y = frames
+        a.frame0 = f0;
+        rc = launch_rgb("rgb_scratch_convert_kernel", quad ? rgb_scratch_convert4_kernel : rgb_scratch_convert_kernel,
+                        dim3(unsigned((p->g.out_h + rows_per_wg - 1) / rows_per_wg), unsigned(std::min(65535, n - f0))), dim3(kScratchThreads), 0, st, a);
+    }
+    return rc;
 }
 
 }  // namespace tts
