@@ -88,6 +88,9 @@ SCRATCH_CASES = [
     ("scale=96:54,pad=128:72:-1:-1:color=red", 640, 360, "rgb24"),
     ("scale=1280:720", 3840, 2160, "rgb24"),           # no picture-size limit: rows are converted independently
     ("scale=640:360", 1920, 1080, "bgra"),
+    ("scale=1280:720", 1920, 1080, "rgb24"),           # 1.5x: 6-7 taps -- the column walk at its smallest window (the strip kernels have no 16-bit store)
+    ("scale=720:1280", 1080, 1920, "bgra"),            # the web compress box (portrait.test.js:70-97) as pixels
+    ("scale=300:200", 400, 300, "rgb24"),
 ]
 
 

@@ -68,7 +68,7 @@ static int build_classes(tts_plan *p, const tts_geom &g, bool full_v)
 {
     std::vector<uint32_t> tab;
     int rc = TTS_OK;
-    for (int ci = 0; ci < 2 && rc == TTS_OK; ++ci) rc = build_class(g, ci, p->cls[ci], tab, 0, full_v && ci);
+    for (int ci = 0; ci < 2 && rc == TTS_OK; ++ci) rc = build_class(g, ci, p->cls[ci], tab, 0, full_v && ci, full_v);   // (full_v: a scratch plan)
     // Column walk: luma and chroma ratios differ by a rounding, so their tap counts may straddle an
     // instantiation boundary (720x1280 -> 101x180: 16 tap pairs luma, 14 chroma) and the chain would take two
     // launches.  The class with fewer is rebuilt with the other's window: a seventh more arithmetic on a third
@@ -78,11 +78,11 @@ static int build_classes(tts_plan *p, const tts_geom &g, bool full_v)
         const int lo = p->cls[0].NTP < p->cls[1].NTP ? 0 : 1, want = p->cls[1 - lo].NTP;
         free_class(p->cls[lo]);
         p->cls[lo] = ClassPlan();
-        rc = build_class(g, lo, p->cls[lo], tab, want, full_v && lo);
+        rc = build_class(g, lo, p->cls[lo], tab, want, full_v && lo, full_v);
         if (rc == TTS_OK && p->cls[lo].kind != 2) {         // (the wider window does not fit this class's rows: as it was)
             free_class(p->cls[lo]);
             p->cls[lo] = ClassPlan();
-            rc = build_class(g, lo, p->cls[lo], tab, 0, full_v && lo);
+            rc = build_class(g, lo, p->cls[lo], tab, 0, full_v && lo, full_v);
         }
     }
     if (rc == TTS_OK && !upload(p->d_tab, tab)) rc = TTS_ERR_INITIALIZATION_FAILED;
@@ -117,7 +117,7 @@ int tts_plan_create(const tts_geom *g, tts_plan **out)
         // every output row, luma unclipped) whose column walk writes into the RGB frame, converted in place.
         // Anything that does not qualify -- or whose classes do not both take the column walk -- stays with p->rgb.
         tts::RgbScratchLayout lay;
-        if (!p->knobs.no_rgb_scratch && tts::rgb_scratch_layout(*g, g->out_w * (g->out_fmt >= TTS_FMT_RGBA ? 4 : 3), lay)) {
+        if (!p->knobs.no_rgb_scratch && !tts::rgb_plan_is_strip(p->rgb) && tts::rgb_scratch_layout(*g, g->out_w * (g->out_fmt >= TTS_FMT_RGBA ? 4 : 3), lay)) {
             tts_plan *sp = new (std::nothrow) tts_plan();
             if (sp) {
                 tts_geom gp = *g;

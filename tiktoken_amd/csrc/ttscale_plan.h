@@ -283,7 +283,8 @@ uint32_t build_d4_tables(const ClassPlan &c, int NTP, int nc, const std::vector<
 // instantiation, i.e. one launch: see tts_plan_create)
 // full_v: the chroma class keeps every OUTPUT row (its source rows are still subsampled): what a swscale context
 // that writes packed RGB computes (chroma at ceil(w / 2) x h) -- the scratch planes of the RGB thumbnail path.
-int build_class(const tts_geom &g, int sub, ClassPlan &c, std::vector<uint32_t> &tab, int min_ntp = 0, bool full_v = false)
+// force_column: the column walk for few taps too (it is the kernel with the 16-bit luma store that plan needs).
+int build_class(const tts_geom &g, int sub, ClassPlan &c, std::vector<uint32_t> &tab, int min_ntp = 0, bool full_v = false, bool force_column = false)
 {
     c.sub = sub;
     const int vsub = full_v ? 0 : sub;                 // subsampling of the output rows
@@ -305,7 +306,7 @@ int build_class(const tts_geom &g, int sub, ClassPlan &c, std::vector<uint32_t> 
     const int HT = c.h.size, VT = c.v.size;
     const int LW = HT <= 4 ? 4 : 8;
     const int R = VT <= 4 ? 4 : VT <= 6 ? 6 : 8;
-    const bool strip_ok = HT <= 8 && VT <= 8 && c.src_w >= LW && monotone(c.v.pos) &&
+    const bool strip_ok = !force_column && HT <= 8 && VT <= 8 && c.src_w >= LW && monotone(c.v.pos) &&
                           !env_int("TTS_FORCE_GENERIC", 0);
     if (!strip_ok) {
         // Many taps: the column walk, if the taps fit its windows and ring and the runs fit its slot.

@@ -1204,6 +1204,7 @@ void rgb_plan_destroy(RgbPlan *p)
 }
 
 const char *rgb_plan_kernel_name(const RgbPlan *p) { return p ? p->name : ""; }
+bool rgb_plan_is_strip(const RgbPlan *p) { return p && p->strip_ok; }
 
 int rgb_launch(const RgbPlan *p, const uint8_t *src, uint8_t *dst, int n, const int src_stride[2], int dst_stride,
                uint64_t src_span, uint64_t dst_span, const FrameAddr &addr, hipStream_t st)
