@@ -88,10 +88,39 @@ SCRATCH_CASES = [
     ("scale=96:54,pad=128:72:-1:-1:color=red", 640, 360, "rgb24"),
     ("scale=1280:720", 3840, 2160, "rgb24"),           # no picture-size limit: rows are converted independently
     ("scale=640:360", 1920, 1080, "bgra"),
-    ("scale=1280:720", 1920, 1080, "rgb24"),           # 1.5x: 6-7 taps -- the column walk at its smallest window (the strip kernels have no 16-bit store)
+    ("scale=1280:720", 1920, 1080, "rgb24"),           # 1.5x: 6-7 taps -- the grouped-window strip kernel with the 16-bit luma store
     ("scale=720:1280", 1080, 1920, "bgra"),            # the web compress box (portrait.test.js:70-97) as pixels
     ("scale=300:200", 400, 300, "rgb24"),
 ]
+
+
+STRIP16_CASES = [
+    ("scale=1280:720", 1920, 1080, "rgb24"),           # 1.5x: four columns per 12-byte window
+    ("scale=720:1280", 1080, 1920, "bgra"),
+    ("scale=1600:900", 1920, 1080, "rgb24"),           # 1.2x: 5-6 taps
+    ("scale=1120:630", 1920, 1080, "bgr24"),           # 1.71x: 7-8 taps, two columns per window
+    ("scale=1920:1080", 3840, 2160, "rgb24"),          # 2x: 8 taps, two DMAs a row, four rows in flight
+    ("scale=1100:1000", 1920, 1080, "rgba"),           # 1.75x across, 1.08x down: 8-byte windows with a 6-row ring
+    ("scale=1700:600,crop=1500:500:100:50", 1920, 1080, "rgb24"),
+]
+
+
+@pytest.mark.parametrize("vf,iw,ih,fmt", STRIP16_CASES)
+def test_rgb_small_shrinks_strip_kernel_with_16_bit_luma(tts, oracle, vf, iw, ih, fmt):
+    """5-8 taps an axis: the scratch planes come from the LDS strip kernels (their Y16 instantiations) instead of the
+    column walk; bytes as the oracle's."""
+    import torch
+    chain = vf + ",format=" + fmt
+    fast = tts.Plan.from_vf(chain, iw, ih)
+    name = fast.kernel_name(0)
+    assert name.startswith("strip_lds") and name.endswith("+rgb_convert"), name
+    n = 1 if iw * ih > 4_000_000 else 3
+    for kind in ("random", "impulse"):
+        src = synth.frames(kind, iw, ih, n)
+        got = fast.run_batch(torch.from_numpy(src).cuda()).cpu().numpy()
+        want = oracle.run_chain(fast.geom, src)
+        bad = np.flatnonzero(got != want)
+        assert bad.size == 0, "%s %s: %d bytes differ, first at %d" % (chain, kind, bad.size, bad[0])
 
 
 @pytest.mark.parametrize("vf,iw,ih,fmt", SCRATCH_CASES)

@@ -64,11 +64,11 @@ int tts_parse_vf_fmt(const char *vf, int iw, int ih, int in_fmt, tts_geom *out)
 }
 
 // The two plane classes of a planar plan and their table buffer.  full_v: see build_class.
-static int build_classes(tts_plan *p, const tts_geom &g, bool full_v)
+static int build_classes(tts_plan *p, const tts_geom &g, bool full_v, bool force_column = false)
 {
     std::vector<uint32_t> tab;
     int rc = TTS_OK;
-    for (int ci = 0; ci < 2 && rc == TTS_OK; ++ci) rc = build_class(g, ci, p->cls[ci], tab, 0, full_v && ci, full_v);   // (full_v: a scratch plan)
+    for (int ci = 0; ci < 2 && rc == TTS_OK; ++ci) rc = build_class(g, ci, p->cls[ci], tab, 0, full_v && ci, force_column);   // (full_v: a scratch plan)
     // Column walk: luma and chroma ratios differ by a rounding, so their tap counts may straddle an
     // instantiation boundary (720x1280 -> 101x180: 16 tap pairs luma, 14 chroma) and the chain would take two
     // launches.  The class with fewer is rebuilt with the other's window: a seventh more arithmetic on a third
@@ -78,11 +78,11 @@ static int build_classes(tts_plan *p, const tts_geom &g, bool full_v)
         const int lo = p->cls[0].NTP < p->cls[1].NTP ? 0 : 1, want = p->cls[1 - lo].NTP;
         free_class(p->cls[lo]);
         p->cls[lo] = ClassPlan();
-        rc = build_class(g, lo, p->cls[lo], tab, want, full_v && lo, full_v);
+        rc = build_class(g, lo, p->cls[lo], tab, want, full_v && lo, force_column);
         if (rc == TTS_OK && p->cls[lo].kind != 2) {         // (the wider window does not fit this class's rows: as it was)
             free_class(p->cls[lo]);
             p->cls[lo] = ClassPlan();
-            rc = build_class(g, lo, p->cls[lo], tab, 0, full_v && lo, full_v);
+            rc = build_class(g, lo, p->cls[lo], tab, 0, full_v && lo, force_column);
         }
     }
     if (rc == TTS_OK && !upload(p->d_tab, tab)) rc = TTS_ERR_INITIALIZATION_FAILED;
@@ -124,7 +124,17 @@ int tts_plan_create(const tts_geom *g, tts_plan **out)
                 gp.out_fmt = TTS_FMT_YUV420P; gp.rgb_stage = TTS_RGB_NONE; gp.fill_rgb = 0;
                 gp.do_pad = 0; gp.pad_x = gp.pad_y = 0; gp.out_w = g->crop_w; gp.out_h = g->crop_h;
                 sp->g = gp; sp->device = dev; sp->knobs = p->knobs; sp->n_cus = p->n_cus; sp->y16 = true;
-                if (build_classes(sp, gp, true) == TTS_OK && sp->cls[0].kind == 2 && sp->cls[1].kind == 2) p->scratch = sp;
+                // 5-8 taps: the strip kernels where both classes get a grouped-window instantiation (those have the
+                // 16-bit luma store), else -- and above 8 taps -- the column walk
+                auto strips16 = [&](const ClassPlan &c) { return c.kind == 1 && strip_has_y16(strip_choice(c, sp->knobs)); };
+                bool ok = build_classes(sp, gp, true) == TTS_OK;
+                if (ok && !(strips16(sp->cls[0]) && strips16(sp->cls[1])) && (sp->cls[0].kind != 2 || sp->cls[1].kind != 2)) {
+                    free_class(sp->cls[0]); free_class(sp->cls[1]);
+                    sp->cls[0] = ClassPlan(); sp->cls[1] = ClassPlan();
+                    (void)hipFree(sp->d_tab); sp->d_tab = nullptr;
+                    ok = build_classes(sp, gp, true, true) == TTS_OK && sp->cls[0].kind == 2 && sp->cls[1].kind == 2;
+                }
+                if (ok) p->scratch = sp;
                 else tts_plan_destroy(sp);
             }
         }

@@ -458,7 +458,9 @@ __device__ __forceinline__ void plan_runs(const StripArgs &a, const StripClass &
 // taps); GC: columns that share one LDS window (0 = none, see the static_assert below; "G4" in the body
 // means GC != 0); NDMA: 1 KiB LDS-DMAs per source row (the wave's runs hold <= 64 * NDMA sixteen-byte
 // chunks); D: source rows in flight per wave, one LDS slot each.  Eight columns per lane.
-template <int LW, int R, int GC, int NDMA, int D>
+// Y16: with a.y16 set, slot 0 (luma) stores its sums UNCLIPPED as int16 (the RGB scratch planes, see the column
+// walk); a parameter rather than a test so that the planar instantiations keep their registers.
+template <int LW, int R, int GC, int NDMA, int D, bool Y16 = false>
 __global__ __launch_bounds__(kMaxLdsBlock, (GC == 4 && R == 4 && LW == 4) ? 8 : 4) void strip_lds_kernel(const uint8_t *__restrict__ src, uint8_t *__restrict__ dst,
                                                                                const uint32_t *__restrict__ tab, const StripArgs a)
 {
@@ -508,7 +510,8 @@ __global__ __launch_bounds__(kMaxLdsBlock, (GC == 4 && R == 4 && LW == 4) ? 8 : 
     const uint8_t *wsrc = src;                       // this wave's bases
     uint8_t *wdst = dst;
     frame_offsets(a, plane, frame, wsrc, wdst, src_rec, dst_rec, soff, doff);
-    doff += uint32_t(min(strip * N, c.ow - N));              // the last strip is slid left, not cut short
+    [[maybe_unused]] const bool y16 = Y16 && a.y16 != 0 && ci == 0;       // wave-uniform
+    doff += uint32_t(min(strip * N, c.ow - N)) << (y16 ? 1 : 0);  // the last strip is slid left, not cut short
     // Dead lanes run the same instruction stream (so the wave's store count stays uniform) with an
     // offset past the end of the buffer: the descriptor's range check discards their stores.
     if (!live) doff = kDiscard;
@@ -684,6 +687,27 @@ __global__ __launch_bounds__(kMaxLdsBlock, (GC == 4 && R == 4 && LW == 4) ? 8 : 
                 const int yn = min(y + 1, last_y);
 #pragma unroll
                 for (int q = 0; q < R / 2; ++q) vk_next[q] = uni(vco[yn * (R / 2) + q]);
+                if constexpr (Y16) {
+                    if (y16) {
+                        uint32_t w[N / 2];
+#pragma unroll
+                        for (int q = 0; q < N / 2; ++q) {
+                            int v[2];
+#pragma unroll
+                            for (int j = 0; j < 2; ++j) {
+                                int acc = 64 << 12;
+#pragma unroll
+                                for (int p = 0; p < R / 2; ++p) acc = dot2(ring[2 * q + j][p], vk[p], acc);
+                                v[j] = acc;
+                            }
+                            w[q] = (uint32_t(v[0] >> 19) & 0xffffu) | (uint32_t(v[1] >> 19) << 16);
+                        }
+                        if (bar) asm volatile("s_barrier" ::: "memory");
+                        store_b128(u32x4_t{w[0], w[1], w[2], w[3]}, drs, doff, y * dst_stride);
+                        ++y;
+                        continue;
+                    }
+                }
                 uint32_t o[N / 4];
 #pragma unroll
                 for (int q = 0; q < N / 4; ++q) {

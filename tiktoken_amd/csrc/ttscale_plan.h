@@ -532,21 +532,27 @@ StripChoice strip_choice(const ClassPlan &c, const Knobs &kn)
     return ch;
 }
 
-strip_fn pick_strip(const StripChoice &ch, const Knobs &kn)
+// y16: the instantiation with the 16-bit luma store (scratch plans; the grouped 12-byte-window kernels only)
+bool strip_has_y16(const StripChoice &ch) { return ch.lds && ch.g12; }
+
+strip_fn pick_strip(const StripChoice &ch, const Knobs &kn, bool y16 = false)
 {
     const int D = kn.strip_d;                          // rows in flight of the register kernels (tuning knob)
+    if (y16 && !strip_has_y16(ch)) return nullptr;
     if (ch.lds && ch.g4 && !ch.g12) {
         if (ch.R == 4) return ch.depth == 2 ? strip_lds_kernel<4, 4, 4, 1, 2> : strip_lds_kernel<4, 4, 4, 1, 1>;
         return ch.R == 6 ? strip_lds_kernel<4, 6, 4, 1, 1> : strip_lds_kernel<4, 8, 4, 1, 1>;
     }
-    if (ch.lds && ch.g12 == 4) return ch.R == 4 ? strip_lds_kernel<6, 4, 4, 1, 1> : ch.R == 6 ? strip_lds_kernel<6, 6, 4, 1, 1> : strip_lds_kernel<6, 8, 4, 1, 1>;
+#define TTS_Y(LW_, R_, GC_, NDMA_, D_) (y16 ? strip_lds_kernel<LW_, R_, GC_, NDMA_, D_, true> : strip_lds_kernel<LW_, R_, GC_, NDMA_, D_>)
+    if (ch.lds && ch.g12 == 4) return ch.R == 4 ? TTS_Y(6, 4, 4, 1, 1) : ch.R == 6 ? TTS_Y(6, 6, 4, 1, 1) : TTS_Y(6, 8, 4, 1, 1);
     if (ch.lds && ch.g12 == 2) {
-#define TTS_G2_PICK(LW_, R_) (ch.lds == 1 ? strip_lds_kernel<LW_, R_, 2, 1, 1> : ch.lds == 2 ? strip_lds_kernel<LW_, R_, 2, 2, 1> : strip_lds_kernel<LW_, R_, 2, 4, 1>)
-        if (ch.depth == 4) return strip_lds_kernel<8, 8, 2, 2, 4>;
+#define TTS_G2_PICK(LW_, R_) (ch.lds == 1 ? TTS_Y(LW_, R_, 2, 1, 1) : ch.lds == 2 ? TTS_Y(LW_, R_, 2, 2, 1) : TTS_Y(LW_, R_, 2, 4, 1))
+        if (ch.depth == 4) return TTS_Y(8, 8, 2, 2, 4);
         if (ch.LW == 6) return ch.R == 4 ? TTS_G2_PICK(6, 4) : ch.R == 6 ? TTS_G2_PICK(6, 6) : TTS_G2_PICK(6, 8);
         return ch.R == 4 ? TTS_G2_PICK(8, 4) : ch.R == 6 ? TTS_G2_PICK(8, 6) : TTS_G2_PICK(8, 8);
 #undef TTS_G2_PICK
     }
+#undef TTS_Y
     if (ch.lds) {
 #define TTS_LDS_PICK(LW_, R_) (ch.lds == 1 ? strip_lds_kernel<LW_, R_, 0, 1, 1> : ch.lds == 2 ? strip_lds_kernel<LW_, R_, 0, 2, 1> : strip_lds_kernel<LW_, R_, 0, 4, 1>)
         if (ch.LW == 4) return ch.R == 4 ? TTS_LDS_PICK(4, 4) : ch.R == 6 ? TTS_LDS_PICK(4, 6) : TTS_LDS_PICK(4, 8);
@@ -814,8 +820,9 @@ int launch_all(const tts_plan *p, const uint8_t *src, uint8_t *dst, int n, const
         const ClassPlan &c = p->cls[ci];
         if (c.kind == 0) to_generic[ci] = true;
         if (c.kind == 2 && (src_span < 4096u || (addr.use_table && (c.segs[0].nseg < 2 || c.segs[0].spans_plane || c.src_w < 48 || c.src_h < 32)))) to_generic[ci] = true;
-        // (the scratch plan of the packed-RGB thumbnail path: only the column walk stores int16 luma; the caller falls back)
-        if (p->y16 && (c.kind != 2 || to_generic[ci]) && active(ci)) { g_last_error = "scratch pass needs the column walk"; return TTS_ERR_UNSUPPORTED; }
+        // (the scratch plan of the packed-RGB shrinks: only the column walk and the grouped-window strip kernels
+        // store int16 luma; the caller falls back)
+        if (p->y16 && (c.kind == 0 || to_generic[ci]) && active(ci)) { g_last_error = "scratch pass needs the column walk or an LDS strip kernel"; return TTS_ERR_UNSUPPORTED; }
     }
     RangeStep range{};
     if (p->g.out_range != TTS_RANGE_KEEP) {
@@ -899,7 +906,9 @@ int launch_all(const tts_plan *p, const uint8_t *src, uint8_t *dst, int n, const
             short_plane |= cj.segs[0].nseg < 2 || cj.segs[0].spans_plane || cj.src_w < 48 || cj.src_h < 32;
         }
         if (src_span < 4096u || (addr.use_table && short_plane)) { ch.lds = 0; ch.depth = 1; ch.LW = p->cls[ci].LW; if (ch.g12) { ch.g4 = false; ch.g12 = 0; } }
-        strip_fn fn = pick_strip(ch, p->knobs);
+        a.y16 = p->y16 && (merged || ci == 0);
+        if (p->y16 && !strip_has_y16(ch)) return TTS_ERR_UNSUPPORTED;   // (the caller falls back to the RGB kernels)
+        strip_fn fn = pick_strip(ch, p->knobs, a.y16 != 0);
         if (!fn) return TTS_ERR_UNSUPPORTED;
         size_t si[2];
         int max_items = 0;
