@@ -158,6 +158,38 @@ def test_random_geometries_packed_rgb_out(tts, oracle, seed):
 
 
 @pytest.mark.parametrize("seed", range(int(__import__("os").environ.get("TTS_FUZZ_RGB_SEEDS", "12"))))
+def test_random_small_shrinks_packed_rgb_out(tts, oracle, seed):
+    """Shrinks between 1x and 2.2x an axis (5-8 taps) at sizes where the LDS strip kernels run: their 16-bit luma
+    store and the in-place conversion behind it, with crops, pads and odd sizes; batches and one-off frames."""
+    import torch
+    rng = np.random.default_rng(12000 + seed)
+    ran = 0
+    for _ in range(6):
+        iw, ih = 2 * int(rng.integers(40, 700)), 2 * int(rng.integers(30, 420))
+        ow, oh = max(16, int(iw / rng.uniform(1.0, 2.2))), max(16, int(ih / rng.uniform(1.0, 2.2)))
+        parts = ["scale=%d:%d%s" % (ow, oh, rng.choice(["", "", ":flags=bilinear", ":flags=area"]))]
+        if rng.random() < 0.3:
+            cw, chh = int(rng.integers(12, ow + 1)), int(rng.integers(12, oh + 1))
+            parts.append("crop=%d:%d:%d:%d" % (cw, chh, int(rng.integers(0, ow - cw + 1)), int(rng.integers(0, oh - chh + 1))))
+        if rng.random() < 0.3:
+            parts.append("pad=iw+%d:ih+%d:-1:-1:color=%s" % (int(rng.integers(0, 40)), int(rng.integers(0, 40)), rng.choice(["black", "red", "white"])))
+        parts.append("format=%s" % rng.choice(["rgb24", "rgb24", "bgr24", "rgba", "bgra"]))
+        vf, n = ",".join(parts), int(rng.choice([1, 2, 3]))
+        try:
+            plan = tts.Plan.from_vf(vf, iw, ih)
+        except tts.TtsError:
+            continue
+        src = synth.frames(str(rng.choice(["random", "impulse", "zone"])), iw, ih, n)
+        want = oracle.run_chain(plan.geom, src)
+        got = plan.run_batch(torch.from_numpy(src).cuda()).cpu().numpy()
+        bad = np.flatnonzero(got != want)
+        assert bad.size == 0, "%s %dx%d n=%d [%s]: %d bytes differ, first at %d (got %d want %d)" % (
+            vf, iw, ih, n, plan.kernel_name(0), bad.size, bad[0], got.ravel()[bad[0]], want.ravel()[bad[0]])
+        ran += 1
+    assert ran, "no case ran"
+
+
+@pytest.mark.parametrize("seed", range(int(__import__("os").environ.get("TTS_FUZZ_RGB_SEEDS", "12"))))
 def test_random_geometries_packed_rgb_in(tts, oracle, seed):
     import torch
     rng = np.random.default_rng(11000 + seed)
