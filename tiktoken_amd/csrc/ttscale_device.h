@@ -76,18 +76,41 @@ __device__ __forceinline__ uint32_t sat_pk_u8(uint32_t packed_i16)
     return r;
 }
 
-// four vertical sums -> four clipped bytes (val >> 19, clip to 0..255)
+// four vertical sums -> four clipped bytes (val >> 19, clip to 0..255) in two instructions: gfx950's
+// v_ashr_pk_u8_i32 shifts two int32, clips both to 0..255 and writes them as two bytes into ONE HALF of the
+// destination -- the low half, or with op_sel:[0,0,0,1] the high half -- leaving the other half as it was (that
+// is the "garbage" of the note above).  tools/micro/ashr_pk.hip checks both forms against the host over edge
+// values.  (Was: two v_perm, two packed shifts, two v_sat_pk_u8_i16 and an or.)  The s_nop is the wait state a
+// VALU result written through op_sel's high half needs before the next VALU reads it (gfx940-family forwarding
+// hazard; the compiler inserts it for its own instructions and cannot see into this one).
+template <int SH = 19>
 __device__ __forceinline__ uint32_t pack4(int v0, int v1, int v2, int v3)
 {
-    // high halves of each pair, then >>3 on the packed int16s == >>19 on the int32s
-    const uint32_t h01 = __builtin_amdgcn_perm(uint32_t(v1), uint32_t(v0), 0x07060302);
-    const uint32_t h23 = __builtin_amdgcn_perm(uint32_t(v3), uint32_t(v2), 0x07060302);
-    const short2_t s01 = __builtin_bit_cast(short2_t, h01) >> short2_t{3, 3};
-    const short2_t s23 = __builtin_bit_cast(short2_t, h23) >> short2_t{3, 3};
-    uint32_t b01, b23;
-    asm("v_sat_pk_u8_i16 %0, %1" : "=v"(b01) : "v"(s01));
-    asm("v_sat_pk_u8_i16 %0, %1" : "=v"(b23) : "v"(s23));
-    return b01 | (b23 << 16);
+    uint32_t d;
+    asm("v_ashr_pk_u8_i32 %0, %1, %2, %3" : "=v"(d) : "v"(v0), "v"(v1), "n"(SH));
+    asm("v_ashr_pk_u8_i32 %0, %1, %2, %3 op_sel:[0,0,0,1]\n\ts_nop 0" : "+v"(d) : "v"(v2), "v"(v3), "n"(SH));
+    return d;
+}
+// two sums -> two clipped bytes in bits 0..15; bits 16..31 are whatever the register held
+__device__ __forceinline__ uint32_t pack2(int v0, int v1)
+{
+    uint32_t d;
+    asm("v_ashr_pk_u8_i32 %0, %1, %2, 19" : "=v"(d) : "v"(v0), "v"(v1));
+    return d;
+}
+__device__ __forceinline__ uint32_t pack2_by(int v0, int v1, int sh)
+{
+    uint32_t d;
+    asm("v_ashr_pk_u8_i32 %0, %1, %2, %3" : "=v"(d) : "v"(v0), "v"(v1), "s"(sh));
+    return d;
+}
+// the same with the shift in a register (the range step's)
+__device__ __forceinline__ uint32_t pack4_by(int v0, int v1, int v2, int v3, int sh)
+{
+    uint32_t d;
+    asm("v_ashr_pk_u8_i32 %0, %1, %2, %3" : "=v"(d) : "v"(v0), "v"(v1), "s"(sh));
+    asm("v_ashr_pk_u8_i32 %0, %1, %2, %3 op_sel:[0,0,0,1]\n\ts_nop 0" : "+v"(d) : "v"(v2), "v"(v3), "s"(sh));
+    return d;
 }
 
 // Output stores are issued from inline asm.  hipcc's s_waitcnt pass counts the vector-memory

@@ -83,20 +83,12 @@ __device__ __forceinline__ void pad_fill_blocks(const StripArgs &a, uint8_t *dst
     }
 }
 
-// the range step on one finished byte / on four packed bytes ((p * mul + add) >> shift lies within int16:
-// -20 .. 280 for the four forms of filter.cpp; the clip is v_sat_pk_u8_i16's)
-__device__ __forceinline__ int range_byte(int p, int mul, int add, int shift)
-{
-    const int v = (__mul24(p, mul) + add) >> shift;          // (p < 2^8, mul < 2^23: the full-rate 24-bit multiply)
-    return int(sat_pk_u8(uint32_t(v) & 0xffffu));
-}
+// the range step on four packed bytes ((p * mul + add) >> shift, clipped by the pack)
 __device__ __forceinline__ uint32_t range_bytes4(uint32_t o, int mul, int add, int shift)
 {
-    const int v0 = (__mul24(int(o & 255u), mul) + add) >> shift, v1 = (__mul24(int((o >> 8) & 255u), mul) + add) >> shift;
-    const int v2 = (__mul24(int((o >> 16) & 255u), mul) + add) >> shift, v3 = (__mul24(int(o >> 24), mul) + add) >> shift;
-    const uint32_t lo = sat_pk_u8((uint32_t(v0) & 0xffffu) | (uint32_t(v1) << 16));
-    const uint32_t hi = sat_pk_u8((uint32_t(v2) & 0xffffu) | (uint32_t(v3) << 16));
-    return lo | (hi << 16);
+    const int v0 = __mul24(int(o & 255u), mul) + add, v1 = __mul24(int((o >> 8) & 255u), mul) + add;
+    const int v2 = __mul24(int((o >> 16) & 255u), mul) + add, v3 = __mul24(int(o >> 24), mul) + add;
+    return pack4_by(v0, v1, v2, v3, shift);                  // (>> shift and the clip in the pack)
 }
 
 // Where this lane's plane lies.  Lane offsets are 32-bit, a launch is not: in packed mode every wave
@@ -1004,14 +996,10 @@ __global__ __launch_bounds__(kBlock, (D4 && NC == 2 && NTP == 12 && NDMA == 1) ?
                     if (rng) o4 = range_bytes4(o4, rmul, radd, rsh);
                     store_b32(o4, drs, doff, yoff);
                 } else {
-#pragma unroll
-                    for (int j = 0; j < NC; ++j) { v[j] >>= 19; v[j] = v[j] < 0 ? 0 : v[j] > 255 ? 255 : v[j]; }
-                    if (rng) {                                  // wave-uniform
-#pragma unroll
-                        for (int j = 0; j < NC; ++j) v[j] = range_byte(v[j], rmul, radd, rsh);
-                    }
-                    if constexpr (NC == 2) store_b16(uint32_t(v[0]) | (uint32_t(v[1]) << 8), drs, doff, yoff);
-                    else store_b8(uint32_t(v[0]), drs, doff, yoff);
+                    uint32_t o2 = pack2(v[0], v[NC - 1]);       // bits 16..31 undefined: the stores below take 8 / 16 bits
+                    if (rng) o2 = pack2_by(__mul24(int(o2 & 255u), rmul) + radd, __mul24(int((o2 >> 8) & 255u), rmul) + radd, rsh);   // wave-uniform
+                    if constexpr (NC == 2) store_b16(o2, drs, doff, yoff);
+                    else store_b8(o2, drs, doff, yoff);
                 }
                 ++y;
             }

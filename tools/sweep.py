@@ -63,9 +63,10 @@ def main():
     ap.add_argument("--segs", default="0,16,32,48,64,128")
     ap.add_argument("--ns", default="16,8")
     ap.add_argument("--extra", default="", help="comma list of ENV=V1|V2 knobs to cross")
+    ap.add_argument("--dst-align", default="0", help="comma list: destination rows padded to a multiple of this many bytes (0 = packed rows); planar output")
     args = ap.parse_args()
     vf, iw, ih, algo = CASES[args.case]
-    knobs = {"TTS_SEG_ROWS": args.segs.split(","), "TTS_STRIP_N": args.ns.split(",")}
+    knobs = {"TTS_SEG_ROWS": args.segs.split(","), "TTS_STRIP_N": args.ns.split(","), "DST_ALIGN": args.dst_align.split(",")}
     for e in filter(None, args.extra.split(",")):
         k, v = e.split("=")
         knobs[k] = v.split("|")
@@ -79,7 +80,11 @@ def main():
         plans[combo] = plan_for(args.case)
     p0 = plans[combos[0]]
     src = torch.randint(0, 256, (args.frames, p0.in_bytes), dtype=torch.uint8, device="cuda")
-    dst = torch.empty((args.frames, p0.out_bytes), dtype=torch.uint8, device="cuda")
+    ow, oh = p0.out_size
+    up = lambda v, a: (v + a - 1) // a * a
+    dstr = {a: ((ow, (ow + 1) // 2) if a == 0 else (up(ow, a), up((ow + 1) // 2, a))) for a in map(int, knobs["DST_ALIGN"])}
+    dst = torch.empty((args.frames, max(p0.strided_bytes("out", *d) for d in dstr.values())), dtype=torch.uint8, device="cuda")   # (flat: frames lie strided_bytes apart)
+    sstr = (iw, (iw + 1) // 2)
     times = {c: [] for c in combos}
     for rnd in range(args.rounds + 1):
         for combo in combos:
@@ -88,8 +93,12 @@ def main():
             p = plans[combo]
             e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
             e0.record()
+            al = int(combo[names.index("DST_ALIGN")])
             for _ in range(args.iters):
-                p.run_batch(src, dst)
+                if len(dstr) > 1 or al:
+                    p.run_batch_strided(src, sstr, dst, dstr[al], args.frames)
+                else:
+                    p.run_batch(src, dst)
             e1.record()
             torch.cuda.synchronize()
             if rnd:
