@@ -684,8 +684,12 @@ __global__ __launch_bounds__(kScratchThreads) void rgb_scratch_convert_kernel(co
 // the thumbnail chain does): a thread takes FOUR adjacent pixels -- 8 bytes of luma, 2 + 2 of chroma in, 12 or 16
 // bytes of pixels out, as dwords -- instead of one pixel through byte and halfword accesses, which kept the
 // texture addresser busier than the memory (82 -> 3x fewer memory instructions).
+// PX = 4 or 8 pixels a thread (8 where the picture is a multiple of eight wide: 16 bytes of luma, 4 + 4 of chroma in,
+// 24 or 32 bytes of pixels out).
+template <int PX>
 __global__ __launch_bounds__(kScratchThreads) void rgb_scratch_convert4_kernel(const RgbScratchArgs a)
 {
+    static_assert(PX == 4 || PX == 8, "pixels a thread");
     const int frame = a.frame0 + int(blockIdx.y), t = int(threadIdx.x) & (a.tpr - 1);
     uint8_t *fb = a.dst + size_t(frame) * a.addr.dst_pitch + a.addr.dst_plane[0];
     const int cy = int(blockIdx.x) * (kScratchThreads / a.tpr) + int(threadIdx.x) / a.tpr;   // canvas row
@@ -694,47 +698,60 @@ __global__ __launch_bounds__(kScratchThreads) void rgb_scratch_convert4_kernel(c
     const bool in_rows = row_ok && cy >= a.py && cy < a.py + a.ph;
     uint8_t *prow = crow + size_t(a.px) * a.bpp;
     const uint8_t *urow = prow + 2 * size_t(a.pw), *vrow = urow + a.cw;
-    const int quads = a.pw >> 2;
-    constexpr int kIters = kScratchMaxPerThread / 4;
-    uint32_t y01[kIters], y23[kIters], uv[kIters];
+    const int units = a.pw / PX;
+    constexpr int kIters = kScratchMaxPerThread / PX, LW = PX / 2, CW = PX / 4;   // dwords of luma / of each chroma plane a unit
+    uint32_t yw[kIters][LW], uw[kIters][CW], vw[kIters][CW];
 #pragma unroll
     for (int it = 0; it < kIters; ++it) {
-        if (it * a.tpr >= quads) break;                            // (uniform)
+        if (it * a.tpr >= units) break;                            // (uniform)
         const int q = it * a.tpr + t;
-        uint32_t l0 = 0, l1 = 0, c = 0;
-        if (in_rows && q < quads) {
-            const uint32_t *yp = reinterpret_cast<const uint32_t *>(prow + 8 * size_t(q));
-            l0 = yp[0]; l1 = yp[1];
-            c = uint32_t(*reinterpret_cast<const uint16_t *>(urow + 2 * size_t(q))) | uint32_t(*reinterpret_cast<const uint16_t *>(vrow + 2 * size_t(q))) << 16;
+#pragma unroll
+        for (int k = 0; k < LW; ++k) yw[it][k] = 0;
+#pragma unroll
+        for (int k = 0; k < CW; ++k) uw[it][k] = vw[it][k] = 0;
+        if (in_rows && q < units) {
+            const uint32_t *yp = reinterpret_cast<const uint32_t *>(prow + 2 * PX * size_t(q));
+#pragma unroll
+            for (int k = 0; k < LW; ++k) yw[it][k] = yp[k];
+            if constexpr (PX == 8) {
+                uw[it][0] = *reinterpret_cast<const uint32_t *>(urow + 4 * size_t(q));
+                vw[it][0] = *reinterpret_cast<const uint32_t *>(vrow + 4 * size_t(q));
+            } else {
+                uw[it][0] = *reinterpret_cast<const uint16_t *>(urow + 2 * size_t(q));
+                vw[it][0] = *reinterpret_cast<const uint16_t *>(vrow + 2 * size_t(q));
+            }
         }
-        y01[it] = l0; y23[it] = l1; uv[it] = c;
     }
     __syncthreads();                                               // the workgroup's rows sit in registers: they may be overwritten
     if (!row_ok) return;
     if (in_rows) {
 #pragma unroll
         for (int it = 0; it < kIters; ++it) {
-            if (it * a.tpr >= quads) break;
+            if (it * a.tpr >= units) break;
             const int q = it * a.tpr + t;
-            if (q < quads) {
-                int r[4], g[4], b[4];
+            if (q < units) {
+                int r[PX], g[PX], b[PX];
 #pragma unroll
-                for (int i = 0; i < 4; ++i) {
-                    const uint32_t yw = i < 2 ? y01[it] : y23[it];
-                    const int Y = int(int16_t(i & 1 ? yw >> 16 : yw & 0xffffu));
-                    const int U = int((uv[it] >> (8 * (i >> 1))) & 255u), V = int((uv[it] >> (16 + 8 * (i >> 1))) & 255u);
+                for (int i = 0; i < PX; ++i) {
+                    const uint32_t w = yw[it][i >> 1];
+                    const int Y = int(int16_t(i & 1 ? w >> 16 : w & 0xffffu));
+                    const int U = int((uw[it][0] >> (8 * (i >> 1))) & 255u), V = int((vw[it][0] >> (8 * (i >> 1))) & 255u);
                     tts::rgb_pixel(a.coef, Y, U, V, r[i], g[i], b[i]);
                     if (a.swap) { const int s = r[i]; r[i] = b[i]; b[i] = s; }
                 }
                 if (a.bpp == 4) {
-                    uint32_t *d = reinterpret_cast<uint32_t *>(prow + 16 * size_t(q));
+                    uint32_t *d = reinterpret_cast<uint32_t *>(prow + 4 * PX * size_t(q));
 #pragma unroll
-                    for (int i = 0; i < 4; ++i) d[i] = uint32_t(r[i]) | uint32_t(g[i]) << 8 | uint32_t(b[i]) << 16 | 0xff000000u;
+                    for (int i = 0; i < PX; ++i) d[i] = uint32_t(r[i]) | uint32_t(g[i]) << 8 | uint32_t(b[i]) << 16 | 0xff000000u;
                 } else {
-                    uint32_t *d = reinterpret_cast<uint32_t *>(prow + 12 * size_t(q));
-                    d[0] = uint32_t(r[0]) | uint32_t(g[0]) << 8 | uint32_t(b[0]) << 16 | uint32_t(r[1]) << 24;
-                    d[1] = uint32_t(g[1]) | uint32_t(b[1]) << 8 | uint32_t(r[2]) << 16 | uint32_t(g[2]) << 24;
-                    d[2] = uint32_t(b[2]) | uint32_t(r[3]) << 8 | uint32_t(g[3]) << 16 | uint32_t(b[3]) << 24;
+                    uint32_t *d = reinterpret_cast<uint32_t *>(prow + 3 * PX * size_t(q));
+#pragma unroll
+                    for (int h = 0; h < PX / 4; ++h) {
+                        const int *R = r + 4 * h, *G = g + 4 * h, *B = b + 4 * h;
+                        d[3 * h]     = uint32_t(R[0]) | uint32_t(G[0]) << 8 | uint32_t(B[0]) << 16 | uint32_t(R[1]) << 24;
+                        d[3 * h + 1] = uint32_t(G[1]) | uint32_t(B[1]) << 8 | uint32_t(R[2]) << 16 | uint32_t(G[2]) << 24;
+                        d[3 * h + 2] = uint32_t(B[2]) | uint32_t(R[3]) << 8 | uint32_t(G[3]) << 16 | uint32_t(B[3]) << 24;
+                    }
                 }
             }
         }
@@ -1002,6 +1019,7 @@ struct RgbPlan {
     enum Mode { kUnscaled, kGeneric } mode = kGeneric;
     // the fused strip walk (every axis <= 4 taps, no pad, even crop): tables in HBM, one set per segment length
     bool strip_ok = false;
+    bool convert4 = false;                // in-place conversion: four pixels a thread even where eight fit (TTS_RGB_CONVERT4, A/B)
     bool strip_lds = false;            // ... with the source rows staged through LDS (the runs of any 64 strips fit a 1 KiB slot per plane)
     uint32_t *d_tab = nullptr;
     RgbStripArgs strip{};              // table offsets and constants; per-launch fields are filled in by rgb_launch
@@ -1126,6 +1144,7 @@ int rgb_plan_create(const tts_geom &g, int n_cus, RgbPlan **out)
     p->bpp = g.out_fmt >= TTS_FMT_RGBA ? 4 : 3;
     p->swap = g.out_fmt == TTS_FMT_BGR24 || g.out_fmt == TTS_FMT_BGRA;
     p->coef = rgb_coef();
+    p->convert4 = std::getenv("TTS_RGB_CONVERT4") && std::atoi(std::getenv("TTS_RGB_CONVERT4"));
     p->px = g.do_pad ? g.pad_x : 0; p->py = g.do_pad ? g.pad_y : 0;
     p->pw = g.crop_w; p->ph = g.crop_h; p->ox = g.crop_x; p->oy = g.crop_y;
 
@@ -1320,13 +1339,14 @@ int rgb_scratch_convert(const RgbPlan *p, uint8_t *dst, int dst_stride, int n, c
     // four pixels a thread through dword accesses where every picture row starts on a dword and holds whole quads
     const bool quad = !addr.use_table && p->pw % 4 == 0 && (reinterpret_cast<uintptr_t>(dst) & 3u) == 0 && addr.dst_pitch % 4 == 0 &&
                       addr.dst_plane[0] % 4 == 0 && dst_stride % 4 == 0 && (p->px * p->bpp) % 4 == 0;
-    const int units = quad ? p->pw / 4 : p->pw;                   // per row; about two quads / six pixels a thread on narrow pictures
+    const int px_unit = !quad ? 1 : p->pw % 8 == 0 && !p->convert4 ? 8 : 4;
+    const int units = p->pw / px_unit;                            // per row; about two units a thread (six pixels without dword accesses) on narrow pictures
     a.tpr = units <= 64 * (quad ? 2 : 6) ? 64 : units <= 128 * (quad ? 2 : 6) ? 128 : 256;
     const int rows_per_wg = kScratchThreads / a.tpr;
     int rc = TTS_OK;
     for (int f0 = 0; f0 < n && !rc; f0 += 65535) {               // grid.y = frames
         a.frame0 = f0;
-        rc = launch_rgb("rgb_scratch_convert_kernel", quad ? rgb_scratch_convert4_kernel : rgb_scratch_convert_kernel,
+        rc = launch_rgb("rgb_scratch_convert_kernel", px_unit == 8 ? rgb_scratch_convert4_kernel<8> : px_unit == 4 ? rgb_scratch_convert4_kernel<4> : rgb_scratch_convert_kernel,
                         dim3(unsigned((p->g.out_h + rows_per_wg - 1) / rows_per_wg), unsigned(std::min(65535, n - f0))), dim3(kScratchThreads), 0, st, a);
     }
     return rc;

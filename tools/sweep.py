@@ -15,6 +15,8 @@ CASES = {
     "portrait": ("scale=1080:1920:force_original_aspect_ratio=increase,crop=1080:1920", 1920, 1080, 4095360),
     "4k": ("scale=1080:1920:force_original_aspect_ratio=increase,crop=1080:1920", 3840, 2160, 7050240),
     "720p": ("scale=1080:1920:force_original_aspect_ratio=increase,crop=1080:1920", 1280, 720, 3548880),
+    "w1088": ("scale=1080:1920:force_original_aspect_ratio=increase,crop=1088:1920", 1920, 1080, 613 * 1080 * 3 // 2 + 1088 * 1920 * 3 // 2),
+    "w1152": ("scale=1080:1920:force_original_aspect_ratio=increase,crop=1152:1920", 1920, 1080, 649 * 1080 * 3 // 2 + 1152 * 1920 * 3 // 2),
     "aligned": ("scale=1080:1920:force_original_aspect_ratio=increase,crop=1024:1920", 1920, 1080, 3882240),
     # the reference's own thumbnail chain (src/services/video.js:329-332) on a 1080p / portrait 1080p / 4K source
     "thumbref": ("scale=320x180:force_original_aspect_ratio=decrease,pad=320x180:-1:-1:color=black,format=yuv420p", 1920, 1080, 3110400 + 86400),
@@ -83,7 +85,7 @@ def main():
     ow, oh = p0.out_size
     up = lambda v, a: (v + a - 1) // a * a
     dstr = {a: ((ow, (ow + 1) // 2) if a == 0 else (up(ow, a), up((ow + 1) // 2, a))) for a in map(int, knobs["DST_ALIGN"])}
-    dst = torch.empty((args.frames, max(p0.strided_bytes("out", *d) for d in dstr.values())), dtype=torch.uint8, device="cuda")   # (flat: frames lie strided_bytes apart)
+    dst = torch.empty((args.frames, max([p0.out_bytes] + [p0.strided_bytes("out", *d) for d in dstr.values()])), dtype=torch.uint8, device="cuda")   # (flat: frames lie strided_bytes apart)
     sstr = (iw, (iw + 1) // 2)
     times = {c: [] for c in combos}
     for rnd in range(args.rounds + 1):
@@ -98,7 +100,7 @@ def main():
                 if len(dstr) > 1 or al:
                     p.run_batch_strided(src, sstr, dst, dstr[al], args.frames)
                 else:
-                    p.run_batch(src, dst)
+                    p.run_batch(src, dst if dst.shape[1] == p0.out_bytes else dst.view(-1)[: args.frames * p0.out_bytes].view(args.frames, p0.out_bytes))
             e1.record()
             torch.cuda.synchronize()
             if rnd:
