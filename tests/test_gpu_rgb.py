@@ -94,6 +94,40 @@ SCRATCH_CASES = [
 ]
 
 
+UNSCALED_CASES = [
+    ("format=rgb24", 1920, 1080, "rgb_unscaled8"),            # the streaming form: 8 pixels of a row pair a lane
+    ("format=bgra", 1920, 1080, "rgb_unscaled8"),
+    ("format=bgr24", 1280, 720, "rgb_unscaled8"),
+    ("format=rgba", 48, 32, "rgb_unscaled8"),                 # one partial wave a row pair
+    ("format=rgb24", 1040, 64, "rgb_unscaled8"),              # 130 units: the third wave of a row pair holds two
+    ("crop=640:360:16:10,format=rgb24", 1280, 720, "rgb_unscaled8"),
+    ("crop=640:360:4:10,format=rgb24", 1280, 720, "rgb_unscaled"),     # source rows off the dword grid
+    ("format=rgb24", 1928, 1080, "rgb_unscaled"),             # not a multiple of 16 wide
+    ("pad=1936:1096:-1:-1,format=rgb24", 1920, 1080, "rgb_unscaled"),
+]
+
+
+@pytest.mark.parametrize("vf,iw,ih,kernel", UNSCALED_CASES)
+def test_rgb_conversion_alone_streaming_kernel(tts, oracle, monkeypatch, vf, iw, ih, kernel):
+    """`format=rgb24` with no scale: the 8-pixels-a-lane kernel where the geometry fits, the per-pixel one elsewhere;
+    both give the oracle's bytes (TTS_RGB_CONVERT4=1 forces the per-pixel kernel)."""
+    import torch
+    n = 3
+    plan = tts.Plan.from_vf(vf, iw, ih)
+    for kind in ("random", "impulse"):
+        src = synth.frames(kind, iw, ih, n)
+        want = oracle.run_chain(plan.geom, src)
+        got = plan.run_batch(torch.from_numpy(src).cuda()).cpu().numpy()
+        bad = np.flatnonzero(got != want)
+        assert bad.size == 0, "%s %s: %d bytes differ, first at %d (got %d want %d)" % (vf, kind, bad.size, bad[0], got.ravel()[bad[0]], want.ravel()[bad[0]])
+    assert plan.kernel_name(0) == kernel, plan.kernel_name(0)
+    monkeypatch.setenv("TTS_RGB_CONVERT4", "1")
+    slow = tts.Plan.from_vf(vf, iw, ih)
+    src = synth.frames("random", iw, ih, n)
+    d = torch.from_numpy(src).cuda()
+    assert np.array_equal(slow.run_batch(d).cpu().numpy(), plan.run_batch(d).cpu().numpy())
+
+
 STRIP16_CASES = [
     ("scale=1280:720", 1920, 1080, "rgb24"),           # 1.5x: four columns per 12-byte window
     ("scale=720:1280", 1080, 1920, "bgra"),

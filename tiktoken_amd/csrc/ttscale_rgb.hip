@@ -354,6 +354,86 @@ constexpr int kRgbMaxPieces = 8;
                  : "v"(waddr), "v"(u32x4_t{o[0], o[1], o[2], o[3]}), "v"(u32x4_t{o[4], o[5], o[6], o[7]}), "v"(r1), "v"(r2) : "memory");
 }
 
+// ---- same size in and out, the fast form: eight pixels of a row PAIR a lane --------------------------------
+// The conversion alone (`format=rgb24` with no scale in the chain, or behind a crop: yuv2rgb_c_24_rgb) is a
+// streaming job: 1.5 bytes in, 3 (4) out per pixel.  A lane takes 8 adjacent pixels of two rows that share a chroma
+// row -- 8 + 8 bytes of luma, 4 + 4 of chroma, as dwords -- and produces 2 x 24 (32) bytes; the chroma terms
+// (three products per sample) serve four pixels, a pixel costs one multiply and three adds, and four channel
+// values become four clipped bytes in two instructions (pack4<16>).  A wave's row goes through the LDS exchange of
+// the strip kernel above, so that every store instruction writes whole sectors.  The host sends here only what
+// fits: no border, a picture that is a multiple of 16 wide, dword-aligned source rows, 16-byte-aligned output
+// rows, frames at a fixed pitch; everything else stays with rgb_unscaled_kernel.
+template <int BPP>
+__global__ __launch_bounds__(kBlock) void rgb_unscaled8_kernel(const RgbFrameArgs a)
+{
+    static_assert(BPP == 3 || BPP == 4, "rgb24 / bgr24 or rgba / bgra");
+    __shared__ __attribute__((aligned(16))) uint8_t xlds[kBlock / 64][64 * 8 * BPP];
+    const int wave = __builtin_amdgcn_readfirstlane(int(threadIdx.x >> 6)), lane = int(threadIdx.x & 63);
+    const int units = a.pw >> 3;                                   // 8-pixel units a row
+    const int wpr = (units + 63) >> 6;                             // waves a row pair
+    const int wid = int(blockIdx.x) * (kBlock / 64) + wave;
+    const int rp = wid / wpr, wx = wid - rp * wpr;
+    if (rp >= (a.ph >> 1)) return;                                 // (whole waves; the kernel has no barrier)
+    const int u = wx * 64 + lane;
+    const bool live = u < units;
+    const int nlive = min(64, units - wx * 64);                    // wave-uniform
+    const uint8_t *sp[3];
+    uint8_t *dp;
+    rgb_frame_bases(a, a.frame0 + int(blockIdx.z), sp, dp);
+    const int sy = a.oy + 2 * rp, sx = a.ox + 8 * u;
+    uint32_t yw[2][2] = {{0, 0}, {0, 0}}, uw = 0, vw = 0;
+    if (live) {
+        const uint32_t *y0 = reinterpret_cast<const uint32_t *>(sp[0] + size_t(sy) * a.src_stride_y + sx);
+        const uint32_t *y1 = reinterpret_cast<const uint32_t *>(sp[0] + size_t(sy + 1) * a.src_stride_y + sx);
+        yw[0][0] = y0[0]; yw[0][1] = y0[1]; yw[1][0] = y1[0]; yw[1][1] = y1[1];
+        const size_t co = size_t(sy >> 1) * a.src_stride_c + (sx >> 1);
+        uw = *reinterpret_cast<const uint32_t *>(sp[1] + co);
+        vw = *reinterpret_cast<const uint32_t *>(sp[2] + co);
+    }
+    const RgbCoef &c = a.coef;
+    int CR[4], CG[4], CB[4];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        const int U = int((uw >> (8 * j)) & 255u), V = int((vw >> (8 * j)) & 255u);
+        const int cr = __mul24((__mul24(V, c.crv) >> 16) + c.off_r, c.cy) + c.k;
+        const int cb = __mul24((__mul24(U, c.cbu) >> 16) + c.off_b, c.cy) + c.k;
+        CG[j] = __mul24((__mul24(U, c.cgu) >> 16) + (__mul24(V, c.cgv) >> 16) + c.off_g, c.cy) + c.k;
+        CR[j] = a.swap ? cb : cr;                                  // (bgr: the first byte of a pixel is B)
+        CB[j] = a.swap ? cr : cb;
+    }
+    const uint32_t xbase = uint32_t(reinterpret_cast<uintptr_t>((rgb_lds_t *)&xlds[wave][0]));
+    const uint32_t xw = xbase + uint32_t(lane) * (8u * BPP);
+    constexpr int kChunks = 64 * 8 * BPP / 16;                     // 16-byte chunks of a full wave's row: 96 / 128
+    const int live_chunks = nlive * 8 * BPP / 16;                  // (a multiple of 3 / of 2: the host sends even unit counts)
+    const int c2 = 64 + lane;
+    const uint32_t xr1 = xbase + 16u * uint32_t(lane), xr2 = xbase + 16u * uint32_t(c2 < kChunks ? c2 : 0);
+    uint8_t *drow = dp + size_t(2 * rp) * a.dst_stride + size_t(wx) * (64 * 8 * BPP);
+#pragma unroll
+    for (int r = 0; r < 2; ++r) {
+        int P[8];
+#pragma unroll
+        for (int i = 0; i < 8; ++i) P[i] = __mul24(int((yw[r][i >> 2] >> (8 * (i & 3))) & 255u), c.cy);
+        u32x4_t v1, v2;
+        if constexpr (BPP == 3) {
+            int v[24];
+#pragma unroll
+            for (int i = 0; i < 8; ++i) { v[3 * i] = P[i] + CR[i / 2]; v[3 * i + 1] = P[i] + CG[i / 2]; v[3 * i + 2] = P[i] + CB[i / 2]; }
+            uint32_t o[6];
+#pragma unroll
+            for (int q = 0; q < 6; ++q) o[q] = pack4<16>(v[4 * q], v[4 * q + 1], v[4 * q + 2], v[4 * q + 3]);
+            rgb_lds_exchange3(xw, o, xr1, xr2, v1, v2);
+        } else {
+            uint32_t o[8];
+#pragma unroll
+            for (int i = 0; i < 8; ++i) o[i] = pack4<16>(P[i] + CR[i / 2], P[i] + CG[i / 2], P[i] + CB[i / 2], 0x7fff0000);   // alpha 255
+            rgb_lds_exchange4(xw, o, xr1, xr2, v1, v2);
+        }
+        uint8_t *d = drow + size_t(r) * a.dst_stride;
+        if (lane < live_chunks) *reinterpret_cast<u32x4_t *>(d + 16 * lane) = v1;
+        if (c2 < live_chunks) *reinterpret_cast<u32x4_t *>(d + 16 * c2) = v2;
+    }
+}
+
 template <int BPP, bool LDS, bool XP>
 __global__ __launch_bounds__(kBlock, 4) void rgb_strip_kernel(const uint8_t *__restrict__ src, uint8_t *__restrict__ dst,
                                                            const uint32_t *__restrict__ tab, const RgbStripArgs a)
@@ -1019,6 +1099,7 @@ struct RgbPlan {
     enum Mode { kUnscaled, kGeneric } mode = kGeneric;
     // the fused strip walk (every axis <= 4 taps, no pad, even crop): tables in HBM, one set per segment length
     bool strip_ok = false;
+    bool unscaled8 = false;               // kUnscaled: rgb_unscaled8_kernel where a launch's addresses allow
     bool convert4 = false;                // in-place conversion: four pixels a thread even where eight fit (TTS_RGB_CONVERT4, A/B)
     bool strip_lds = false;            // ... with the source rows staged through LDS (the runs of any 64 strips fit a 1 KiB slot per plane)
     uint32_t *d_tab = nullptr;
@@ -1186,7 +1267,11 @@ int rgb_plan_create(const tts_geom &g, int n_cus, RgbPlan **out)
     } else if (ctx_sw == ctx_dw && ctx_sh == ctx_dh && !(ctx_dh & 1)) {
         p->mode = RgbPlan::kUnscaled;
         if (ctx_dw & 1) { set_last_error("swscale's unscaled yuv420p -> RGB converter never writes the last column of an odd width: not supported"); rc = TTS_ERR_UNSUPPORTED; }
-        std::snprintf(p->name, sizeof p->name, "rgb_unscaled");
+        // the streaming form where the geometry fits it (the addresses are checked per launch): no border, a
+        // picture that is a multiple of 16 wide, its source rows on the dword grid
+        p->unscaled8 = !p->convert4 && (g.rgb_stage != TTS_RGB_AT_END || (p->cpx == 0 && p->cpy == 0 && 2 * p->cpw == p->pw && 2 * p->cph == p->ph)) && p->px == 0 && p->py == 0 && p->pw == g.out_w && p->ph == g.out_h &&
+                       p->pw % 16 == 0 && p->ph % 2 == 0 && p->ox % 8 == 0 && p->oy % 2 == 0 && g.pre_x % 8 == 0;
+        std::snprintf(p->name, sizeof p->name, p->unscaled8 ? "rgb_unscaled8" : "rgb_unscaled");
     } else {
         if (g.rgb_stage == TTS_RGB_AT_END && (g.do_pad || g.crop_w != g.sc_w || g.crop_h != g.sc_h)) {
             // (cannot happen: crop and pad make the height even, which selects the unscaled converter)
@@ -1292,6 +1377,16 @@ int rgb_launch(const RgbPlan *p, const uint8_t *src, uint8_t *dst, int n, const 
         const int nf = std::min(65535, n - f0);
         f.frame0 = f0;
         if (p->mode == RgbPlan::kUnscaled) {
+            // the streaming form where the geometry and the addresses allow (see the kernel)
+            const bool fast = p->unscaled8 && !addr.use_table &&
+                              reinterpret_cast<uintptr_t>(src) % 4 == 0 && addr.src_pitch % 4 == 0 && addr.src_plane[0] % 4 == 0 &&
+                              addr.src_plane[1] % 4 == 0 && addr.src_plane[2] % 4 == 0 && src_stride[0] % 4 == 0 && src_stride[1] % 4 == 0 &&
+                              reinterpret_cast<uintptr_t>(dst) % 16 == 0 && addr.dst_pitch % 16 == 0 && dst_stride % 16 == 0;
+            if (fast) {
+                const int waves = ((f.pw / 8 + 63) / 64) * (f.ph / 2);
+                rc = launch_rgb("rgb_unscaled8_kernel", p->bpp == 3 ? rgb_unscaled8_kernel<3> : rgb_unscaled8_kernel<4>,
+                                dim3((waves + kBlock / 64 - 1) / (kBlock / 64), 1, nf), dim3(kBlock), 0, st, f);
+            } else
             rc = launch_rgb("rgb_unscaled_kernel", rgb_unscaled_kernel, dim3((f.canvas_w + 255) / 256, (f.canvas_h + 3) / 4, nf), dim3(kBlock), 0, st, f);
         } else {
             RgbGenericArgs a{};

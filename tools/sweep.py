@@ -42,12 +42,15 @@ CASES = {
     # packed rgb24 IN, yuv420p out (the reverse of the above): 3 bytes a pixel read once + the planes written once
     "portrait_rgbin": ("scale=1080:1920:force_original_aspect_ratio=increase,crop=1080:1920", 1920, 1080, 608 * 1080 * 3 + 3110400),
     "stretch_rgbin": ("scale=w=720:h=1280", 480, 854, 480 * 854 * 3 + 1382400),
+    "cvt_rgb24": ("format=rgb24", 1920, 1080, 3110400 + 6220800),                          # conversion alone (yuv2rgb_c_24_rgb)
+    "cvt_rgba": ("format=rgba", 1920, 1080, 3110400 + 8294400),
+    "cvt_rgbin": ("format=yuv420p", 1920, 1080, 6220800 + 3110400),                                  # rgb24 -> yuv420p, no scale
     "web_rgb24": ("scale=720:1280,format=rgb24", 1080, 1920, 3110400 + 2764800),      # 1.5x shrink written as RGB
     "thumbref_rgb24": ("scale=320x180:force_original_aspect_ratio=decrease,pad=320x180:-1:-1:color=black,format=rgb24", 1920, 1080, 3110400 + 172800),
 }
 
 
-IN_FMT = {"portrait_rgbin": "rgb24", "stretch_rgbin": "rgb24"}
+IN_FMT = {"portrait_rgbin": "rgb24", "stretch_rgbin": "rgb24", "cvt_rgbin": "rgb24"}
 
 
 def plan_for(case):
