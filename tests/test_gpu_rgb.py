@@ -301,6 +301,40 @@ RGBIN_CASES = [
 ]
 
 
+RGBIN_WALK_CASES = [
+    ("format=yuv420p", 1920, 1080),                    # the conversion alone: north_star's "YUV420<->RGB colour conversion", RGB in
+    ("format=yuv420p", 1280, 720),
+    ("format=yuv420p", 64, 48),
+    ("format=yuv420p", 72, 35),                        # nine units (one partial wave), odd height: 18 chroma rows out
+    ("format=yuv420p", 520, 8),                        # two waves across, the shortest picture the walk takes
+    ("scale=640:360", 640, 360),                       # a same-size scale is no scale
+    ("crop=320:200:8:6", 640, 360),                    # a crop in front of the conversion: the walk starts inside the frame
+]
+
+
+@pytest.mark.parametrize("vf,iw,ih", RGBIN_WALK_CASES)
+def test_rgb24_input_conversion_alone_streaming_walk(tts, oracle, monkeypatch, vf, iw, ih):
+    """rgb24 -> yuv420p with nothing resized: rgbin_walk_kernel (8 pixel columns a lane down a row segment, chroma's
+    2 : 1 vertical bicubic from a register ring); the tiled kernel (TTS_NO_RGBIN_WALK=1) and the oracle give the same
+    bytes; batches long enough for several row segments and single frames."""
+    import torch
+    walk = tts.Plan.from_vf(vf, iw, ih, in_fmt="rgb24")
+    assert walk.kernel_name(0).startswith("rgbin_walk"), walk.kernel_name(0)
+    monkeypatch.setenv("TTS_NO_RGBIN_WALK", "1")
+    tiled = tts.Plan.from_vf(vf, iw, ih, in_fmt="rgb24")
+    assert not tiled.kernel_name(0).startswith("rgbin_walk"), tiled.kernel_name(0)
+    big = iw * ih > 1000 * 1000
+    for pat, n in (("random", 1), ("impulse", 2), ("random", 2 if big else 40)):
+        src = rgb_frames(pat, iw, ih, n)
+        d = torch.from_numpy(src).cuda()
+        got = walk.run_batch(d).cpu().numpy()
+        want = oracle.run_chain(walk.geom, src[: min(n, 3)])
+        bad = np.flatnonzero(got[: min(n, 3)] != want)
+        assert bad.size == 0, "%s %dx%d %s n=%d: %d bytes differ, first at %d (got %d want %d)" % (
+            vf, iw, ih, pat, n, bad.size, bad[0], got.ravel()[bad[0]], want.ravel()[bad[0]])
+        assert np.array_equal(got, tiled.run_batch(d).cpu().numpy())
+
+
 def rgb_frames(pattern, w, h, n):
     """Packed rgb24 test frames: the three planes of the yuv generator at full size, interleaved."""
     y = synth.frames(pattern, 2 * w, 2 * h, n)         # gives planes of w x h as its chroma

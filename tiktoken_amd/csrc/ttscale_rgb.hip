@@ -1068,6 +1068,129 @@ __global__ __launch_bounds__(kBlock) void rgbin_tile_kernel(const RgbInTileArgs 
     }
 }
 
+// ---- packed rgb24 in, same size out: the conversion alone as a streaming walk ------------------------------
+// `-pix_fmt rgb24` in front of a chain with no scale in it is swscale's ordinary scaler with one-tap filters in
+// three of its four passes -- luma is converted sample by sample -- but the chroma planes still shrink 2 : 1 DOWN
+// the picture (an RGB source has a chroma sample on every row), an 8-tap bicubic.  A lane owns 8 adjacent pixel
+// columns (4 chroma columns) and walks a segment of source rows: 24 bytes in per row, 8 luma bytes out at once, the
+// row's 4 + 4 chroma samples (15-bit, as hScale16To15_c leaves them) into a register ring of 8 rows, kept as row
+// pairs per dword; a chroma output row is emitted when its last source row has entered: 8 sums of 4 v_dot2 over
+// the ring with the row's taps arranged by ring slot (host table), two packs, 4 + 4 bytes out.  Segments start up
+// to 7 rows early to fill the ring.  The host sends here only what fits (rgbin_plan_create / rgbin_launch).
+struct RgbInWalkArgs {
+    const uint8_t *src;
+    uint8_t       *dst;
+    const int32_t *last;               // [ny]: last source row of chroma output row y
+    const uint32_t *vco;               // [ny][4]: its taps by ring slot (source row & 7), as int16 pairs
+    int32_t w, h, ny, vt;              // picture, chroma output rows, vertical chroma taps (<= 8)
+    int32_t seg_rows, nseg;
+    int32_t src_stride, dst_stride[2];
+    uint32_t src_origin;
+    int32_t coef[9];
+    int32_t frame0;
+    FrameAddr addr;
+};
+
+__device__ __forceinline__ int rgbin_lower_bound(const int32_t *last, int n, int v)    // first y with last[y] >= v (uniform)
+{
+    int lo = 0, hi = n;
+    while (lo < hi) { const int mid = (lo + hi) >> 1; if (last[mid] < v) lo = mid + 1; else hi = mid; }
+    return lo;
+}
+
+__global__ __launch_bounds__(kBlock) void rgbin_walk_kernel(const RgbInWalkArgs a)
+{
+    const int wave = __builtin_amdgcn_readfirstlane(int(threadIdx.x >> 6)), lane = int(threadIdx.x & 63);
+    const int units = a.w >> 3, wpr = (units + 63) >> 6;           // 8-pixel units, waves across the picture
+    const int wid = int(blockIdx.x) * (kBlock / 64) + wave;
+    const int seg = wid / wpr, wx = wid - seg * wpr;
+    if (seg >= a.nseg) return;                                     // (whole waves; no barrier in this kernel)
+    const int u = min(wx * 64 + lane, units - 1);                  // dead lanes shadow the last unit and store nothing
+    const bool live = wx * 64 + lane < units;
+    const int frame = a.frame0 + int(blockIdx.z);
+    const uint8_t *sp = a.src + size_t(frame) * a.addr.src_pitch + a.addr.src_plane[0] + a.src_origin + 24 * size_t(u);
+    uint8_t *dpf = a.dst + size_t(frame) * a.addr.dst_pitch;
+    uint8_t *dy = dpf + a.addr.dst_plane[0] + 8 * size_t(u);
+    uint8_t *du = dpf + a.addr.dst_plane[1] + 4 * size_t(u), *dv = dpf + a.addr.dst_plane[2] + 4 * size_t(u);
+    const int ra = seg * a.seg_rows, rb = min(ra + a.seg_rows, a.h);
+    int y = rgbin_lower_bound(a.last, a.ny, ra);
+    const int yend = rgbin_lower_bound(a.last, a.ny, rb);
+    const int rstart = y < yend ? min(int(a.last[y]) - (a.vt - 1), ra) : ra;
+    int next_last = y < yend ? int(a.last[y]) : -1;
+    const int ry = a.coef[0], gy = a.coef[1], by = a.coef[2], ru = a.coef[3], gu = a.coef[4], bu = a.coef[5], rv = a.coef[6], gv = a.coef[7], bv = a.coef[8];
+    uint32_t ring[2][4][4];                                        // plane, chroma column, row pair (slots 2k, 2k + 1)
+#pragma unroll
+    for (int i = 0; i < 32; ++i) (&ring[0][0][0])[i] = 0;
+    u32x2_t nx[3];
+    {
+        const u32x2_t *q = reinterpret_cast<const u32x2_t *>(sp + size_t(rstart) * a.src_stride);
+        nx[0] = q[0]; nx[1] = q[1]; nx[2] = q[2];
+    }
+    for (int r0 = rstart & ~7; r0 < rb; r0 += 8) {
+#pragma unroll
+        for (int s = 0; s < 8; ++s) {
+            const int r = r0 + s;
+            if (r < rstart || r >= rb) continue;                   // wave-uniform
+            const uint32_t w[6] = {nx[0].x, nx[0].y, nx[1].x, nx[1].y, nx[2].x, nx[2].y};
+            {
+                const u32x2_t *q = reinterpret_cast<const u32x2_t *>(sp + size_t(min(r + 1, rb - 1)) * a.src_stride);
+                nx[0] = q[0]; nx[1] = q[1]; nx[2] = q[2];
+            }
+            int R[8], G[8], B[8];
+#pragma unroll
+            for (int i = 0; i < 8; ++i) {
+                const int b0 = 3 * i;
+                R[i] = int((w[b0 >> 2] >> (8 * (b0 & 3))) & 255u);
+                G[i] = int((w[(b0 + 1) >> 2] >> (8 * ((b0 + 1) & 3))) & 255u);
+                B[i] = int((w[(b0 + 2) >> 2] >> (8 * ((b0 + 2) & 3))) & 255u);
+            }
+            if (r >= ra) {
+                // rgb24ToY_c, hScale16To15_c with its one tap of 1 << 14 (x 2, clip), yuv2plane1_8
+                int v[8];
+#pragma unroll
+                for (int i = 0; i < 8; ++i) {
+                    const int s14 = (__mul24(ry, R[i]) + __mul24(gy, G[i]) + __mul24(by, B[i]) + (32 << 14) + (1 << 8)) >> 9;
+                    v[i] = min(2 * s14, 32767) + 64;
+                }
+                const u32x2_t o = {pack4<7>(v[0], v[1], v[2], v[3]), pack4<7>(v[4], v[5], v[6], v[7])};
+                if (live) *reinterpret_cast<u32x2_t *>(dy + size_t(r) * a.dst_stride[0]) = o;
+            }
+            // rgb24ToUV_half_c on the four pixel pairs, hScale16To15_c (one tap), into ring slot r & 7 (= s)
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                const int sr = R[2 * j] + R[2 * j + 1], sg = G[2 * j] + G[2 * j + 1], sb = B[2 * j] + B[2 * j + 1];
+                const int u14 = (__mul24(ru, sr) + __mul24(gu, sg) + __mul24(bu, sb) + (256 << 15) + (1 << 9)) >> 10;
+                const int v14 = (__mul24(rv, sr) + __mul24(gv, sg) + __mul24(bv, sb) + (256 << 15) + (1 << 9)) >> 10;
+                const uint32_t tu = uint32_t(min(2 * u14, 32767)), tv = uint32_t(min(2 * v14, 32767));
+                ring[0][j][s / 2] = (s & 1) ? __builtin_amdgcn_perm(tu, ring[0][j][s / 2], 0x05040100) : __builtin_amdgcn_perm(ring[0][j][s / 2], tu, 0x07060100);
+                ring[1][j][s / 2] = (s & 1) ? __builtin_amdgcn_perm(tv, ring[1][j][s / 2], 0x05040100) : __builtin_amdgcn_perm(ring[1][j][s / 2], tv, 0x07060100);
+            }
+            while (next_last == r) {                               // wave-uniform: chroma output rows this source row completes
+                uint32_t vk[4];
+#pragma unroll
+                for (int k = 0; k < 4; ++k) vk[k] = uni(a.vco[4 * y + k]);
+                int acc[2][4];
+#pragma unroll
+                for (int pl = 0; pl < 2; ++pl)
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) {
+                        int t = 64 << 12;
+#pragma unroll
+                        for (int k = 0; k < 4; ++k) t = dot2(ring[pl][j][k], vk[k], t);
+                        acc[pl][j] = t;
+                    }
+                const uint32_t ou = pack4<19>(acc[0][0], acc[0][1], acc[0][2], acc[0][3]), ov = pack4<19>(acc[1][0], acc[1][1], acc[1][2], acc[1][3]);
+                if (live) {
+                    *reinterpret_cast<uint32_t *>(du + size_t(y) * a.dst_stride[1]) = ou;
+                    *reinterpret_cast<uint32_t *>(dv + size_t(y) * a.dst_stride[1]) = ov;
+                }
+                ++y;
+                next_last = y < yend ? int(a.last[y]) : -1;
+            }
+        }
+    }
+}
+
 template <class T>
 bool upload_vec(T *&dptr, const std::vector<T> &host)
 {
@@ -1460,6 +1583,9 @@ struct RgbInPlan {
     bool tiled = false;
     int th[2] = {0, 0}, sx_max[2] = {0, 0}, sy_max[2] = {0, 0}, tiles_y[2] = {0, 0};
     size_t lds_bytes = 0;
+    // rgbin_walk_kernel (the conversion alone): per chroma output row its last source row, then its taps by ring slot
+    bool walk = false;
+    int32_t *d_walk = nullptr;
     char name[96] = "";
 };
 
@@ -1530,7 +1656,33 @@ int rgbin_plan_create(const tts_geom &g, RgbInPlan **out)
             for (int k = 0; k < 2; ++k) p->lds_bytes = std::max(p->lds_bytes, rgbin_tile_lds(p->sy_max[k], p->sx_max[k], p->th[k], vf[k]->size, k ? 6 : 3));
         }
     }
-    if (p->tiled) std::snprintf(p->name, sizeof p->name, "rgbin_tile<%d,%d>", p->th[0], p->th[1]);
+    // The conversion alone (nothing in the chain resizes, crops or pads): the streaming walk.  Its arithmetic has the
+    // one-tap filters folded in, so they are checked to be exactly that: position i, the full weight.
+    if (!rc && !std::getenv("TTS_FORCE_GENERIC") && !(std::getenv("TTS_NO_RGBIN_WALK") && std::atoi(std::getenv("TTS_NO_RGBIN_WALK")))) {
+        auto identity = [](const AxisFilter &f, int one) {
+            if (f.size != 1) return false;
+            for (size_t i = 0; i < f.pos.size(); ++i) if (f.pos[i] != int(i) || f.taps[i] != one) return false;
+            return true;
+        };
+        auto monotone = [](const std::vector<int32_t> &v) { for (size_t i = 1; i < v.size(); ++i) if (v[i] < v[i - 1]) return false; return true; };
+        const int ny = (g.sc_h + 1) >> 1;
+        if (!g.do_pad && g.sc_w == g.pre_w && g.sc_h == g.pre_h && g.crop_x == 0 && g.crop_y == 0 && g.crop_w == g.sc_w && g.crop_h == g.sc_h &&
+            g.out_w == g.sc_w && g.out_h == g.sc_h && g.pre_w % 8 == 0 && g.pre_h >= 8 && identity(p->lh, 1 << 14) && identity(p->lv, 1 << 12) &&
+            identity(p->ch, 1 << 14) && p->cv.size <= 8 && int(p->cv.pos.size()) == ny && monotone(p->cv.pos)) {
+            const int vt = p->cv.size;
+            std::vector<int32_t> tabw(size_t(ny) * 5);
+            for (int y = 0; y < ny; ++y) {
+                tabw[y] = p->cv.pos[y] + vt - 1;
+                int16_t slot[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+                for (int j = 0; j < vt; ++j) slot[(p->cv.pos[y] + j) & 7] = p->cv.taps[size_t(y) * vt + j];
+                for (int k = 0; k < 4; ++k) tabw[size_t(ny) + 4 * size_t(y) + k] = int32_t(uint32_t(uint16_t(slot[2 * k])) | uint32_t(uint16_t(slot[2 * k + 1])) << 16);
+            }
+            if (!upload_vec(p->d_walk, tabw)) { set_last_error("table upload failed (hipMalloc / hipMemcpy)"); rc = TTS_ERR_INITIALIZATION_FAILED; }
+            else p->walk = true;
+        }
+    }
+    if (p->walk) std::snprintf(p->name, sizeof p->name, "rgbin_walk<%d>", p->cv.size);
+    else if (p->tiled) std::snprintf(p->name, sizeof p->name, "rgbin_tile<%d,%d>", p->th[0], p->th[1]);
     else std::snprintf(p->name, sizeof p->name, "rgbin_generic<%d,%d,%d,%d>", p->lh.size, p->lv.size, p->ch.size, p->cv.size);
     if (rc) { rgbin_plan_destroy(p); return rc; }
     *out = p;
@@ -1541,6 +1693,7 @@ void rgbin_plan_destroy(RgbInPlan *p)
 {
     if (!p) return;
     for (int i = 0; i < 4; ++i) { (void)hipFree(p->d_pos[i]); (void)hipFree(p->d_taps[i]); }
+    (void)hipFree(p->d_walk);
     delete p;
 }
 
@@ -1574,6 +1727,32 @@ int rgbin_launch(const RgbInPlan *p, const uint8_t *src, uint8_t *dst, int n, in
     for (int i = 0; i < 9; ++i) a.coef[i] = coef[i];
     a.addr = addr;
     int rc = TTS_OK;
+    // the conversion alone, frames at a fixed pitch, rows where 8-byte loads and stores may go: the streaming walk
+    if (p->walk && !addr.use_table && only_plane < 0 && reinterpret_cast<uintptr_t>(src) % 8 == 0 && addr.src_pitch % 8 == 0 &&
+        (addr.src_plane[0] + a.src_origin) % 8 == 0 && src_stride % 8 == 0 && reinterpret_cast<uintptr_t>(dst) % 8 == 0 && addr.dst_pitch % 8 == 0 &&
+        addr.dst_plane[0] % 8 == 0 && dst_stride[0] % 8 == 0 && addr.dst_plane[1] % 4 == 0 && addr.dst_plane[2] % 4 == 0 && dst_stride[1] % 4 == 0) {
+        RgbInWalkArgs w{};
+        w.src = src; w.dst = dst;
+        w.ny = (g.sc_h + 1) >> 1;
+        w.last = p->d_walk; w.vco = reinterpret_cast<const uint32_t *>(p->d_walk + w.ny);
+        w.w = g.pre_w; w.h = g.pre_h; w.vt = p->cv.size;
+        w.src_stride = src_stride; w.dst_stride[0] = dst_stride[0]; w.dst_stride[1] = dst_stride[1];
+        w.src_origin = a.src_origin;
+        for (int i = 0; i < 9; ++i) w.coef[i] = coef[i];
+        w.addr = addr;
+        // row segments: enough waves for a few rounds of the chip, none shorter than 32 rows (each starts 7 rows early)
+        const int wpr = (g.pre_w / 8 + 63) / 64;
+        const int64_t want = 4 * 2048;
+        int nseg = int(std::min<int64_t>(std::max<int64_t>(1, (want + int64_t(wpr) * n - 1) / (int64_t(wpr) * n)), std::max(1, g.pre_h / 32)));
+        w.seg_rows = (g.pre_h + nseg - 1) / nseg;
+        w.nseg = (g.pre_h + w.seg_rows - 1) / w.seg_rows;
+        for (int f0 = 0; f0 < n && !rc; f0 += 65535) {
+            w.frame0 = f0;
+            rc = launch_rgb("rgbin_walk_kernel", rgbin_walk_kernel, dim3(unsigned((wpr * w.nseg + kBlock / 64 - 1) / (kBlock / 64)), 1, unsigned(std::min(65535, n - f0))),
+                            dim3(kBlock), 0, st, w);
+        }
+        return rc;
+    }
     for (int f0 = 0; f0 < n && !rc; f0 += 21845) {          // grid.z = frames x 3 planes
         const int nf = std::min(21845, n - f0);
         a.frame0 = f0;
