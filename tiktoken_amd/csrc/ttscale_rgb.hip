@@ -804,7 +804,63 @@ __global__ __launch_bounds__(kScratchThreads) void rgb_scratch_convert4_kernel(c
     }
     __syncthreads();                                               // the workgroup's rows sit in registers: they may be overwritten
     if (!row_ok) return;
-    if (in_rows) {
+    // Eight pixels a thread, an even number of units a row: the arithmetic of rgb_unscaled8_kernel (chroma terms
+    // shared by a sample's pixels, two-instruction packs) and its whole-sector stores through an LDS exchange -- a
+    // wave is 64 adjacent units of ONE row (tpr >= 64), its pixels one string of 1.5 (2) KiB.
+    if (PX == 8 && (units & 1) == 0) {
+        if constexpr (PX == 8) {
+            __shared__ __attribute__((aligned(16))) uint8_t xlds[kScratchThreads / 64][64 * 8 * 4];
+            if (in_rows) {
+                const int wave = __builtin_amdgcn_readfirstlane(int(threadIdx.x >> 6)), lane = int(threadIdx.x & 63);
+                const RgbCoef &c = a.coef;
+                const uint32_t xbase = uint32_t(reinterpret_cast<uintptr_t>((rgb_lds_t *)&xlds[wave][0]));
+                const int ubytes = 8 * a.bpp;                      // bytes of a unit's pixels
+                const uint32_t xw = xbase + uint32_t(lane * ubytes);
+#pragma unroll
+                for (int it = 0; it < kIters; ++it) {
+                    const int base = it * a.tpr + (t - lane);      // the wave's first unit (wave-uniform)
+                    if (base >= units) break;
+                    const int live_chunks = min(64, units - base) * ubytes / 16;
+                    int CR[4], CG[4], CB[4];
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) {
+                        const int U = int((uw[it][0] >> (8 * j)) & 255u), V = int((vw[it][0] >> (8 * j)) & 255u);
+                        const int cr = __mul24((__mul24(V, c.crv) >> 16) + c.off_r, c.cy) + c.k;
+                        const int cb = __mul24((__mul24(U, c.cbu) >> 16) + c.off_b, c.cy) + c.k;
+                        CG[j] = __mul24((__mul24(U, c.cgu) >> 16) + (__mul24(V, c.cgv) >> 16) + c.off_g, c.cy) + c.k;
+                        CR[j] = a.swap ? cb : cr;
+                        CB[j] = a.swap ? cr : cb;
+                    }
+                    int P[8];
+#pragma unroll
+                    for (int i = 0; i < 8; ++i) {
+                        const uint32_t w = yw[it][i >> 1];
+                        P[i] = __mul24(int(int16_t(i & 1 ? w >> 16 : w & 0xffffu)), c.cy);      // (unclipped luma, |Y| < 2^12)
+                    }
+                    u32x4_t v1, v2;
+                    const int c2 = 64 + lane;
+                    uint8_t *d = prow + size_t(base) * ubytes;
+                    if (a.bpp == 3) {                              // (uniform)
+                        int v[24];
+#pragma unroll
+                        for (int i = 0; i < 8; ++i) { v[3 * i] = P[i] + CR[i / 2]; v[3 * i + 1] = P[i] + CG[i / 2]; v[3 * i + 2] = P[i] + CB[i / 2]; }
+                        uint32_t o[6];
+#pragma unroll
+                        for (int q = 0; q < 6; ++q) o[q] = pack4<16>(v[4 * q], v[4 * q + 1], v[4 * q + 2], v[4 * q + 3]);
+                        rgb_lds_exchange3(xw, o, xbase + 16u * uint32_t(lane), xbase + 16u * uint32_t(c2 < 96 ? c2 : 0), v1, v2);
+                    } else {
+                        uint32_t o[8];
+#pragma unroll
+                        for (int i = 0; i < 8; ++i) o[i] = pack4<16>(P[i] + CR[i / 2], P[i] + CG[i / 2], P[i] + CB[i / 2], 0x7fff0000);   // alpha 255
+                        rgb_lds_exchange4(xw, o, xbase + 16u * uint32_t(lane), xbase + 16u * uint32_t(c2), v1, v2);
+                    }
+                    typedef uint32_t u32x4_dw __attribute__((ext_vector_type(4), aligned(4)));     // (picture rows start on a dword, not more)
+                    if (lane < live_chunks) *reinterpret_cast<u32x4_dw *>(d + 16 * lane) = v1;
+                    if (c2 < live_chunks) *reinterpret_cast<u32x4_dw *>(d + 16 * c2) = v2;
+                }
+            }
+        }
+    } else if (in_rows) {
 #pragma unroll
         for (int it = 0; it < kIters; ++it) {
             if (it * a.tpr >= units) break;
