@@ -405,6 +405,54 @@ def test_rgb24_input_through_frame_pointers(tts, oracle, monkeypatch, vf, iw, ih
             assert (g[:, w.shape[1]:] == 9).all(), "wrote into the stride padding"
 
 
+@pytest.mark.parametrize("pad_s,pad_d", [(16, 32), (7, 5)])
+def test_conversion_alone_through_frame_pointers(tts, oracle, pad_s, pad_d):
+    """tts_run, conversion only, both directions: planes of their own, rows padded.  With padding that keeps rows on
+    the grid the streaming kernels need (16, 32) they run; with (7, 5) the general kernels do; same bytes, padding
+    untouched."""
+    import torch
+    iw, ih, n = 320, 64, 4
+    # yuv420p -> rgb24
+    plan = tts.Plan.from_vf("format=rgb24", iw, ih)
+    src = synth.frames("random", iw, ih, n)
+    want = oracle.run_chain(plan.geom, src).reshape(n, ih, iw * 3)
+    keep, sp, ss, dp, ds = [], [], [], [], []
+    for i in range(n):
+        planes, strides = [], []
+        for pl in synth.split(src[i], iw, ih):
+            t = torch.zeros((pl.shape[0], pl.shape[1] + pad_s), dtype=torch.uint8, device="cuda")
+            t[:, : pl.shape[1]] = torch.from_numpy(np.ascontiguousarray(pl)).cuda()
+            keep.append(t); planes.append(t.data_ptr()); strides.append(t.shape[1])
+        o = torch.full((ih, iw * 3 + pad_d), 9, dtype=torch.uint8, device="cuda")
+        keep.append(o)
+        sp.append(planes); ss.append(strides); dp.append(o); ds.append([o.shape[1], 0, 0])
+    plan.run_frames(sp, [[o.data_ptr(), 0, 0] for o in dp], ss, ds)
+    torch.cuda.synchronize()
+    for i in range(n):
+        g = dp[i].cpu().numpy()
+        assert np.array_equal(g[:, : iw * 3], want[i]), ("yuv -> rgb", i)
+        assert (g[:, iw * 3:] == 9).all(), "wrote into the stride padding"
+    # rgb24 -> yuv420p
+    plan = tts.Plan.from_vf("format=yuv420p", iw, ih, in_fmt="rgb24")
+    src = rgb_frames("random", iw, ih, n)
+    want = oracle.run_chain(plan.geom, src)
+    keep, sp, ss, dp, ds = [], [], [], [], []
+    for i in range(n):
+        t = torch.zeros((ih, iw * 3 + pad_s), dtype=torch.uint8, device="cuda")
+        t[:, : iw * 3] = torch.from_numpy(src[i].reshape(ih, iw * 3)).cuda()
+        outs = [torch.full((ih // 2 if k else ih, (iw // 2 if k else iw) + pad_d), 9, dtype=torch.uint8, device="cuda") for k in (0, 1, 1)]
+        keep += [t] + outs
+        sp.append([t.data_ptr(), 0, 0]); ss.append([t.shape[1], 0, 0])
+        dp.append(outs); ds.append([o.shape[1] for o in outs])
+    plan.run_frames(sp, [[o.data_ptr() for o in f] for f in dp], ss, ds)
+    torch.cuda.synchronize()
+    for i in range(n):
+        for k, w in enumerate(synth.split(want[i], iw, ih)):
+            g = dp[i][k].cpu().numpy()
+            assert np.array_equal(g[:, : w.shape[1]], w), ("rgb -> yuv", i, k)
+            assert (g[:, w.shape[1]:] == 9).all(), "wrote into the stride padding"
+
+
 def test_rgb24_input_host_path_and_rejections(tts, oracle):
     plan = tts.Plan.from_vf("scale=96:54", 64, 36, in_fmt="rgb24")
     src = rgb_frames("zone", 64, 36, 5)

@@ -1164,10 +1164,18 @@ __global__ __launch_bounds__(kBlock) void rgbin_walk_kernel(const RgbInWalkArgs 
     const int u = min(wx * 64 + lane, units - 1);                  // dead lanes shadow the last unit and store nothing
     const bool live = wx * 64 + lane < units;
     const int frame = a.frame0 + int(blockIdx.z);
-    const uint8_t *sp = a.src + size_t(frame) * a.addr.src_pitch + a.addr.src_plane[0] + a.src_origin + 24 * size_t(u);
-    uint8_t *dpf = a.dst + size_t(frame) * a.addr.dst_pitch;
-    uint8_t *dy = dpf + a.addr.dst_plane[0] + 8 * size_t(u);
-    uint8_t *du = dpf + a.addr.dst_plane[1] + 4 * size_t(u), *dv = dpf + a.addr.dst_plane[2] + 4 * size_t(u);
+    const uint8_t *sp;
+    uint8_t *dy, *du, *dv;
+    if (a.addr.use_table) {                                        // tts_run: per-frame offsets (at most kMaxTableFrames a launch: frame0 is 0)
+        sp = a.src + a.addr.src_tab[0][frame];
+        dy = a.dst + a.addr.dst_tab[0][frame]; du = a.dst + a.addr.dst_tab[1][frame]; dv = a.dst + a.addr.dst_tab[2][frame];
+    } else {
+        sp = a.src + size_t(frame) * a.addr.src_pitch + a.addr.src_plane[0];
+        uint8_t *dpf = a.dst + size_t(frame) * a.addr.dst_pitch;
+        dy = dpf + a.addr.dst_plane[0]; du = dpf + a.addr.dst_plane[1]; dv = dpf + a.addr.dst_plane[2];
+    }
+    sp += a.src_origin + 24 * size_t(u);
+    dy += 8 * size_t(u); du += 4 * size_t(u); dv += 4 * size_t(u);
     const int ra = seg * a.seg_rows, rb = min(ra + a.seg_rows, a.h);
     int y = rgbin_lower_bound(a.last, a.ny, ra);
     const int yend = rgbin_lower_bound(a.last, a.ny, rb);
@@ -1557,10 +1565,13 @@ int rgb_launch(const RgbPlan *p, const uint8_t *src, uint8_t *dst, int n, const 
         f.frame0 = f0;
         if (p->mode == RgbPlan::kUnscaled) {
             // the streaming form where the geometry and the addresses allow (see the kernel)
-            const bool fast = p->unscaled8 && !addr.use_table &&
-                              reinterpret_cast<uintptr_t>(src) % 4 == 0 && addr.src_pitch % 4 == 0 && addr.src_plane[0] % 4 == 0 &&
-                              addr.src_plane[1] % 4 == 0 && addr.src_plane[2] % 4 == 0 && src_stride[0] % 4 == 0 && src_stride[1] % 4 == 0 &&
-                              reinterpret_cast<uintptr_t>(dst) % 16 == 0 && addr.dst_pitch % 16 == 0 && dst_stride % 16 == 0;
+            bool fast = p->unscaled8 && reinterpret_cast<uintptr_t>(src) % 4 == 0 && src_stride[0] % 4 == 0 && src_stride[1] % 4 == 0 &&
+                        reinterpret_cast<uintptr_t>(dst) % 16 == 0 && dst_stride % 16 == 0;
+            if (fast && addr.use_table) {                            // per-frame pointers: every frame's planes
+                for (int i = f0; i < f0 + nf && fast; ++i)
+                    fast = addr.src_tab[0][i] % 4 == 0 && addr.src_tab[1][i] % 4 == 0 && addr.src_tab[2][i] % 4 == 0 && addr.dst_tab[0][i] % 16 == 0;
+            } else if (fast)
+                fast = addr.src_pitch % 4 == 0 && addr.src_plane[0] % 4 == 0 && addr.src_plane[1] % 4 == 0 && addr.src_plane[2] % 4 == 0 && addr.dst_pitch % 16 == 0;
             if (fast) {
                 const int waves = ((f.pw / 8 + 63) / 64) * (f.ph / 2);
                 rc = launch_rgb("rgb_unscaled8_kernel", p->bpp == 3 ? rgb_unscaled8_kernel<3> : rgb_unscaled8_kernel<4>,
@@ -1784,9 +1795,15 @@ int rgbin_launch(const RgbInPlan *p, const uint8_t *src, uint8_t *dst, int n, in
     a.addr = addr;
     int rc = TTS_OK;
     // the conversion alone, frames at a fixed pitch, rows where 8-byte loads and stores may go: the streaming walk
-    if (p->walk && !addr.use_table && only_plane < 0 && reinterpret_cast<uintptr_t>(src) % 8 == 0 && addr.src_pitch % 8 == 0 &&
-        (addr.src_plane[0] + a.src_origin) % 8 == 0 && src_stride % 8 == 0 && reinterpret_cast<uintptr_t>(dst) % 8 == 0 && addr.dst_pitch % 8 == 0 &&
-        addr.dst_plane[0] % 8 == 0 && dst_stride[0] % 8 == 0 && addr.dst_plane[1] % 4 == 0 && addr.dst_plane[2] % 4 == 0 && dst_stride[1] % 4 == 0) {
+    bool walk = p->walk && only_plane < 0 && reinterpret_cast<uintptr_t>(src) % 8 == 0 && src_stride % 8 == 0 && a.src_origin % 8 == 0 &&
+                reinterpret_cast<uintptr_t>(dst) % 8 == 0 && dst_stride[0] % 8 == 0 && dst_stride[1] % 4 == 0;
+    if (walk && addr.use_table) {
+        for (int i = 0; i < n && walk; ++i)
+            walk = addr.src_tab[0][i] % 8 == 0 && addr.dst_tab[0][i] % 8 == 0 && addr.dst_tab[1][i] % 4 == 0 && addr.dst_tab[2][i] % 4 == 0;
+    } else if (walk)
+        walk = addr.src_pitch % 8 == 0 && addr.src_plane[0] % 8 == 0 && addr.dst_pitch % 8 == 0 && addr.dst_plane[0] % 8 == 0 &&
+               addr.dst_plane[1] % 4 == 0 && addr.dst_plane[2] % 4 == 0;
+    if (walk) {
         RgbInWalkArgs w{};
         w.src = src; w.dst = dst;
         w.ny = (g.sc_h + 1) >> 1;
