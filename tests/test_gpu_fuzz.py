@@ -190,6 +190,40 @@ def test_random_small_shrinks_packed_rgb_out(tts, oracle, seed):
 
 
 @pytest.mark.parametrize("seed", range(int(__import__("os").environ.get("TTS_FUZZ_RGB_SEEDS", "12"))))
+def test_random_conversion_alone_both_directions(tts, oracle, seed):
+    """No scale in the chain: yuv420p -> packed RGB and rgb24 -> yuv420p at random sizes -- widths on and off the grids
+    the streaming kernels need, crops in front, short and long batches (one and many row segments)."""
+    import torch
+    rng = np.random.default_rng(15000 + seed)
+    ran = 0
+    for _ in range(6):
+        iw = int(rng.choice([16, 8, 2])) * int(rng.integers(2, 90))
+        iw = max(16, min(iw, 1440))
+        ih = 2 * int(rng.integers(4, 300))
+        parts = []
+        if rng.random() < 0.3 and iw > 48 and ih > 48:
+            cw, chh = 2 * int(rng.integers(8, iw // 2)), 2 * int(rng.integers(8, ih // 2))
+            parts.append("crop=%d:%d:%d:%d" % (cw, chh, int(rng.choice([8, 2, 1])) * int(rng.integers(0, (iw - cw) // 8 + 1)), int(rng.integers(0, ih - chh + 1))))
+        n = int(rng.choice([1, 2, 9, 33]))
+        for rgb_in in (False, True):
+            vf = ",".join(parts + ["format=" + ("yuv420p" if rgb_in else str(rng.choice(["rgb24", "bgr24", "rgba", "bgra"])))])
+            try:
+                plan = tts.Plan.from_vf(vf, iw, ih, in_fmt="rgb24" if rgb_in else "yuv420p")
+            except tts.TtsError:
+                continue
+            if rgb_in:
+                src = rng.integers(0, 256, (n, iw * ih * 3), dtype=np.uint8)
+            else:
+                src = synth.frames(str(rng.choice(["random", "impulse"])), iw, ih, n)
+            want = oracle.run_chain(plan.geom, src)
+            got = plan.run_batch(torch.from_numpy(src).cuda()).cpu().numpy()
+            bad = np.flatnonzero(got.ravel() != want.ravel())
+            assert bad.size == 0, "%s %dx%d n=%d rgb_in=%s [%s]: %d bytes differ, first at %d" % (vf, iw, ih, n, rgb_in, plan.kernel_name(0), bad.size, bad[0])
+            ran += 1
+    assert ran, "no case ran"
+
+
+@pytest.mark.parametrize("seed", range(int(__import__("os").environ.get("TTS_FUZZ_RGB_SEEDS", "12"))))
 def test_random_geometries_packed_rgb_in(tts, oracle, seed):
     import torch
     rng = np.random.default_rng(11000 + seed)
