@@ -651,7 +651,7 @@ __global__ __launch_bounds__(kBlock, 4) void rgb_strip_kernel(const uint8_t *__r
             for (int i = 0; i < 8; ++i) { v[3 * i] = P[i] + CR[i / 2]; v[3 * i + 1] = P[i] + CG[i / 2]; v[3 * i + 2] = P[i] + CB[i / 2]; }
             uint32_t o[6];
 #pragma unroll
-            for (int q = 0; q < 6; ++q) o[q] = hi2_u8(v[4 * q], v[4 * q + 1]) | (hi2_u8(v[4 * q + 2], v[4 * q + 3]) << 16);
+            for (int q = 0; q < 6; ++q) o[q] = pack4<16>(v[4 * q], v[4 * q + 1], v[4 * q + 2], v[4 * q + 3]);      // (>> 16, clip, pack: two instructions)
             if constexpr (XP) {
                 u32x4_t v1, v2;
                 rgb_lds_exchange3(xw, o, xr1, xr2, v1, v2);
@@ -671,7 +671,7 @@ __global__ __launch_bounds__(kBlock, 4) void rgb_strip_kernel(const uint8_t *__r
             uint32_t o[8];
 #pragma unroll
             for (int i = 0; i < 8; ++i)
-                o[i] = hi2_u8(P[i] + CR[i / 2], P[i] + CG[i / 2]) | (hi2_u8(P[i] + CB[i / 2], 0x7fff0000) << 16);   // alpha 255
+                o[i] = pack4<16>(P[i] + CR[i / 2], P[i] + CG[i / 2], P[i] + CB[i / 2], 0x7fff0000);   // alpha 255
             if constexpr (XP) {
                 u32x4_t v1, v2;
                 rgb_lds_exchange4(xw, o, xr1, xr2, v1, v2);
