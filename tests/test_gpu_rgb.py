@@ -335,6 +335,41 @@ def test_rgb24_input_conversion_alone_streaming_walk(tts, oracle, monkeypatch, v
         assert np.array_equal(got, tiled.run_batch(d).cpu().numpy())
 
 
+RGBIN_STRIP_CASES = [
+    (PORTRAIT, 1920, 1080),                            # the portrait chain from an RGB source: 1.78x, crop inside the scaled picture
+    (PORTRAIT, 1280, 720),                             # 2.67x
+    ("scale=w=720:h=1280", 480, 854),                  # scripts/processVideos.js:96: 1.5x
+    ("scale=1280:720", 640, 360),                      # 2x exactly
+    ("scale=168:96", 64, 36),                          # a partial wave, odd ratios per axis
+    ("scale=720:1280:flags=bilinear", 480, 854),       # 2 taps: windows padded to four
+    ("scale=1000:700,crop=800:500:100:101", 640, 360), # crop at an odd row inside the enlargement
+]
+
+
+@pytest.mark.parametrize("vf,iw,ih", RGBIN_STRIP_CASES)
+def test_rgb24_input_enlargements_strip_walk(tts, oracle, monkeypatch, vf, iw, ih):
+    """rgb24 in, enlarged: rgbin_strip_kernel (the wave converts its run of pixels once per source row into LDS, lanes
+    filter 8 luma + 4 + 4 chroma columns from there into register rings); the tiled kernel (TTS_NO_RGBIN_STRIP=1)
+    and the oracle give the same bytes; one frame and batches cut into several row segments."""
+    import torch
+    strip = tts.Plan.from_vf(vf, iw, ih, in_fmt="rgb24")
+    assert strip.kernel_name(0).startswith("rgbin_strip"), strip.kernel_name(0)
+    monkeypatch.setenv("TTS_NO_RGBIN_STRIP", "1")
+    tiled = tts.Plan.from_vf(vf, iw, ih, in_fmt="rgb24")
+    assert tiled.kernel_name(0).startswith("rgbin_tile"), tiled.kernel_name(0)
+    big = iw * ih > 500 * 1000
+    for pat, n in (("random", 1), ("impulse", 2), ("zone", 2 if big else 24)):
+        src = rgb_frames(pat, iw, ih, n)
+        d = torch.from_numpy(src).cuda()
+        got = strip.run_batch(d).cpu().numpy()
+        m = min(n, 2)
+        want = oracle.run_chain(strip.geom, src[:m])
+        bad = np.flatnonzero(got[:m].ravel() != want.ravel())
+        assert bad.size == 0, "%s %dx%d %s n=%d: %d bytes differ, first at %d (got %d want %d)" % (
+            vf, iw, ih, pat, n, bad.size, bad[0], got[:m].ravel()[bad[0]], want.ravel()[bad[0]])
+        assert np.array_equal(got, tiled.run_batch(d).cpu().numpy())
+
+
 def rgb_frames(pattern, w, h, n):
     """Packed rgb24 test frames: the three planes of the yuv generator at full size, interleaved."""
     y = synth.frames(pattern, 2 * w, 2 * h, n)         # gives planes of w x h as its chroma
@@ -366,6 +401,7 @@ def test_rgb24_input_tiled_and_generic_kernels_agree(tts, oracle, monkeypatch, v
     the one-lane-per-sample kernel stays behind it for tiles that do not fit: same bytes from both."""
     import torch
     src = rgb_frames("random", iw, ih, 4)
+    monkeypatch.setenv("TTS_NO_RGBIN_STRIP", "1")        # (enlargements take the strip walk by default: its own test below)
     tiled = tts.Plan.from_vf(vf, iw, ih, in_fmt="rgb24")
     assert tiled.kernel_name(0).startswith("rgbin_tile"), tiled.kernel_name(0)
     monkeypatch.setenv("TTS_FORCE_GENERIC", "1")

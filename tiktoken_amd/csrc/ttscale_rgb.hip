@@ -1255,6 +1255,205 @@ __global__ __launch_bounds__(kBlock) void rgbin_walk_kernel(const RgbInWalkArgs 
     }
 }
 
+// ---- packed rgb24 in, enlarged: the strip walk on 16-bit samples -----------------------------------------------
+// rgbin_tile_kernel spends its time between barriers.  For enlargements (at most 4 horizontal taps,
+// at most 4 vertical luma taps: the portrait chains from an RGB source) a lane owns 8 luma output columns and the 4
+// chroma columns under them and walks a segment of SOURCE rows, as rgbin_walk_kernel does:
+//   per source row the wave converts the run of pixels its lanes' windows need ONCE -- lane j the pixels 8j .. 8j + 7
+//   of the run (rgb24ToY_c, rgb24ToUV_half_c on its four pairs) -- into three int16 rows in the wave's own LDS;
+//   every lane then reads each column's 4-tap window as three aligned dwords, one v_perm selector per column
+//   undoing the window's halfword parity, and runs hScale16To15_c as two v_dot2 (>> 13, clip to 15 bits) into
+//   register rings kept by ring slot (luma: source row & 3; chroma: & 7 -- an RGB source has chroma on every row,
+//   so that plane shrinks 2 : 1 more than luma and wants up to 8 rows);
+//   output rows whose last source row this was leave: luma 8 sums of 2 v_dot2, chroma 4 + 4 sums of 4, packed.
+// No barrier: a wave's LDS rows are its own, its LDS operations complete in order.
+struct RgbInStripArgs {
+    const uint8_t *src;
+    uint8_t       *dst;
+    const int32_t *tab;
+    uint32_t o_run, o_strip, o_lastl, o_vcol, o_lastc, o_vcoc;      // dword offsets into tab
+    int32_t strips, wpr, oh, och, lvt, cvt, h;                       // 8-column strips a row, waves a row; output rows; vertical taps; source rows
+    int32_t seg_rows, nseg;
+    int32_t src_stride, dst_stride[2];
+    uint32_t src_origin, src_extent;
+    int32_t coef[9];
+    int32_t frame0;
+    FrameAddr addr;
+};
+
+constexpr int kRgbInStripRun = 512;                                   // pixels a wave converts per source row at most (8 a lane)
+
+__global__ __launch_bounds__(kBlock) void rgbin_strip_kernel(const RgbInStripArgs a)
+{
+    __shared__ uint32_t ylds[kBlock / 64][kRgbInStripRun / 2 + 4], ulds[kBlock / 64][kRgbInStripRun / 4 + 4], vlds[kBlock / 64][kRgbInStripRun / 4 + 4];
+    const int wave = __builtin_amdgcn_readfirstlane(int(threadIdx.x >> 6)), lane = int(threadIdx.x & 63);
+    const int wid = int(blockIdx.x) * (kBlock / 64) + wave;
+    const int seg = wid / a.wpr, wx = wid - seg * a.wpr;
+    if (seg >= a.nseg) return;                                     // (whole waves; no barrier in this kernel)
+    const int s0 = wx * 64 + lane;
+    const bool live = s0 < a.strips;
+    const int strip = min(s0, a.strips - 1);                       // dead lanes shadow the last strip and store nothing
+    const int frame = a.frame0 + int(blockIdx.z);
+    const uint8_t *fb;
+    uint8_t *dy, *du, *dv;
+    if (a.addr.use_table) {
+        fb = a.src + a.addr.src_tab[0][frame];
+        dy = a.dst + a.addr.dst_tab[0][frame]; du = a.dst + a.addr.dst_tab[1][frame]; dv = a.dst + a.addr.dst_tab[2][frame];
+    } else {
+        fb = a.src + size_t(frame) * a.addr.src_pitch + a.addr.src_plane[0];
+        uint8_t *dpf = a.dst + size_t(frame) * a.addr.dst_pitch;
+        dy = dpf + a.addr.dst_plane[0]; du = dpf + a.addr.dst_plane[1]; dv = dpf + a.addr.dst_plane[2];
+    }
+    dy += 8 * size_t(strip); du += 4 * size_t(strip); dv += 4 * size_t(strip);
+    const uintptr_t lo = reinterpret_cast<uintptr_t>(fb), hi = lo + a.src_extent;
+    const int run0 = a.tab[a.o_run + 2 * wx], run_px = a.tab[a.o_run + 2 * wx + 1];      // wave-uniform
+    const bool conv = 8 * lane < run_px;
+    const uint8_t *pcol = fb + a.src_origin + 3 * size_t(run0 + 8 * lane);
+    // this lane's windows and taps
+    int li[8], ci[4];
+    uint32_t lsel[8], csel[4], lt[8][2], ct[4][2];
+    {
+        const int32_t *T = a.tab + a.o_strip + 36 * size_t(strip);
+#pragma unroll
+        for (int c = 0; c < 8; ++c) { li[c] = T[c] >> 2; lsel[c] = (T[c] & 2) ? 0x05040302u : 0x03020100u; lt[c][0] = uint32_t(T[8 + 2 * c]); lt[c][1] = uint32_t(T[9 + 2 * c]); }
+#pragma unroll
+        for (int j = 0; j < 4; ++j) { ci[j] = T[24 + j] >> 2; csel[j] = (T[24 + j] & 2) ? 0x05040302u : 0x03020100u; ct[j][0] = uint32_t(T[28 + 2 * j]); ct[j][1] = uint32_t(T[29 + 2 * j]); }
+    }
+    const int32_t *lastl = a.tab + a.o_lastl, *lastc = a.tab + a.o_lastc;
+    const uint32_t *vcol = reinterpret_cast<const uint32_t *>(a.tab + a.o_vcol), *vcoc = reinterpret_cast<const uint32_t *>(a.tab + a.o_vcoc);
+    const int ra = seg * a.seg_rows, rb = min(ra + a.seg_rows, a.h);
+    int yl = rgbin_lower_bound(lastl, a.oh, ra), yc = rgbin_lower_bound(lastc, a.och, ra);
+    const int yle = rgbin_lower_bound(lastl, a.oh, rb), yce = rgbin_lower_bound(lastc, a.och, rb);
+    if (yl >= yle && yc >= yce) return;                            // (wave-uniform) no output row ends in this segment
+    int rstart = ra, rlast = ra;
+    if (yl < yle) { rstart = min(rstart, int(lastl[yl]) - (a.lvt - 1)); rlast = max(rlast, int(lastl[yle - 1])); }
+    if (yc < yce) { rstart = min(rstart, int(lastc[yc]) - (a.cvt - 1)); rlast = max(rlast, int(lastc[yce - 1])); }
+    rstart = max(rstart, 0);
+    int nl = yl < yle ? int(lastl[yl]) : -1, nc = yc < yce ? int(lastc[yc]) : -1;
+    const int ry = a.coef[0], gy = a.coef[1], by = a.coef[2], ru = a.coef[3], gu = a.coef[4], bu = a.coef[5], rv = a.coef[6], gv = a.coef[7], bv = a.coef[8];
+    uint32_t ringl[8][2], ringu[4][4], ringv[4][4];
+#pragma unroll
+    for (int i = 0; i < 16; ++i) { (&ringl[0][0])[i] = 0; (&ringu[0][0])[i] = 0; (&ringv[0][0])[i] = 0; }
+    // a lane's 24 bytes of a source row as the 7 aligned dwords that hold them; outside the frame: byte by byte
+    auto fetch = [&](int r, uint32_t (&raw)[7]) {
+        const uintptr_t p = reinterpret_cast<uintptr_t>(pcol + size_t(r) * a.src_stride), pa = p & ~uintptr_t(3);
+        if (!conv) { for (int k = 0; k < 7; ++k) raw[k] = 0; return; }
+        if (pa >= lo && pa + 28 <= hi) {
+            const uint32_t *q = reinterpret_cast<const uint32_t *>(pa);
+#pragma unroll
+            for (int k = 0; k < 7; ++k) raw[k] = q[k];
+        } else {
+#pragma unroll
+            for (int k = 0; k < 7; ++k) {
+                uint32_t w = 0;
+                for (int b = 0; b < 4; ++b) { const uintptr_t q = pa + 4 * k + b; if (q >= lo && q < hi) w |= uint32_t(*reinterpret_cast<const uint8_t *>(q)) << (8 * b); }
+                raw[k] = w;
+            }
+        }
+    };
+    uint32_t nx[7];
+    fetch(rstart, nx);
+    for (int r0 = rstart & ~7; r0 <= rlast; r0 += 8) {
+#pragma unroll
+        for (int s = 0; s < 8; ++s) {
+            const int r = r0 + s;
+            if (r < rstart || r > rlast) continue;                 // wave-uniform
+            // ---- convert this lane's 8 pixels of the run
+            {
+                const uint32_t ph = uint32_t(reinterpret_cast<uintptr_t>(pcol + size_t(r) * a.src_stride) & 3u);
+                uint32_t w[6];
+#pragma unroll
+                for (int k = 0; k < 6; ++k) w[k] = __builtin_amdgcn_alignbyte(nx[k + 1], nx[k], ph);
+                fetch(min(r + 1, rlast), nx);
+                int R[8], G[8], B[8];
+#pragma unroll
+                for (int i = 0; i < 8; ++i) {
+                    const int b0 = 3 * i;
+                    R[i] = int((w[b0 >> 2] >> (8 * (b0 & 3))) & 255u);
+                    G[i] = int((w[(b0 + 1) >> 2] >> (8 * ((b0 + 1) & 3))) & 255u);
+                    B[i] = int((w[(b0 + 2) >> 2] >> (8 * ((b0 + 2) & 3))) & 255u);
+                }
+                uint32_t yy[4], uu[2], vv[2];
+#pragma unroll
+                for (int i = 0; i < 4; ++i) {
+                    const int y0 = (__mul24(ry, R[2 * i]) + __mul24(gy, G[2 * i]) + __mul24(by, B[2 * i]) + (32 << 14) + (1 << 8)) >> 9;
+                    const int y1 = (__mul24(ry, R[2 * i + 1]) + __mul24(gy, G[2 * i + 1]) + __mul24(by, B[2 * i + 1]) + (32 << 14) + (1 << 8)) >> 9;
+                    yy[i] = uint32_t(y0) | uint32_t(y1) << 16;                      // (14-bit values: no sign to keep)
+                }
+                int u14[4], v14[4];
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    const int sr = R[2 * j] + R[2 * j + 1], sg = G[2 * j] + G[2 * j + 1], sb = B[2 * j] + B[2 * j + 1];
+                    u14[j] = (__mul24(ru, sr) + __mul24(gu, sg) + __mul24(bu, sb) + (256 << 15) + (1 << 9)) >> 10;
+                    v14[j] = (__mul24(rv, sr) + __mul24(gv, sg) + __mul24(bv, sb) + (256 << 15) + (1 << 9)) >> 10;
+                }
+                uu[0] = uint32_t(u14[0]) | uint32_t(u14[1]) << 16; uu[1] = uint32_t(u14[2]) | uint32_t(u14[3]) << 16;
+                vv[0] = uint32_t(v14[0]) | uint32_t(v14[1]) << 16; vv[1] = uint32_t(v14[2]) | uint32_t(v14[3]) << 16;
+                if (conv) {
+#pragma unroll
+                    for (int k = 0; k < 4; ++k) ylds[wave][4 * lane + k] = yy[k];
+                    ulds[wave][2 * lane] = uu[0]; ulds[wave][2 * lane + 1] = uu[1];
+                    vlds[wave][2 * lane] = vv[0]; vlds[wave][2 * lane + 1] = vv[1];
+                }
+            }
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+            __builtin_amdgcn_wave_barrier();
+            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+            // ---- hScale16To15_c from the wave's rows into the rings
+#pragma unroll
+            for (int c = 0; c < 8; ++c) {
+                const uint32_t d0 = ylds[wave][li[c]], d1 = ylds[wave][li[c] + 1], d2 = ylds[wave][li[c] + 2];
+                const int acc = dot2(__builtin_amdgcn_perm(d1, d0, lsel[c]), lt[c][0], dot2(__builtin_amdgcn_perm(d2, d1, lsel[c]), lt[c][1], 0)) >> 13;
+                const uint32_t t = uint32_t(min(acc, 32767));
+                ringl[c][(s & 3) / 2] = (s & 1) ? __builtin_amdgcn_perm(t, ringl[c][(s & 3) / 2], 0x05040100) : __builtin_amdgcn_perm(ringl[c][(s & 3) / 2], t, 0x07060100);
+            }
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                const uint32_t u0 = ulds[wave][ci[j]], u1 = ulds[wave][ci[j] + 1], u2 = ulds[wave][ci[j] + 2];
+                const uint32_t v0 = vlds[wave][ci[j]], v1 = vlds[wave][ci[j] + 1], v2 = vlds[wave][ci[j] + 2];
+                const int au = dot2(__builtin_amdgcn_perm(u1, u0, csel[j]), ct[j][0], dot2(__builtin_amdgcn_perm(u2, u1, csel[j]), ct[j][1], 0)) >> 13;
+                const int av = dot2(__builtin_amdgcn_perm(v1, v0, csel[j]), ct[j][0], dot2(__builtin_amdgcn_perm(v2, v1, csel[j]), ct[j][1], 0)) >> 13;
+                const uint32_t tu = uint32_t(min(au, 32767)), tv = uint32_t(min(av, 32767));
+                ringu[j][s / 2] = (s & 1) ? __builtin_amdgcn_perm(tu, ringu[j][s / 2], 0x05040100) : __builtin_amdgcn_perm(ringu[j][s / 2], tu, 0x07060100);
+                ringv[j][s / 2] = (s & 1) ? __builtin_amdgcn_perm(tv, ringv[j][s / 2], 0x05040100) : __builtin_amdgcn_perm(ringv[j][s / 2], tv, 0x07060100);
+            }
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");     // (the next row's conversion overwrites the wave's LDS rows)
+            __builtin_amdgcn_wave_barrier();
+            // ---- output rows this source row completes
+            while (nl == r) {                                      // wave-uniform
+                const uint32_t k0 = uni(vcol[2 * yl]), k1 = uni(vcol[2 * yl + 1]);
+                int v[8];
+#pragma unroll
+                for (int c = 0; c < 8; ++c) v[c] = dot2(ringl[c][1], k1, dot2(ringl[c][0], k0, 64 << 12));
+                const u32x2_t o = {pack4<19>(v[0], v[1], v[2], v[3]), pack4<19>(v[4], v[5], v[6], v[7])};
+                if (live) *reinterpret_cast<u32x2_t *>(dy + size_t(yl) * a.dst_stride[0]) = o;
+                ++yl;
+                nl = yl < yle ? int(lastl[yl]) : -1;
+            }
+            while (nc == r) {
+                uint32_t vk[4];
+#pragma unroll
+                for (int k = 0; k < 4; ++k) vk[k] = uni(vcoc[4 * yc + k]);
+                int au[4], av[4];
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    int tu = 64 << 12, tv = 64 << 12;
+#pragma unroll
+                    for (int k = 0; k < 4; ++k) { tu = dot2(ringu[j][k], vk[k], tu); tv = dot2(ringv[j][k], vk[k], tv); }
+                    au[j] = tu; av[j] = tv;
+                }
+                const uint32_t ou = pack4<19>(au[0], au[1], au[2], au[3]), ov = pack4<19>(av[0], av[1], av[2], av[3]);
+                if (live) {
+                    *reinterpret_cast<uint32_t *>(du + size_t(yc) * a.dst_stride[1]) = ou;
+                    *reinterpret_cast<uint32_t *>(dv + size_t(yc) * a.dst_stride[1]) = ov;
+                }
+                ++yc;
+                nc = yc < yce ? int(lastc[yc]) : -1;
+            }
+        }
+    }
+}
+
 template <class T>
 bool upload_vec(T *&dptr, const std::vector<T> &host)
 {
@@ -1653,6 +1852,11 @@ struct RgbInPlan {
     // rgbin_walk_kernel (the conversion alone): per chroma output row its last source row, then its taps by ring slot
     bool walk = false;
     int32_t *d_walk = nullptr;
+    // rgbin_strip_kernel (enlargements): runs per wave column, per-strip windows and taps, vertical tables
+    bool strip = false;
+    int32_t *d_strip = nullptr;
+    uint32_t so_run = 0, so_strip = 0, so_lastl = 0, so_vcol = 0, so_lastc = 0, so_vcoc = 0;
+    int strips = 0, wpr = 0;
     char name[96] = "";
 };
 
@@ -1748,7 +1952,77 @@ int rgbin_plan_create(const tts_geom &g, RgbInPlan **out)
             else p->walk = true;
         }
     }
+    // Enlargements (<= 4 taps across, <= 4 luma taps down): the strip walk on 16-bit samples, if every wave's run of
+    // source pixels fits what its 64 lanes convert per row
+    if (!rc && !p->walk && !std::getenv("TTS_FORCE_GENERIC") && !(std::getenv("TTS_NO_RGBIN_STRIP") && std::atoi(std::getenv("TTS_NO_RGBIN_STRIP")))) {
+        auto monotone = [](const std::vector<int32_t> &v) { for (size_t i = 1; i < v.size(); ++i) if (v[i] < v[i - 1]) return false; return true; };
+        const int lht = p->lh.size, cht = p->ch.size, lvt = p->lv.size, cvt = p->cv.size;
+        bool ok = !g.do_pad && g.out_w == g.crop_w && g.out_h == g.crop_h && g.out_w % 8 == 0 && g.out_w >= 8 && lht <= 4 && cht <= 4 && lvt <= 4 && cvt <= 8 &&
+                  g.pre_h >= 8 && monotone(p->lh.pos) && monotone(p->ch.pos) && monotone(p->lv.pos) && monotone(p->cv.pos);
+        if (ok) {
+            const int ox = g.crop_x, oy = g.crop_y, oxc = g.crop_x >> 1, oyc = g.crop_y >> 1;
+            const int strips = g.out_w / 8, wpr = (strips + 63) / 64, oh = g.out_h, och = (g.out_h + 1) >> 1;
+            ok = ox + g.out_w <= int(p->lh.pos.size()) && oxc + g.out_w / 2 <= int(p->ch.pos.size()) && oy + oh <= int(p->lv.pos.size()) && oyc + och <= int(p->cv.pos.size());
+            std::vector<int32_t> t;
+            std::vector<int> run0(size_t(wpr), 0);
+            p->so_run = 0;
+            t.resize(size_t(2) * wpr);
+            for (int wx = 0; wx < wpr && ok; ++wx) {
+                const int first = 64 * wx, last = std::min(strips, first + 64) - 1;
+                const int lmin = p->lh.pos[ox + 8 * first], lmax = p->lh.pos[ox + 8 * last + 7] + 4;
+                const int cmin = 2 * p->ch.pos[oxc + 4 * first], cmax = 2 * (p->ch.pos[oxc + 4 * last + 3] + 4);
+                run0[wx] = std::min(lmin, cmin) & ~1;
+                const int len = std::max(lmax, cmax) - run0[wx];
+                if (len > kRgbInStripRun) ok = false;
+                t[2 * size_t(wx)] = run0[wx]; t[2 * size_t(wx) + 1] = len;
+            }
+            if (ok) {
+                auto pk = [](int a0, int a1) { return int32_t(uint32_t(uint16_t(int16_t(a0))) | uint32_t(uint16_t(int16_t(a1))) << 16); };
+                p->so_strip = uint32_t(t.size());
+                t.resize(t.size() + size_t(36) * strips, 0);
+                for (int sidx = 0; sidx < strips; ++sidx) {
+                    int32_t *T = t.data() + p->so_strip + size_t(36) * sidx;
+                    const int r0 = run0[sidx / 64];
+                    for (int c = 0; c < 8; ++c) {
+                        const int vx = ox + 8 * sidx + c;
+                        int tp[4] = {0, 0, 0, 0};
+                        for (int k = 0; k < lht; ++k) tp[k] = p->lh.taps[size_t(vx) * lht + k];
+                        T[c] = 2 * (p->lh.pos[vx] - r0);
+                        T[8 + 2 * c] = pk(tp[0], tp[1]); T[9 + 2 * c] = pk(tp[2], tp[3]);
+                    }
+                    for (int j = 0; j < 4; ++j) {
+                        const int vx = oxc + 4 * sidx + j;
+                        int tp[4] = {0, 0, 0, 0};
+                        for (int k = 0; k < cht; ++k) tp[k] = p->ch.taps[size_t(vx) * cht + k];
+                        T[24 + j] = 2 * (p->ch.pos[vx] - r0 / 2);
+                        T[28 + 2 * j] = pk(tp[0], tp[1]); T[29 + 2 * j] = pk(tp[2], tp[3]);
+                    }
+                }
+                p->so_lastl = uint32_t(t.size()); t.resize(t.size() + oh);
+                p->so_vcol = uint32_t(t.size()); t.resize(t.size() + size_t(2) * oh);
+                for (int y = 0; y < oh; ++y) {
+                    const int pos = p->lv.pos[oy + y];
+                    int slot[4] = {0, 0, 0, 0};
+                    for (int j = 0; j < lvt; ++j) slot[(pos + j) & 3] = p->lv.taps[size_t(oy + y) * lvt + j];
+                    t[p->so_lastl + y] = pos + lvt - 1;
+                    t[p->so_vcol + 2 * size_t(y)] = pk(slot[0], slot[1]); t[p->so_vcol + 2 * size_t(y) + 1] = pk(slot[2], slot[3]);
+                }
+                p->so_lastc = uint32_t(t.size()); t.resize(t.size() + och);
+                p->so_vcoc = uint32_t(t.size()); t.resize(t.size() + size_t(4) * och);
+                for (int y = 0; y < och; ++y) {
+                    const int pos = p->cv.pos[oyc + y];
+                    int slot[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+                    for (int j = 0; j < cvt; ++j) slot[(pos + j) & 7] = p->cv.taps[size_t(oyc + y) * cvt + j];
+                    t[p->so_lastc + y] = pos + cvt - 1;
+                    for (int k = 0; k < 4; ++k) t[p->so_vcoc + 4 * size_t(y) + k] = pk(slot[2 * k], slot[2 * k + 1]);
+                }
+                if (!upload_vec(p->d_strip, t)) { set_last_error("table upload failed (hipMalloc / hipMemcpy)"); rc = TTS_ERR_INITIALIZATION_FAILED; }
+                else { p->strip = true; p->strips = strips; p->wpr = wpr; }
+            }
+        }
+    }
     if (p->walk) std::snprintf(p->name, sizeof p->name, "rgbin_walk<%d>", p->cv.size);
+    else if (p->strip) std::snprintf(p->name, sizeof p->name, "rgbin_strip<%d,%d,%d,%d>", p->lh.size, p->lv.size, p->ch.size, p->cv.size);
     else if (p->tiled) std::snprintf(p->name, sizeof p->name, "rgbin_tile<%d,%d>", p->th[0], p->th[1]);
     else std::snprintf(p->name, sizeof p->name, "rgbin_generic<%d,%d,%d,%d>", p->lh.size, p->lv.size, p->ch.size, p->cv.size);
     if (rc) { rgbin_plan_destroy(p); return rc; }
@@ -1760,7 +2034,7 @@ void rgbin_plan_destroy(RgbInPlan *p)
 {
     if (!p) return;
     for (int i = 0; i < 4; ++i) { (void)hipFree(p->d_pos[i]); (void)hipFree(p->d_taps[i]); }
-    (void)hipFree(p->d_walk);
+    (void)hipFree(p->d_walk); (void)hipFree(p->d_strip);
     delete p;
 }
 
@@ -1822,6 +2096,32 @@ int rgbin_launch(const RgbInPlan *p, const uint8_t *src, uint8_t *dst, int n, in
         for (int f0 = 0; f0 < n && !rc; f0 += 65535) {
             w.frame0 = f0;
             rc = launch_rgb("rgbin_walk_kernel", rgbin_walk_kernel, dim3(unsigned((wpr * w.nseg + kBlock / 64 - 1) / (kBlock / 64)), 1, unsigned(std::min(65535, n - f0))),
+                            dim3(kBlock), 0, st, w);
+        }
+        return rc;
+    }
+    // enlargements: the strip walk on 16-bit samples, where the output rows lie on the grid its stores need
+    bool strip = p->strip && only_plane < 0 && reinterpret_cast<uintptr_t>(dst) % 8 == 0 && dst_stride[0] % 8 == 0 && dst_stride[1] % 4 == 0;
+    if (strip && addr.use_table) {
+        for (int i = 0; i < n && strip; ++i) strip = addr.dst_tab[0][i] % 8 == 0 && addr.dst_tab[1][i] % 4 == 0 && addr.dst_tab[2][i] % 4 == 0;
+    } else if (strip)
+        strip = addr.dst_pitch % 8 == 0 && addr.dst_plane[0] % 8 == 0 && addr.dst_plane[1] % 4 == 0 && addr.dst_plane[2] % 4 == 0;
+    if (strip) {
+        RgbInStripArgs w{};
+        w.src = src; w.dst = dst; w.tab = p->d_strip;
+        w.o_run = p->so_run; w.o_strip = p->so_strip; w.o_lastl = p->so_lastl; w.o_vcol = p->so_vcol; w.o_lastc = p->so_lastc; w.o_vcoc = p->so_vcoc;
+        w.strips = p->strips; w.wpr = p->wpr; w.oh = g.out_h; w.och = (g.out_h + 1) >> 1; w.lvt = p->lv.size; w.cvt = p->cv.size; w.h = g.pre_h;
+        w.src_stride = src_stride; w.dst_stride[0] = dst_stride[0]; w.dst_stride[1] = dst_stride[1];
+        w.src_origin = a.src_origin; w.src_extent = a.src_extent;
+        for (int i = 0; i < 9; ++i) w.coef[i] = coef[i];
+        w.addr = addr;
+        const int64_t want = 4 * 3072;                             // waves for a few rounds of the chip at 3 a SIMD
+        int nseg = int(std::min<int64_t>(std::max<int64_t>(1, (want + int64_t(p->wpr) * n - 1) / (int64_t(p->wpr) * n)), std::max(1, g.pre_h / 32)));
+        w.seg_rows = (g.pre_h + nseg - 1) / nseg;
+        w.nseg = (g.pre_h + w.seg_rows - 1) / w.seg_rows;
+        for (int f0 = 0; f0 < n && !rc; f0 += 65535) {
+            w.frame0 = f0;
+            rc = launch_rgb("rgbin_strip_kernel", rgbin_strip_kernel, dim3(unsigned((p->wpr * w.nseg + kBlock / 64 - 1) / (kBlock / 64)), 1, unsigned(std::min(65535, n - f0))),
                             dim3(kBlock), 0, st, w);
         }
         return rc;
