@@ -1282,10 +1282,14 @@ struct RgbInStripArgs {
 };
 
 constexpr int kRgbInStripRun = 512;                                   // pixels a wave converts per source row at most (8 a lane)
+constexpr int kRgbInStripYB = kRgbInStripRun / 2 + 4, kRgbInStripCB = kRgbInStripRun / 4 + 4;   // dwords of one copy of a luma / chroma row (the odd copy starts one dword in)
 
-__global__ __launch_bounds__(kBlock) void rgbin_strip_kernel(const RgbInStripArgs a)
+template <int OCC>                                                     // waves a SIMD the register budget is cut to
+__global__ __launch_bounds__(kBlock, OCC) void rgbin_strip_kernel(const RgbInStripArgs a)
 {
-    __shared__ uint32_t ylds[kBlock / 64][kRgbInStripRun / 2 + 4], ulds[kBlock / 64][kRgbInStripRun / 4 + 4], vlds[kBlock / 64][kRgbInStripRun / 4 + 4];
+    // every row twice: as pairs (s0 s1)(s2 s3).. and, one halfword on, as (s1 s2)(s3 s4)..: a window that starts on an
+    // odd sample reads the second copy, so that every tap pair of every window is ONE aligned dword (no v_perm)
+    __shared__ uint32_t ylds[kBlock / 64][2 * kRgbInStripYB], ulds[kBlock / 64][2 * kRgbInStripCB], vlds[kBlock / 64][2 * kRgbInStripCB];
     const int wave = __builtin_amdgcn_readfirstlane(int(threadIdx.x >> 6)), lane = int(threadIdx.x & 63);
     const int wid = int(blockIdx.x) * (kBlock / 64) + wave;
     const int seg = wid / a.wpr, wx = wid - seg * a.wpr;
@@ -1310,14 +1314,14 @@ __global__ __launch_bounds__(kBlock) void rgbin_strip_kernel(const RgbInStripArg
     const bool conv = 8 * lane < run_px;
     const uint8_t *pcol = fb + a.src_origin + 3 * size_t(run0 + 8 * lane);
     // this lane's windows and taps
-    int li[8], ci[4];
-    uint32_t lsel[8], csel[4], lt[8][2], ct[4][2];
+    int li[8], ci[4];                                              // first dword of each window, in the copy its parity picks (host)
+    uint32_t lt[8][2], ct[4][2];
     {
         const int32_t *T = a.tab + a.o_strip + 36 * size_t(strip);
 #pragma unroll
-        for (int c = 0; c < 8; ++c) { li[c] = T[c] >> 2; lsel[c] = (T[c] & 2) ? 0x05040302u : 0x03020100u; lt[c][0] = uint32_t(T[8 + 2 * c]); lt[c][1] = uint32_t(T[9 + 2 * c]); }
+        for (int c = 0; c < 8; ++c) { li[c] = T[c]; lt[c][0] = uint32_t(T[8 + 2 * c]); lt[c][1] = uint32_t(T[9 + 2 * c]); }
 #pragma unroll
-        for (int j = 0; j < 4; ++j) { ci[j] = T[24 + j] >> 2; csel[j] = (T[24 + j] & 2) ? 0x05040302u : 0x03020100u; ct[j][0] = uint32_t(T[28 + 2 * j]); ct[j][1] = uint32_t(T[29 + 2 * j]); }
+        for (int j = 0; j < 4; ++j) { ci[j] = T[24 + j]; ct[j][0] = uint32_t(T[28 + 2 * j]); ct[j][1] = uint32_t(T[29 + 2 * j]); }
     }
     const int32_t *lastl = a.tab + a.o_lastl, *lastc = a.tab + a.o_lastc;
     const uint32_t *vcol = reinterpret_cast<const uint32_t *>(a.tab + a.o_vcol), *vcoc = reinterpret_cast<const uint32_t *>(a.tab + a.o_vcoc);
@@ -1394,6 +1398,18 @@ __global__ __launch_bounds__(kBlock) void rgbin_strip_kernel(const RgbInStripArg
                     for (int k = 0; k < 4; ++k) ylds[wave][4 * lane + k] = yy[k];
                     ulds[wave][2 * lane] = uu[0]; ulds[wave][2 * lane + 1] = uu[1];
                     vlds[wave][2 * lane] = vv[0]; vlds[wave][2 * lane + 1] = vv[1];
+                    // the odd copies: dword m = (s[2m + 1], s[2m + 2]); its first and last halfword belong to the neighbours' dwords
+                    uint32_t *yb = &ylds[wave][kRgbInStripYB + 1 + 4 * lane], *ub = &ulds[wave][kRgbInStripCB + 1 + 2 * lane], *vb = &vlds[wave][kRgbInStripCB + 1 + 2 * lane];
+                    reinterpret_cast<uint16_t *>(yb - 1)[1] = uint16_t(yy[0]);
+#pragma unroll
+                    for (int k = 0; k < 3; ++k) yb[k] = __builtin_amdgcn_perm(yy[k + 1], yy[k], 0x05040302);
+                    reinterpret_cast<uint16_t *>(yb + 3)[0] = uint16_t(yy[3] >> 16);
+                    reinterpret_cast<uint16_t *>(ub - 1)[1] = uint16_t(uu[0]);
+                    ub[0] = __builtin_amdgcn_perm(uu[1], uu[0], 0x05040302);
+                    reinterpret_cast<uint16_t *>(ub + 1)[0] = uint16_t(uu[1] >> 16);
+                    reinterpret_cast<uint16_t *>(vb - 1)[1] = uint16_t(vv[0]);
+                    vb[0] = __builtin_amdgcn_perm(vv[1], vv[0], 0x05040302);
+                    reinterpret_cast<uint16_t *>(vb + 1)[0] = uint16_t(vv[1] >> 16);
                 }
             }
             __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
@@ -1402,17 +1418,14 @@ __global__ __launch_bounds__(kBlock) void rgbin_strip_kernel(const RgbInStripArg
             // ---- hScale16To15_c from the wave's rows into the rings
 #pragma unroll
             for (int c = 0; c < 8; ++c) {
-                const uint32_t d0 = ylds[wave][li[c]], d1 = ylds[wave][li[c] + 1], d2 = ylds[wave][li[c] + 2];
-                const int acc = dot2(__builtin_amdgcn_perm(d1, d0, lsel[c]), lt[c][0], dot2(__builtin_amdgcn_perm(d2, d1, lsel[c]), lt[c][1], 0)) >> 13;
+                const int acc = dot2(ylds[wave][li[c]], lt[c][0], dot2(ylds[wave][li[c] + 1], lt[c][1], 0)) >> 13;
                 const uint32_t t = uint32_t(min(acc, 32767));
                 ringl[c][(s & 3) / 2] = (s & 1) ? __builtin_amdgcn_perm(t, ringl[c][(s & 3) / 2], 0x05040100) : __builtin_amdgcn_perm(ringl[c][(s & 3) / 2], t, 0x07060100);
             }
 #pragma unroll
             for (int j = 0; j < 4; ++j) {
-                const uint32_t u0 = ulds[wave][ci[j]], u1 = ulds[wave][ci[j] + 1], u2 = ulds[wave][ci[j] + 2];
-                const uint32_t v0 = vlds[wave][ci[j]], v1 = vlds[wave][ci[j] + 1], v2 = vlds[wave][ci[j] + 2];
-                const int au = dot2(__builtin_amdgcn_perm(u1, u0, csel[j]), ct[j][0], dot2(__builtin_amdgcn_perm(u2, u1, csel[j]), ct[j][1], 0)) >> 13;
-                const int av = dot2(__builtin_amdgcn_perm(v1, v0, csel[j]), ct[j][0], dot2(__builtin_amdgcn_perm(v2, v1, csel[j]), ct[j][1], 0)) >> 13;
+                const int au = dot2(ulds[wave][ci[j]], ct[j][0], dot2(ulds[wave][ci[j] + 1], ct[j][1], 0)) >> 13;
+                const int av = dot2(vlds[wave][ci[j]], ct[j][0], dot2(vlds[wave][ci[j] + 1], ct[j][1], 0)) >> 13;
                 const uint32_t tu = uint32_t(min(au, 32767)), tv = uint32_t(min(av, 32767));
                 ringu[j][s / 2] = (s & 1) ? __builtin_amdgcn_perm(tu, ringu[j][s / 2], 0x05040100) : __builtin_amdgcn_perm(ringu[j][s / 2], tu, 0x07060100);
                 ringv[j][s / 2] = (s & 1) ? __builtin_amdgcn_perm(tv, ringv[j][s / 2], 0x05040100) : __builtin_amdgcn_perm(ringv[j][s / 2], tv, 0x07060100);
@@ -1987,14 +2000,16 @@ int rgbin_plan_create(const tts_geom &g, RgbInPlan **out)
                         const int vx = ox + 8 * sidx + c;
                         int tp[4] = {0, 0, 0, 0};
                         for (int k = 0; k < lht; ++k) tp[k] = p->lh.taps[size_t(vx) * lht + k];
-                        T[c] = 2 * (p->lh.pos[vx] - r0);
+                        const int h = p->lh.pos[vx] - r0;                          // first sample of the window; odd: the second copy
+                        T[c] = (h & 1) ? kRgbInStripYB + 1 + (h >> 1) : (h >> 1);
                         T[8 + 2 * c] = pk(tp[0], tp[1]); T[9 + 2 * c] = pk(tp[2], tp[3]);
                     }
                     for (int j = 0; j < 4; ++j) {
                         const int vx = oxc + 4 * sidx + j;
                         int tp[4] = {0, 0, 0, 0};
                         for (int k = 0; k < cht; ++k) tp[k] = p->ch.taps[size_t(vx) * cht + k];
-                        T[24 + j] = 2 * (p->ch.pos[vx] - r0 / 2);
+                        const int h = p->ch.pos[vx] - r0 / 2;
+                        T[24 + j] = (h & 1) ? kRgbInStripCB + 1 + (h >> 1) : (h >> 1);
                         T[28 + 2 * j] = pk(tp[0], tp[1]); T[29 + 2 * j] = pk(tp[2], tp[3]);
                     }
                 }
@@ -2121,7 +2136,8 @@ int rgbin_launch(const RgbInPlan *p, const uint8_t *src, uint8_t *dst, int n, in
         w.nseg = (g.pre_h + w.seg_rows - 1) / w.seg_rows;
         for (int f0 = 0; f0 < n && !rc; f0 += 65535) {
             w.frame0 = f0;
-            rc = launch_rgb("rgbin_strip_kernel", rgbin_strip_kernel, dim3(unsigned((p->wpr * w.nseg + kBlock / 64 - 1) / (kBlock / 64)), 1, unsigned(std::min(65535, n - f0))),
+            const int occ = std::getenv("TTS_RGBIN_STRIP_OCC") ? std::atoi(std::getenv("TTS_RGBIN_STRIP_OCC")) : 3;   // (A/B)
+            rc = launch_rgb("rgbin_strip_kernel", occ == 2 ? rgbin_strip_kernel<2> : occ == 4 ? rgbin_strip_kernel<4> : rgbin_strip_kernel<3>, dim3(unsigned((p->wpr * w.nseg + kBlock / 64 - 1) / (kBlock / 64)), 1, unsigned(std::min(65535, n - f0))),
                             dim3(kBlock), 0, st, w);
         }
         return rc;
