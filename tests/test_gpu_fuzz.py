@@ -190,6 +190,43 @@ def test_random_small_shrinks_packed_rgb_out(tts, oracle, seed):
 
 
 @pytest.mark.parametrize("seed", range(int(__import__("os").environ.get("TTS_FUZZ_RGB_SEEDS", "12"))))
+def test_random_enlargements_packed_rgb_in(tts, oracle, seed):
+    """rgb24 in, enlarged by 1.05x .. 4x an axis (independently), output widths on and off the strip walk's grid, crops
+    inside the enlarged picture at odd offsets, bilinear now and then; batches of one and of many row segments."""
+    import torch
+    rng = np.random.default_rng(18000 + seed)
+    ran = strip = 0
+    for _ in range(6):
+        iw, ih = 2 * int(rng.integers(8, 330)), 2 * int(rng.integers(6, 200))
+        ow = int(iw * rng.uniform(1.05, 4.0))
+        if rng.random() < 0.8:
+            ow = max(8, ow // 8 * 8)
+        oh = max(8, int(ih * rng.uniform(1.05, 4.0)))
+        parts = ["scale=%d:%d%s" % (ow, oh, rng.choice(["", "", ":flags=bilinear"]))]
+        if rng.random() < 0.35:
+            cw = max(8, int(rng.integers(8, ow + 1)) // 8 * 8)
+            chh = int(rng.integers(8, oh + 1))
+            parts.append("crop=%d:%d:%d:%d" % (cw, chh, int(rng.integers(0, ow - cw + 1)), int(rng.integers(0, oh - chh + 1))))
+        vf, n = ",".join(parts), int(rng.choice([1, 2, 5, 21]))
+        try:
+            plan = tts.Plan.from_vf(vf, iw, ih, in_fmt="rgb24")
+        except tts.TtsError:
+            continue
+        strip += plan.kernel_name(0).startswith("rgbin_strip")
+        src = rng.integers(0, 256, (n, iw * ih * 3), dtype=np.uint8)
+        m = min(n, 3)
+        want = oracle.run_chain(plan.geom, src[:m])
+        got = plan.run_batch(torch.from_numpy(src).cuda()).cpu().numpy()
+        bad = np.flatnonzero(got[:m].ravel() != want.ravel())
+        assert bad.size == 0, "%s %dx%d n=%d [%s]: %d bytes differ, first at %d" % (vf, iw, ih, n, plan.kernel_name(0), bad.size, bad[0])
+        if n > m:                                              # the rest of a batch: frame k against frame k alone
+            k = int(rng.integers(m, n))
+            assert np.array_equal(got[k], plan.run_batch(torch.from_numpy(src[k: k + 1]).cuda()).cpu().numpy()[0])
+        ran += 1
+    assert ran, "no case ran"
+
+
+@pytest.mark.parametrize("seed", range(int(__import__("os").environ.get("TTS_FUZZ_RGB_SEEDS", "12"))))
 def test_random_conversion_alone_both_directions(tts, oracle, seed):
     """No scale in the chain: yuv420p -> packed RGB and rgb24 -> yuv420p at random sizes -- widths on and off the grids
     the streaming kernels need, crops in front, short and long batches (one and many row segments)."""

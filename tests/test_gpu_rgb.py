@@ -412,13 +412,14 @@ def test_rgb24_input_tiled_and_generic_kernels_agree(tts, oracle, monkeypatch, v
     assert np.array_equal(a, b) and np.array_equal(a, oracle.run_chain(tiled.geom, src))
 
 
-@pytest.mark.parametrize("planewise", ["0", "1"])
+@pytest.mark.parametrize("planewise,pad_s,pad_d", [("0", 7, 5), ("1", 7, 5), ("0", 9, 8)])
 @pytest.mark.parametrize("vf,iw,ih", [RGBIN_CASES[0], RGBIN_CASES[8], RGBIN_CASES[11], RGBIN_CASES[2]])
-def test_rgb24_input_through_frame_pointers(tts, oracle, monkeypatch, vf, iw, ih, planewise):
+def test_rgb24_input_through_frame_pointers(tts, oracle, monkeypatch, vf, iw, ih, planewise, pad_s, pad_d):
     """tts_run with packed-RGB source frames: one source plane per frame (rows padded), three destination planes,
-    every buffer its own allocation; padding is never written."""
+    every buffer its own allocation; padding is never written.  (Destination rows padded by 8 stay on the grid the
+    strip walk's stores need: enlargements take it through the pointer tables too; by 5 they fall back.)"""
     import torch
-    n, pad_s, pad_d = 5, 7, 5
+    n = 5
     monkeypatch.setenv("TTS_PLANEWISE", planewise)       # "1": one destination plane per launch (planes further than 4 GiB apart)
     plan = tts.Plan.from_vf(vf, iw, ih, in_fmt="rgb24")
     ow, oh = plan.out_size

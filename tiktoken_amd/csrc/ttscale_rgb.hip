@@ -1284,8 +1284,8 @@ struct RgbInStripArgs {
 constexpr int kRgbInStripRun = 512;                                   // pixels a wave converts per source row at most (8 a lane)
 constexpr int kRgbInStripYB = kRgbInStripRun / 2 + 4, kRgbInStripCB = kRgbInStripRun / 4 + 4;   // dwords of one copy of a luma / chroma row (the odd copy starts one dword in)
 
-template <int OCC>                                                     // waves a SIMD the register budget is cut to
-__global__ __launch_bounds__(kBlock, OCC) void rgbin_strip_kernel(const RgbInStripArgs a)
+// (register budget for 3 waves a SIMD: 152 VGPRs; cut to 128 the compiler spills 15 and the kernel is a fifth slower)
+__global__ __launch_bounds__(kBlock, 3) void rgbin_strip_kernel(const RgbInStripArgs a)
 {
     // every row twice: as pairs (s0 s1)(s2 s3).. and, one halfword on, as (s1 s2)(s3 s4)..: a window that starts on an
     // odd sample reads the second copy, so that every tap pair of every window is ONE aligned dword (no v_perm)
@@ -2136,8 +2136,7 @@ int rgbin_launch(const RgbInPlan *p, const uint8_t *src, uint8_t *dst, int n, in
         w.nseg = (g.pre_h + w.seg_rows - 1) / w.seg_rows;
         for (int f0 = 0; f0 < n && !rc; f0 += 65535) {
             w.frame0 = f0;
-            const int occ = std::getenv("TTS_RGBIN_STRIP_OCC") ? std::atoi(std::getenv("TTS_RGBIN_STRIP_OCC")) : 3;   // (A/B)
-            rc = launch_rgb("rgbin_strip_kernel", occ == 2 ? rgbin_strip_kernel<2> : occ == 4 ? rgbin_strip_kernel<4> : rgbin_strip_kernel<3>, dim3(unsigned((p->wpr * w.nseg + kBlock / 64 - 1) / (kBlock / 64)), 1, unsigned(std::min(65535, n - f0))),
+            rc = launch_rgb("rgbin_strip_kernel", rgbin_strip_kernel, dim3(unsigned((p->wpr * w.nseg + kBlock / 64 - 1) / (kBlock / 64)), 1, unsigned(std::min(65535, n - f0))),
                             dim3(kBlock), 0, st, w);
         }
         return rc;
