@@ -2102,9 +2102,9 @@ int rgbin_launch(const RgbInPlan *p, const uint8_t *src, uint8_t *dst, int n, in
         w.src_origin = a.src_origin;
         for (int i = 0; i < 9; ++i) w.coef[i] = coef[i];
         w.addr = addr;
-        // row segments: enough waves for a few rounds of the chip, none shorter than 32 rows (each starts 7 rows early)
+        // row segments: enough waves for many rounds of the chip, none shorter than 32 rows (each starts 7 rows early)
         const int wpr = (g.pre_w / 8 + 63) / 64;
-        const int64_t want = 4 * 2048;
+        const int64_t want = 16 * 2048;                              // (many short rounds: 4 x 2048 left 1.6 rounds at 300 frames of 1080p and ran 6 % slower)
         int nseg = int(std::min<int64_t>(std::max<int64_t>(1, (want + int64_t(wpr) * n - 1) / (int64_t(wpr) * n)), std::max(1, g.pre_h / 32)));
         w.seg_rows = (g.pre_h + nseg - 1) / nseg;
         w.nseg = (g.pre_h + w.seg_rows - 1) / w.seg_rows;
@@ -2130,8 +2130,10 @@ int rgbin_launch(const RgbInPlan *p, const uint8_t *src, uint8_t *dst, int n, in
         w.src_origin = a.src_origin; w.src_extent = a.src_extent;
         for (int i = 0; i < 9; ++i) w.coef[i] = coef[i];
         w.addr = addr;
-        const int64_t want = 8 * 3072;                             // waves for eight rounds of the chip at 3 a SIMD (4: 5 % slower; 12: the same)
-        int nseg = int(std::min<int64_t>(std::max<int64_t>(1, (want + int64_t(p->wpr) * n - 1) / (int64_t(p->wpr) * n)), std::max(1, g.pre_h / 32)));
+        // row segments of about 24 source rows whatever the batch (each starts up to 7 rows early; 16 and 40 measured 1-3 %
+        // slower at 300 and 1,200 frames of 1080p), down to 16 where that is what fills the chip for eight rounds
+        const int64_t fill = (int64_t(8) * 3072 + int64_t(p->wpr) * n - 1) / (int64_t(p->wpr) * n);
+        const int nseg = int(std::max<int64_t>(1, std::min<int64_t>(std::max<int64_t>((g.pre_h + 12) / 24, fill), std::max(1, g.pre_h / 16))));
         w.seg_rows = (g.pre_h + nseg - 1) / nseg;
         w.nseg = (g.pre_h + w.seg_rows - 1) / w.seg_rows;
         for (int f0 = 0; f0 < n && !rc; f0 += 65535) {
