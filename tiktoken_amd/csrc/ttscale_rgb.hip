@@ -1285,6 +1285,9 @@ constexpr int kRgbInStripRun = 512;                                   // pixels 
 constexpr int kRgbInStripYB = kRgbInStripRun / 2 + 4, kRgbInStripCB = kRgbInStripRun / 4 + 4;   // dwords of one copy of a luma / chroma row (the odd copy starts one dword in)
 
 // (register budget for 3 waves a SIMD: 152 VGPRs; cut to 128 the compiler spills 15 and the kernel is a fifth slower)
+// PXL: pixels of the run a lane converts per row -- 8, or 6 / 4 where the waves' runs are that short (the portrait chain
+// reads 290 pixels a wave: with 8 a lane 27 of the 64 lanes would convert for nothing).
+template <int PXL>
 __global__ __launch_bounds__(kBlock, 3) void rgbin_strip_kernel(const RgbInStripArgs a)
 {
     // every row twice: as pairs (s0 s1)(s2 s3).. and, one halfword on, as (s1 s2)(s3 s4)..: a window that starts on an
@@ -1311,8 +1314,10 @@ __global__ __launch_bounds__(kBlock, 3) void rgbin_strip_kernel(const RgbInStrip
     dy += 8 * size_t(strip); du += 4 * size_t(strip); dv += 4 * size_t(strip);
     const uintptr_t lo = reinterpret_cast<uintptr_t>(fb), hi = lo + a.src_extent;
     const int run0 = a.tab[a.o_run + 2 * wx], run_px = a.tab[a.o_run + 2 * wx + 1];      // wave-uniform
-    const bool conv = 8 * lane < run_px;
-    const uint8_t *pcol = fb + a.src_origin + 3 * size_t(run0 + 8 * lane);
+    static_assert(PXL == 4 || PXL == 6 || PXL == 8, "pixels a lane converts");
+    constexpr int NP = PXL / 2, NDW = (3 * PXL + 6) / 4;             // pixel pairs; aligned dwords that hold a lane's 3 PXL bytes at any phase
+    const bool conv = PXL * lane < run_px;
+    const uint8_t *pcol = fb + a.src_origin + 3 * size_t(run0 + PXL * lane);
     // this lane's windows and taps
     int li[8], ci[4];                                              // first dword of each window, in the copy its parity picks (host)
     uint32_t lt[8][2], ct[4][2];
@@ -1338,78 +1343,73 @@ __global__ __launch_bounds__(kBlock, 3) void rgbin_strip_kernel(const RgbInStrip
     uint32_t ringl[8][2], ringu[4][4], ringv[4][4];
 #pragma unroll
     for (int i = 0; i < 16; ++i) { (&ringl[0][0])[i] = 0; (&ringu[0][0])[i] = 0; (&ringv[0][0])[i] = 0; }
-    // a lane's 24 bytes of a source row as the 7 aligned dwords that hold them; outside the frame: byte by byte
-    auto fetch = [&](int r, uint32_t (&raw)[7]) {
+    // a lane's bytes of a source row as the aligned dwords that hold them; outside the frame: byte by byte
+    auto fetch = [&](int r, uint32_t (&raw)[NDW]) {
         const uintptr_t p = reinterpret_cast<uintptr_t>(pcol + size_t(r) * a.src_stride), pa = p & ~uintptr_t(3);
-        if (!conv) { for (int k = 0; k < 7; ++k) raw[k] = 0; return; }
-        if (pa >= lo && pa + 28 <= hi) {
+        if (!conv) { for (int k = 0; k < NDW; ++k) raw[k] = 0; return; }
+        if (pa >= lo && pa + 4 * NDW <= hi) {
             const uint32_t *q = reinterpret_cast<const uint32_t *>(pa);
 #pragma unroll
-            for (int k = 0; k < 7; ++k) raw[k] = q[k];
+            for (int k = 0; k < NDW; ++k) raw[k] = q[k];
         } else {
 #pragma unroll
-            for (int k = 0; k < 7; ++k) {
+            for (int k = 0; k < NDW; ++k) {
                 uint32_t w = 0;
                 for (int b = 0; b < 4; ++b) { const uintptr_t q = pa + 4 * k + b; if (q >= lo && q < hi) w |= uint32_t(*reinterpret_cast<const uint8_t *>(q)) << (8 * b); }
                 raw[k] = w;
             }
         }
     };
-    uint32_t nx[7];
+    uint32_t nx[NDW];
     fetch(rstart, nx);
     for (int r0 = rstart & ~7; r0 <= rlast; r0 += 8) {
 #pragma unroll
         for (int s = 0; s < 8; ++s) {
             const int r = r0 + s;
             if (r < rstart || r > rlast) continue;                 // wave-uniform
-            // ---- convert this lane's 8 pixels of the run
+            // ---- convert this lane's PXL pixels of the run
             {
                 const uint32_t ph = uint32_t(reinterpret_cast<uintptr_t>(pcol + size_t(r) * a.src_stride) & 3u);
-                uint32_t w[6];
+                uint32_t w[NDW - 1];
 #pragma unroll
-                for (int k = 0; k < 6; ++k) w[k] = __builtin_amdgcn_alignbyte(nx[k + 1], nx[k], ph);
+                for (int k = 0; k < NDW - 1; ++k) w[k] = __builtin_amdgcn_alignbyte(nx[k + 1], nx[k], ph);
                 fetch(min(r + 1, rlast), nx);
-                int R[8], G[8], B[8];
+                int R[PXL], G[PXL], B[PXL];
 #pragma unroll
-                for (int i = 0; i < 8; ++i) {
+                for (int i = 0; i < PXL; ++i) {
                     const int b0 = 3 * i;
                     R[i] = int((w[b0 >> 2] >> (8 * (b0 & 3))) & 255u);
                     G[i] = int((w[(b0 + 1) >> 2] >> (8 * ((b0 + 1) & 3))) & 255u);
                     B[i] = int((w[(b0 + 2) >> 2] >> (8 * ((b0 + 2) & 3))) & 255u);
                 }
-                uint32_t yy[4], uu[2], vv[2];
+                uint32_t yy[NP];
 #pragma unroll
-                for (int i = 0; i < 4; ++i) {
+                for (int i = 0; i < NP; ++i) {
                     const int y0 = (__mul24(ry, R[2 * i]) + __mul24(gy, G[2 * i]) + __mul24(by, B[2 * i]) + (32 << 14) + (1 << 8)) >> 9;
                     const int y1 = (__mul24(ry, R[2 * i + 1]) + __mul24(gy, G[2 * i + 1]) + __mul24(by, B[2 * i + 1]) + (32 << 14) + (1 << 8)) >> 9;
                     yy[i] = uint32_t(y0) | uint32_t(y1) << 16;                      // (14-bit values: no sign to keep)
                 }
-                int u14[4], v14[4];
+                int u14[NP], v14[NP];
 #pragma unroll
-                for (int j = 0; j < 4; ++j) {
+                for (int j = 0; j < NP; ++j) {
                     const int sr = R[2 * j] + R[2 * j + 1], sg = G[2 * j] + G[2 * j + 1], sb = B[2 * j] + B[2 * j + 1];
                     u14[j] = (__mul24(ru, sr) + __mul24(gu, sg) + __mul24(bu, sb) + (256 << 15) + (1 << 9)) >> 10;
                     v14[j] = (__mul24(rv, sr) + __mul24(gv, sg) + __mul24(bv, sb) + (256 << 15) + (1 << 9)) >> 10;
                 }
-                uu[0] = uint32_t(u14[0]) | uint32_t(u14[1]) << 16; uu[1] = uint32_t(u14[2]) | uint32_t(u14[3]) << 16;
-                vv[0] = uint32_t(v14[0]) | uint32_t(v14[1]) << 16; vv[1] = uint32_t(v14[2]) | uint32_t(v14[3]) << 16;
                 if (conv) {
+                    // even copy, then the odd one: dword m = (s[2m + 1], s[2m + 2]); its first and last halfword belong to the neighbours' dwords
 #pragma unroll
-                    for (int k = 0; k < 4; ++k) ylds[wave][4 * lane + k] = yy[k];
-                    ulds[wave][2 * lane] = uu[0]; ulds[wave][2 * lane + 1] = uu[1];
-                    vlds[wave][2 * lane] = vv[0]; vlds[wave][2 * lane + 1] = vv[1];
-                    // the odd copies: dword m = (s[2m + 1], s[2m + 2]); its first and last halfword belong to the neighbours' dwords
-                    uint32_t *yb = &ylds[wave][kRgbInStripYB + 1 + 4 * lane], *ub = &ulds[wave][kRgbInStripCB + 1 + 2 * lane], *vb = &vlds[wave][kRgbInStripCB + 1 + 2 * lane];
+                    for (int k = 0; k < NP; ++k) ylds[wave][NP * lane + k] = yy[k];
+                    uint32_t *yb = &ylds[wave][kRgbInStripYB + 1 + NP * lane];
                     reinterpret_cast<uint16_t *>(yb - 1)[1] = uint16_t(yy[0]);
 #pragma unroll
-                    for (int k = 0; k < 3; ++k) yb[k] = __builtin_amdgcn_perm(yy[k + 1], yy[k], 0x05040302);
-                    reinterpret_cast<uint16_t *>(yb + 3)[0] = uint16_t(yy[3] >> 16);
-                    reinterpret_cast<uint16_t *>(ub - 1)[1] = uint16_t(uu[0]);
-                    ub[0] = __builtin_amdgcn_perm(uu[1], uu[0], 0x05040302);
-                    reinterpret_cast<uint16_t *>(ub + 1)[0] = uint16_t(uu[1] >> 16);
-                    reinterpret_cast<uint16_t *>(vb - 1)[1] = uint16_t(vv[0]);
-                    vb[0] = __builtin_amdgcn_perm(vv[1], vv[0], 0x05040302);
-                    reinterpret_cast<uint16_t *>(vb + 1)[0] = uint16_t(vv[1] >> 16);
+                    for (int k = 0; k < NP - 1; ++k) yb[k] = __builtin_amdgcn_perm(yy[k + 1], yy[k], 0x05040302);
+                    reinterpret_cast<uint16_t *>(yb + NP - 1)[0] = uint16_t(yy[NP - 1] >> 16);
+                    // chroma (NP samples a lane: an odd count leaves lanes on either parity): halfword stores
+                    uint16_t *ua = reinterpret_cast<uint16_t *>(&ulds[wave][0]) + NP * lane, *ub = reinterpret_cast<uint16_t *>(&ulds[wave][kRgbInStripCB + 1]) + NP * lane - 1;
+                    uint16_t *va = reinterpret_cast<uint16_t *>(&vlds[wave][0]) + NP * lane, *vb = reinterpret_cast<uint16_t *>(&vlds[wave][kRgbInStripCB + 1]) + NP * lane - 1;
+#pragma unroll
+                    for (int k = 0; k < NP; ++k) { ua[k] = uint16_t(u14[k]); ub[k] = uint16_t(u14[k]); va[k] = uint16_t(v14[k]); vb[k] = uint16_t(v14[k]); }
                 }
             }
             __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
@@ -1869,7 +1869,7 @@ struct RgbInPlan {
     bool strip = false;
     int32_t *d_strip = nullptr;
     uint32_t so_run = 0, so_strip = 0, so_lastl = 0, so_vcol = 0, so_lastc = 0, so_vcoc = 0;
-    int strips = 0, wpr = 0;
+    int strips = 0, wpr = 0, pxl = 8;
     char name[96] = "";
 };
 
@@ -1978,6 +1978,7 @@ int rgbin_plan_create(const tts_geom &g, RgbInPlan **out)
             ok = ox + g.out_w <= int(p->lh.pos.size()) && oxc + g.out_w / 2 <= int(p->ch.pos.size()) && oy + oh <= int(p->lv.pos.size()) && oyc + och <= int(p->cv.pos.size());
             std::vector<int32_t> t;
             std::vector<int> run0(size_t(wpr), 0);
+            int max_len = 0;
             p->so_run = 0;
             t.resize(size_t(2) * wpr);
             for (int wx = 0; wx < wpr && ok; ++wx) {
@@ -1987,6 +1988,7 @@ int rgbin_plan_create(const tts_geom &g, RgbInPlan **out)
                 run0[wx] = std::min(lmin, cmin) & ~1;
                 const int len = std::max(lmax, cmax) - run0[wx];
                 if (len > kRgbInStripRun) ok = false;
+                max_len = std::max(max_len, len);
                 t[2 * size_t(wx)] = run0[wx]; t[2 * size_t(wx) + 1] = len;
             }
             if (ok) {
@@ -2032,12 +2034,12 @@ int rgbin_plan_create(const tts_geom &g, RgbInPlan **out)
                     for (int k = 0; k < 4; ++k) t[p->so_vcoc + 4 * size_t(y) + k] = pk(slot[2 * k], slot[2 * k + 1]);
                 }
                 if (!upload_vec(p->d_strip, t)) { set_last_error("table upload failed (hipMalloc / hipMemcpy)"); rc = TTS_ERR_INITIALIZATION_FAILED; }
-                else { p->strip = true; p->strips = strips; p->wpr = wpr; }
+                else { p->strip = true; p->strips = strips; p->wpr = wpr; p->pxl = max_len <= 256 ? 4 : max_len <= 384 ? 6 : 8; }
             }
         }
     }
     if (p->walk) std::snprintf(p->name, sizeof p->name, "rgbin_walk<%d>", p->cv.size);
-    else if (p->strip) std::snprintf(p->name, sizeof p->name, "rgbin_strip<%d,%d,%d,%d>", p->lh.size, p->lv.size, p->ch.size, p->cv.size);
+    else if (p->strip) std::snprintf(p->name, sizeof p->name, "rgbin_strip<%d,%d,%d,%d,%dpx>", p->lh.size, p->lv.size, p->ch.size, p->cv.size, p->pxl);
     else if (p->tiled) std::snprintf(p->name, sizeof p->name, "rgbin_tile<%d,%d>", p->th[0], p->th[1]);
     else std::snprintf(p->name, sizeof p->name, "rgbin_generic<%d,%d,%d,%d>", p->lh.size, p->lv.size, p->ch.size, p->cv.size);
     if (rc) { rgbin_plan_destroy(p); return rc; }
@@ -2138,7 +2140,7 @@ int rgbin_launch(const RgbInPlan *p, const uint8_t *src, uint8_t *dst, int n, in
         w.nseg = (g.pre_h + w.seg_rows - 1) / w.seg_rows;
         for (int f0 = 0; f0 < n && !rc; f0 += 65535) {
             w.frame0 = f0;
-            rc = launch_rgb("rgbin_strip_kernel", rgbin_strip_kernel, dim3(unsigned((p->wpr * w.nseg + kBlock / 64 - 1) / (kBlock / 64)), 1, unsigned(std::min(65535, n - f0))),
+            rc = launch_rgb("rgbin_strip_kernel", p->pxl == 4 ? rgbin_strip_kernel<4> : p->pxl == 6 ? rgbin_strip_kernel<6> : rgbin_strip_kernel<8>, dim3(unsigned((p->wpr * w.nseg + kBlock / 64 - 1) / (kBlock / 64)), 1, unsigned(std::min(65535, n - f0))),
                             dim3(kBlock), 0, st, w);
         }
         return rc;
