@@ -42,6 +42,9 @@ CASES = {
     # packed rgb24 IN, yuv420p out (the reverse of the above): 3 bytes a pixel read once + the planes written once
     "portrait_rgbin": ("scale=1080:1920:force_original_aspect_ratio=increase,crop=1080:1920", 1920, 1080, 608 * 1080 * 3 + 3110400),
     "stretch_rgbin": ("scale=w=720:h=1280", 480, 854, 480 * 854 * 3 + 1382400),
+    "cvt_yuvj": ("format=yuvj420p", 1920, 1080, 3110400 * 2),                               # range step alone
+    "pad_only": ("pad=1920:1280:-1:-1:color=black", 1920, 1080, 3110400 + 1920 * 1280 * 3 // 2),
+    "crop_only": ("crop=1080:1080", 1920, 1080, 1080 * 1080 * 3),
     "cvt_rgb24": ("format=rgb24", 1920, 1080, 3110400 + 6220800),                          # conversion alone (yuv2rgb_c_24_rgb)
     "cvt_rgba": ("format=rgba", 1920, 1080, 3110400 + 8294400),
     "cvt_rgbin": ("format=yuv420p", 1920, 1080, 6220800 + 3110400),                                  # rgb24 -> yuv420p, no scale
