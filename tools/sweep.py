@@ -21,6 +21,7 @@ CASES = {
     # the reference's own thumbnail chain (src/services/video.js:329-332) on a 1080p / portrait 1080p / 4K source
     "thumbref": ("scale=320x180:force_original_aspect_ratio=decrease,pad=320x180:-1:-1:color=black,format=yuv420p", 1920, 1080, 3110400 + 86400),
     "thumbref_portrait": ("scale=320x180:force_original_aspect_ratio=decrease,pad=320x180:-1:-1:color=black,format=yuv420p", 1080, 1920, 3110400 + 86400),
+    "thumbref_portrait_nopad": ("scale=320x180:force_original_aspect_ratio=decrease", 1080, 1920, 3110400 + 101 * 180 + 2 * 51 * 90),
     "thumbref_4k": ("scale=320x180:force_original_aspect_ratio=decrease,pad=320x180:-1:-1:color=black,format=yuv420p", 3840, 2160, 12441600 + 86400),
     # web compress (portrait.test.js:70-97): a 1080x1920 phone clip into the 720x1280 box; 2160x3840 likewise
     "web": ("scale=720:1280", 1080, 1920, 3110400 + 1382400),
