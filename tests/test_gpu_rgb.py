@@ -102,7 +102,11 @@ UNSCALED_CASES = [
     ("format=rgb24", 1040, 64, "rgb_unscaled8"),              # 130 units: the third wave of a row pair holds two
     ("crop=640:360:16:10,format=rgb24", 1280, 720, "rgb_unscaled8"),
     ("crop=640:360:4:10,format=rgb24", 1280, 720, "rgb_unscaled"),     # source rows off the dword grid
-    ("format=rgb24", 1928, 1080, "rgb_unscaled"),             # not a multiple of 16 wide
+    ("format=rgb24", 1080, 1920, "rgb_unscaled8"),            # portrait frames: 135 units a row, the third wave of a row pair ends in half a chunk
+    ("format=bgr24", 1928, 1080, "rgb_unscaled8"),            # a multiple of 8, not of 16
+    ("format=rgba", 1080, 64, "rgb_unscaled8"),
+    ("format=rgb24", 24, 16, "rgb_unscaled8"),                # three units: one and a half chunks... of a single wave
+    ("format=rgb24", 1924, 1080, "rgb_unscaled"),             # not a multiple of 8 wide
     ("pad=1936:1096:-1:-1,format=rgb24", 1920, 1080, "rgb_unscaled"),
 ]
 

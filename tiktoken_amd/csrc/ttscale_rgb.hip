@@ -361,8 +361,8 @@ constexpr int kRgbMaxPieces = 8;
 // (three products per sample) serve four pixels, a pixel costs one multiply and three adds, and four channel
 // values become four clipped bytes in two instructions (pack4<16>).  A wave's row goes through the LDS exchange of
 // the strip kernel above, so that every store instruction writes whole sectors.  The host sends here only what
-// fits: no border, a picture that is a multiple of 16 wide, dword-aligned source rows, 16-byte-aligned output
-// rows, frames at a fixed pitch; everything else stays with rgb_unscaled_kernel.
+// fits: no border, a picture that is a multiple of 8 wide, dword-aligned source and output rows; everything else
+// stays with rgb_unscaled_kernel.
 template <int BPP>
 __global__ __launch_bounds__(kBlock) void rgb_unscaled8_kernel(const RgbFrameArgs a)
 {
@@ -404,7 +404,8 @@ __global__ __launch_bounds__(kBlock) void rgb_unscaled8_kernel(const RgbFrameArg
     const uint32_t xbase = uint32_t(reinterpret_cast<uintptr_t>((rgb_lds_t *)&xlds[wave][0]));
     const uint32_t xw = xbase + uint32_t(lane) * (8u * BPP);
     constexpr int kChunks = 64 * 8 * BPP / 16;                     // 16-byte chunks of a full wave's row: 96 / 128
-    const int live_chunks = nlive * 8 * BPP / 16;                  // (a multiple of 3 / of 2: the host sends even unit counts)
+    const int live_bytes = nlive * 8 * BPP, live_chunks = live_bytes / 16;   // an odd count of rgb24 units ends in half a chunk: stored by itself
+    const bool half = (live_bytes & 8) != 0;
     const int c2 = 64 + lane;
     const uint32_t xr1 = xbase + 16u * uint32_t(lane), xr2 = xbase + 16u * uint32_t(c2 < kChunks ? c2 : 0);
     uint8_t *drow = dp + size_t(2 * rp) * a.dst_stride + size_t(wx) * (64 * 8 * BPP);
@@ -429,8 +430,12 @@ __global__ __launch_bounds__(kBlock) void rgb_unscaled8_kernel(const RgbFrameArg
             rgb_lds_exchange4(xw, o, xr1, xr2, v1, v2);
         }
         uint8_t *d = drow + size_t(r) * a.dst_stride;
-        if (lane < live_chunks) *reinterpret_cast<u32x4_t *>(d + 16 * lane) = v1;
-        if (c2 < live_chunks) *reinterpret_cast<u32x4_t *>(d + 16 * c2) = v2;
+        typedef uint32_t u32x4_dw __attribute__((ext_vector_type(4), aligned(4)));     // (rows start on a dword, not more)
+        typedef uint32_t u32x2_dw __attribute__((ext_vector_type(2), aligned(4)));
+        if (lane < live_chunks) *reinterpret_cast<u32x4_dw *>(d + 16 * lane) = v1;
+        if (c2 < live_chunks) *reinterpret_cast<u32x4_dw *>(d + 16 * c2) = v2;
+        if (half && lane == live_chunks) *reinterpret_cast<u32x2_dw *>(d + 16 * lane) = u32x2_dw{v1.x, v1.y};
+        if (half && c2 == live_chunks) *reinterpret_cast<u32x2_dw *>(d + 16 * c2) = u32x2_dw{v2.x, v2.y};
     }
 }
 
@@ -1667,9 +1672,9 @@ int rgb_plan_create(const tts_geom &g, int n_cus, RgbPlan **out)
         p->mode = RgbPlan::kUnscaled;
         if (ctx_dw & 1) { set_last_error("swscale's unscaled yuv420p -> RGB converter never writes the last column of an odd width: not supported"); rc = TTS_ERR_UNSUPPORTED; }
         // the streaming form where the geometry fits it (the addresses are checked per launch): no border, a
-        // picture that is a multiple of 16 wide, its source rows on the dword grid
+        // picture that is a multiple of 8 wide, its source rows on the dword grid
         p->unscaled8 = !p->convert4 && (g.rgb_stage != TTS_RGB_AT_END || (p->cpx == 0 && p->cpy == 0 && 2 * p->cpw == p->pw && 2 * p->cph == p->ph)) && p->px == 0 && p->py == 0 && p->pw == g.out_w && p->ph == g.out_h &&
-                       p->pw % 16 == 0 && p->ph % 2 == 0 && p->ox % 8 == 0 && p->oy % 2 == 0 && g.pre_x % 8 == 0;
+                       p->pw % 8 == 0 && p->ph % 2 == 0 && p->ox % 8 == 0 && p->oy % 2 == 0 && g.pre_x % 8 == 0;
         std::snprintf(p->name, sizeof p->name, p->unscaled8 ? "rgb_unscaled8" : "rgb_unscaled");
     } else {
         if (g.rgb_stage == TTS_RGB_AT_END && (g.do_pad || g.crop_w != g.sc_w || g.crop_h != g.sc_h)) {
@@ -1778,12 +1783,12 @@ int rgb_launch(const RgbPlan *p, const uint8_t *src, uint8_t *dst, int n, const 
         if (p->mode == RgbPlan::kUnscaled) {
             // the streaming form where the geometry and the addresses allow (see the kernel)
             bool fast = p->unscaled8 && reinterpret_cast<uintptr_t>(src) % 4 == 0 && src_stride[0] % 4 == 0 && src_stride[1] % 4 == 0 &&
-                        reinterpret_cast<uintptr_t>(dst) % 16 == 0 && dst_stride % 16 == 0;
+                        reinterpret_cast<uintptr_t>(dst) % 4 == 0 && dst_stride % 4 == 0;
             if (fast && addr.use_table) {                            // per-frame pointers: every frame's planes
                 for (int i = f0; i < f0 + nf && fast; ++i)
-                    fast = addr.src_tab[0][i] % 4 == 0 && addr.src_tab[1][i] % 4 == 0 && addr.src_tab[2][i] % 4 == 0 && addr.dst_tab[0][i] % 16 == 0;
+                    fast = addr.src_tab[0][i] % 4 == 0 && addr.src_tab[1][i] % 4 == 0 && addr.src_tab[2][i] % 4 == 0 && addr.dst_tab[0][i] % 4 == 0;
             } else if (fast)
-                fast = addr.src_pitch % 4 == 0 && addr.src_plane[0] % 4 == 0 && addr.src_plane[1] % 4 == 0 && addr.src_plane[2] % 4 == 0 && addr.dst_pitch % 16 == 0;
+                fast = addr.src_pitch % 4 == 0 && addr.src_plane[0] % 4 == 0 && addr.src_plane[1] % 4 == 0 && addr.src_plane[2] % 4 == 0 && addr.dst_pitch % 4 == 0;
             if (fast) {
                 const int waves = ((f.pw / 8 + 63) / 64) * (f.ph / 2);
                 rc = launch_rgb("rgb_unscaled8_kernel", p->bpp == 3 ? rgb_unscaled8_kernel<3> : rgb_unscaled8_kernel<4>,

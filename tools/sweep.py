@@ -47,6 +47,7 @@ CASES = {
     "pad_only": ("pad=1920:1280:-1:-1:color=black", 1920, 1080, 3110400 + 1920 * 1280 * 3 // 2),
     "crop_only": ("crop=1080:1080", 1920, 1080, 1080 * 1080 * 3),
     "cvt_rgb24": ("format=rgb24", 1920, 1080, 3110400 + 6220800),                          # conversion alone (yuv2rgb_c_24_rgb)
+    "cvt_rgb24_portrait": ("format=rgb24", 1080, 1920, 3110400 + 6220800),
     "cvt_rgba": ("format=rgba", 1920, 1080, 3110400 + 8294400),
     "cvt_rgbin": ("format=yuv420p", 1920, 1080, 6220800 + 3110400),                                  # rgb24 -> yuv420p, no scale
     "web_rgb24": ("scale=720:1280,format=rgb24", 1080, 1920, 3110400 + 2764800),      # 1.5x shrink written as RGB
