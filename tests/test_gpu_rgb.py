@@ -91,6 +91,8 @@ SCRATCH_CASES = [
     ("scale=1280:720", 1920, 1080, "rgb24"),           # 1.5x: 6-7 taps -- the grouped-window strip kernel with the 16-bit luma store
     ("scale=720:1280", 1080, 1920, "bgra"),            # the web compress box (portrait.test.js:70-97) as pixels
     ("scale=300:200", 400, 300, "rgb24"),
+    ("scale=1080:608", 1920, 1080, "bgr24"),           # 135 eight-pixel units a row: the last wave's string ends in half a chunk
+    ("scale=200:120,pad=240:136:-1:-1:color=white", 640, 360, "rgb24"),   # 25 units
 ]
 
 

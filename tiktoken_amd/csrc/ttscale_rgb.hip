@@ -809,10 +809,10 @@ __global__ __launch_bounds__(kScratchThreads) void rgb_scratch_convert4_kernel(c
     }
     __syncthreads();                                               // the workgroup's rows sit in registers: they may be overwritten
     if (!row_ok) return;
-    // Eight pixels a thread, an even number of units a row: the arithmetic of rgb_unscaled8_kernel (chroma terms
+    // Eight pixels a thread: the arithmetic of rgb_unscaled8_kernel (chroma terms
     // shared by a sample's pixels, two-instruction packs) and its whole-sector stores through an LDS exchange -- a
     // wave is 64 adjacent units of ONE row (tpr >= 64), its pixels one string of 1.5 (2) KiB.
-    if (PX == 8 && (units & 1) == 0) {
+    if (PX == 8) {
         if constexpr (PX == 8) {
             __shared__ __attribute__((aligned(16))) uint8_t xlds[kScratchThreads / 64][64 * 8 * 4];
             if (in_rows) {
@@ -825,7 +825,8 @@ __global__ __launch_bounds__(kScratchThreads) void rgb_scratch_convert4_kernel(c
                 for (int it = 0; it < kIters; ++it) {
                     const int base = it * a.tpr + (t - lane);      // the wave's first unit (wave-uniform)
                     if (base >= units) break;
-                    const int live_chunks = min(64, units - base) * ubytes / 16;
+                    const int live_bytes = min(64, units - base) * ubytes, live_chunks = live_bytes / 16;
+                    const bool half = (live_bytes & 8) != 0;           // an odd count of rgb24 units: the last chunk is half a chunk
                     int CR[4], CG[4], CB[4];
 #pragma unroll
                     for (int j = 0; j < 4; ++j) {
@@ -860,8 +861,11 @@ __global__ __launch_bounds__(kScratchThreads) void rgb_scratch_convert4_kernel(c
                         rgb_lds_exchange4(xw, o, xbase + 16u * uint32_t(lane), xbase + 16u * uint32_t(c2), v1, v2);
                     }
                     typedef uint32_t u32x4_dw __attribute__((ext_vector_type(4), aligned(4)));     // (picture rows start on a dword, not more)
+                    typedef uint32_t u32x2_dw __attribute__((ext_vector_type(2), aligned(4)));
                     if (lane < live_chunks) *reinterpret_cast<u32x4_dw *>(d + 16 * lane) = v1;
                     if (c2 < live_chunks) *reinterpret_cast<u32x4_dw *>(d + 16 * c2) = v2;
+                    if (half && lane == live_chunks) *reinterpret_cast<u32x2_dw *>(d + 16 * lane) = u32x2_dw{v1.x, v1.y};
+                    if (half && c2 == live_chunks) *reinterpret_cast<u32x2_dw *>(d + 16 * c2) = u32x2_dw{v2.x, v2.y};
                 }
             }
         }
