@@ -32,13 +32,17 @@ struct StripClass {
 struct RangeStep { int32_t on; int32_t mul[2], add[2], shift[2]; };
 
 // The pad border of one plane class, written by extra workgroups of the SAME launch (they follow the scaler's
-// workgroups in the logical block order): a workgroup takes `blockDim / 64` canvas rows x 256 columns of one
-// plane and stores the fill byte (already range-mapped) wherever the picture is not.
+// workgroups in the logical block order).  Only the border is tiled: the full-width rows above and below the
+// picture (`chunks` x `rowgroups` workgroups per plane), then the columns left and right of it over the picture's
+// rows (`chunks_sd` x `rgs_sd`); a workgroup takes blockDim / 64 * kPadRowsPerWave rows x 256 columns of its region
+// and stores the fill byte (already range-mapped).  (Tiling the whole canvas and leaving where a tile held no
+// border cost a large canvas thousands of idle workgroups: 1080p letterboxed into 1920x1280 ran 2.5x slower.)
 struct PadClass {
     int32_t w, h, stride;              // canvas of this plane class
     int32_t px, py, pw, ph;            // picture rectangle that is left alone
     int32_t planes, plane0;
-    int32_t chunks, rowgroups;         // 256-column chunks per row, groups of blockDim / 64 * kPadRowsPerWave rows
+    int32_t chunks, rowgroups;         // rows above / below the picture: 256-column chunks, row groups
+    int32_t chunks_sd, rgs_sd;         // columns left / right of it
     uint32_t origin;                   // bytes from the canvas origin to the picture origin (frame offsets point at the picture)
     uint32_t nblocks;
     int32_t fill[3];
@@ -62,24 +66,28 @@ __device__ __forceinline__ void pad_fill_blocks(const StripArgs &a, uint8_t *dst
     const int k = fb >= a.pad[0].nblocks ? 1 : 0;
     if (k) fb -= a.pad[0].nblocks;
     const PadClass &c = a.pad[k];
-    const int chunk = int(fb % uint32_t(c.chunks));
-    const uint32_t rest = fb / uint32_t(c.chunks);
-    const int rg = int(rest % uint32_t(c.rowgroups)), fp = int(rest / uint32_t(c.rowgroups));
-    const int x = chunk * 256 + int(threadIdx.x & 63) * 4;
-    if (x >= c.w) return;
+    const uint32_t tb = uint32_t(c.chunks) * uint32_t(c.rowgroups), per_fp = tb + uint32_t(c.chunks_sd) * uint32_t(c.rgs_sd);
+    const int fp = int(fb / per_fp);
+    uint32_t b = fb % per_fp;
+    const bool side = b >= tb;                                     // workgroup-uniform
+    if (side) b -= tb;
+    const uint32_t nch = uint32_t(side ? c.chunks_sd : c.chunks);
+    const int chunk = int(b % nch), rg = int(b / nch);
+    // the region as a rectangle of its own: `vw` x `vh`, mapped back to canvas columns and rows around the picture
+    const int vw = side ? c.w - c.pw : c.w, vh = side ? c.ph : c.h - c.ph;
+    const int u0 = chunk * 256 + int(threadIdx.x & 63) * 4;
+    if (u0 >= vw) return;
     const int plane = c.plane0 + fp % c.planes, frame = fp / c.planes;
     const size_t doff = (a.addr.use_table ? size_t(a.addr.dst_tab[plane][frame])
                                           : size_t(frame) * a.addr.dst_pitch + a.addr.dst_plane[plane]) - c.origin;
     const uint8_t f = uint8_t(c.fill[plane]);
     const int waves = int(blockDim.x >> 6);
-    // kPadRowsPerWave rows per wave: a 101x180 picture in a 320x180 canvas was 136 workgroups of 1 KiB per frame
     for (int it = 0; it < kPadRowsPerWave; ++it) {
-        const int y = (rg * kPadRowsPerWave + it) * waves + int(threadIdx.x >> 6);
-        if (y >= c.h) return;
+        const int v = (rg * kPadRowsPerWave + it) * waves + int(threadIdx.x >> 6);
+        if (v >= vh) return;
+        const int y = side ? c.py + v : (v < c.py ? v : v + c.ph);
         uint8_t *row = dst + doff + size_t(y) * size_t(c.stride);
-        const bool in_rows = y >= c.py && y < c.py + c.ph;
-        for (int i = x; i < min(x + 4, c.w); ++i)
-            if (!(in_rows && i >= c.px && i < c.px + c.pw)) row[i] = f;
+        for (int u = u0; u < min(u0 + 4, vw); ++u) row[side ? (u < c.px ? u : u + c.pw) : u] = f;
     }
 }
 

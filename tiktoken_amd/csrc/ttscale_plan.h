@@ -839,7 +839,10 @@ int launch_all(const tts_plan *p, const uint8_t *src, uint8_t *dst, int n, const
         pc.w = c.canvas_w; pc.h = c.canvas_h; pc.stride = dst_stride[ci];
         pc.px = c.pad_x; pc.py = c.pad_y; pc.pw = c.ow; pc.ph = c.oh;
         pc.planes = nplanes(ci); pc.plane0 = plane0(ci);
-        pc.chunks = (c.canvas_w + 255) / 256; pc.rowgroups = (c.canvas_h + threads / 64 * kPadRowsPerWave - 1) / (threads / 64 * kPadRowsPerWave);
+        const int rows_wg = threads / 64 * kPadRowsPerWave;        // rows a pad workgroup covers
+        pc.chunks = (c.canvas_w + 255) / 256; pc.rowgroups = (c.canvas_h - c.oh + rows_wg - 1) / rows_wg;          // above and below the picture
+        pc.chunks_sd = (c.canvas_w - c.ow + 255) / 256; pc.rgs_sd = pc.chunks_sd ? (c.oh + rows_wg - 1) / rows_wg : 0;   // left and right of it
+        if (!pc.rowgroups) pc.chunks = 0;
         pc.origin = uint32_t(c.pad_y) * uint32_t(dst_stride[ci]) + uint32_t(c.pad_x);
         const int fill[3] = {p->g.fill_y, p->g.fill_u, p->g.fill_v};
         for (int k = 0; k < 3; ++k) {
@@ -850,7 +853,7 @@ int launch_all(const tts_plan *p, const uint8_t *src, uint8_t *dst, int n, const
                 pc.fill[k] = lut[fill[k] & 255];
             }
         }
-        pc.nblocks = uint32_t(pc.chunks) * uint32_t(pc.rowgroups) * uint32_t(n) * uint32_t(pc.planes);
+        pc.nblocks = (uint32_t(pc.chunks) * uint32_t(pc.rowgroups) + uint32_t(pc.chunks_sd) * uint32_t(pc.rgs_sd)) * uint32_t(n) * uint32_t(pc.planes);
     };
     if (p->g.do_pad) {
         for (int ci = 0; ci < 2; ++ci) {
