@@ -8,6 +8,10 @@ R=$GRAFT_REPO_ROOT
 O=$R/gpurun_out
 mkdir -p $O
 cd $R
+# (a line a minute: the harness takes three silent minutes for a hang, and the profiled bench writes nothing until it ends)
+( while sleep 45; do echo "[final_evidence] $(date +%T) running"; done ) &
+HB=$!
+trap 'kill $HB 2>/dev/null' EXIT
 timeout -k 10 300 python bench.py > $O/${P}_bench.json 2> $O/${P}_bench.err || { echo "bench failed"; tail -n 5 $O/${P}_bench.err; exit 1; }
 timeout -k 10 300 python bench.py --frames 300 > $O/${P}_bench300.json 2> $O/${P}_bench300.err || { echo "bench 300 failed"; exit 1; }
 (cd /tmp && TMPDIR=/tmp timeout -k 10 400 rocprofv3 --kernel-trace --stats --output-format csv -d $O/${P}_benchprof -- python3 $R/bench.py > $O/${P}_bench_under_rocprof.json 2> $O/${P}_benchprof.err) || { echo "rocprofv3 bench failed"; exit 1; }
