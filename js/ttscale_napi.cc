@@ -44,13 +44,29 @@ bool parse_common(napi_env env, napi_callback_info info, size_t want, napi_value
            napi_get_value_int32(env, argv[2], &ih) == napi_ok;
 }
 
+// optional trailing argument: the input's pixel format, as `-pix_fmt` in front of `-i` ("yuv420p", the default, or "rgb24")
+bool get_in_fmt(napi_env env, napi_callback_info info, size_t index, int &in_fmt)
+{
+    size_t argc = 8; napi_value argv[8];
+    in_fmt = TTS_FMT_YUV420P;
+    if (napi_get_cb_info(env, info, &argc, argv, nullptr, nullptr) != napi_ok || argc <= index) return true;
+    napi_valuetype t;
+    if (napi_typeof(env, argv[index], &t) != napi_ok || t == napi_undefined || t == napi_null) return true;
+    std::string f;
+    if (!get_string(env, argv[index], f)) return false;
+    if (f == "rgb24") in_fmt = TTS_FMT_RGB24;
+    else if (f != "yuv420p") return false;
+    return true;
+}
+
 napi_value ParseVf(napi_env env, napi_callback_info info)
 {
     napi_value argv[3];
     std::string vf; int32_t iw, ih;
-    if (!parse_common(env, info, 3, argv, vf, iw, ih)) return throw_status(env, "parseVf(vf, iw, ih)", TTS_ERR_INVALID_INPUT);
+    int in_fmt;
+    if (!parse_common(env, info, 3, argv, vf, iw, ih) || !get_in_fmt(env, info, 3, in_fmt)) return throw_status(env, "parseVf(vf, iw, ih[, 'yuv420p' | 'rgb24'])", TTS_ERR_INVALID_INPUT);
     tts_geom g;
-    const int rc = tts_parse_vf(vf.c_str(), iw, ih, &g);
+    const int rc = tts_parse_vf_fmt(vf.c_str(), iw, ih, in_fmt, &g);
     if (rc) return throw_status(env, "filter chain", rc);
     napi_value obj;
     napi_create_object(env, &obj);
@@ -98,7 +114,7 @@ napi_value Terminate(napi_env env, napi_callback_info)
 
 tts_plan *cached_plan(const std::string &vf, int32_t iw, int32_t ih, const tts_geom &g, int *rc)
 {
-    const std::string key = vf + "|" + std::to_string(iw) + "x" + std::to_string(ih);
+    const std::string key = vf + "|" + std::to_string(iw) + "x" + std::to_string(ih) + "|" + std::to_string(g.in_fmt);
     auto it = plans.find(key);
     if (it != plans.end()) { *rc = TTS_OK; return it->second; }
     if (plans.size() >= 32) {                       // bounded: drop everything rather than track ages
@@ -116,17 +132,18 @@ napi_value RunHost(napi_env env, napi_callback_info info)
 {
     napi_value argv[4];
     std::string vf; int32_t iw, ih;
-    if (!parse_common(env, info, 4, argv, vf, iw, ih)) return throw_status(env, "runHost(vf, iw, ih, buffer)", TTS_ERR_INVALID_INPUT);
+    int in_fmt;
+    if (!parse_common(env, info, 4, argv, vf, iw, ih) || !get_in_fmt(env, info, 4, in_fmt)) return throw_status(env, "runHost(vf, iw, ih, buffer[, 'yuv420p' | 'rgb24'])", TTS_ERR_INVALID_INPUT);
     void *src = nullptr; size_t len = 0;
     if (napi_get_buffer_info(env, argv[3], &src, &len) != napi_ok) return throw_status(env, "frames must be a Buffer", TTS_ERR_INVALID_INPUT);
     tts_geom g;
-    int rc = tts_parse_vf(vf.c_str(), iw, ih, &g);
+    int rc = tts_parse_vf_fmt(vf.c_str(), iw, ih, in_fmt, &g);
     if (rc) return throw_status(env, "filter chain", rc);
-    const size_t sb = tts_frame_bytes(g.in_w, g.in_h);
-    if (len == 0 || len % sb) return throw_status(env, "buffer is not a whole number of frames", TTS_ERR_INVALID_INPUT);
-    const int n = int(len / sb);
     tts_plan *plan = cached_plan(vf, iw, ih, g, &rc);
     if (rc) return throw_status(env, "plan", rc);
+    const size_t sb = tts_plan_frame_bytes(plan, 0);      // packed I420, or in_w * in_h * 3 for an rgb24 source
+    if (len == 0 || len % sb) return throw_status(env, "buffer is not a whole number of frames", TTS_ERR_INVALID_INPUT);
+    const int n = int(len / sb);
     const size_t db = tts_plan_frame_bytes(plan, 1);      // packed I420, or out_w * out_h * bpp behind format=rgb24 & co.
     napi_value out; void *dst = nullptr;
     if (napi_create_buffer(env, db * n, &dst, &out) != napi_ok) return throw_status(env, "allocation", TTS_ERR_PROCESSING_FAILED);

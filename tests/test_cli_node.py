@@ -34,6 +34,34 @@ def test_node_addon_parses_like_python(tts):
     assert json.loads(out) == tts.parse_vf(THUMB, 720, 1280).as_dict()
     js = "const t=require(%r);try{t.parseVf('hflip',8,8)}catch(e){console.log(e.message)}" % os.path.join(ROOT, "js")
     assert "INVALID_FORMAT" in subprocess.run([NODE, "-e", js], capture_output=True, text=True, check=True).stdout
+    # the input's pixel format (`-pix_fmt rgb24` in front of `-i`) as an optional last argument
+    js = "const t=require(%r);console.log(JSON.stringify(t.parseVf('scale=96:54',64,36,'rgb24')))" % os.path.join(ROOT, "js")
+    out = subprocess.run([NODE, "-e", js], capture_output=True, text=True, check=True).stdout
+    assert json.loads(out) == tts.parse_vf("scale=96:54", 64, 36, in_fmt="rgb24").as_dict()
+    js = "const t=require(%r);try{t.parseVf('scale=96:54',64,36,'nv12')}catch(e){console.log(e.message)}" % os.path.join(ROOT, "js")
+    assert "INVALID_INPUT" in subprocess.run([NODE, "-e", js], capture_output=True, text=True, check=True).stdout
+
+
+@pytest.mark.gpu
+@needs_node
+def test_node_addon_rgb24_in_and_out(tts, oracle, tmp_path):
+    """runHost with packed RGB on either side: `format=rgb24` ending the chain (the thumbnail's colour conversion,
+    src/services/video.js:329-334) and an rgb24 source (`-pix_fmt rgb24` in front of `-i`)."""
+    yuv = synth.frames("random", 64, 48, 2)
+    rgb = np.random.default_rng(3).integers(0, 256, (2, 64 * 48 * 3), dtype=np.uint8)
+    (tmp_path / "in.yuv").write_bytes(yuv.tobytes())
+    (tmp_path / "in.rgb").write_bytes(rgb.tobytes())
+    js = """
+const fs = require('fs'), t = require(%r);
+fs.writeFileSync(%r, t.runHost('format=rgb24', 64, 48, fs.readFileSync(%r)));
+fs.writeFileSync(%r, t.runHost('scale=96:72', 64, 48, fs.readFileSync(%r), 'rgb24'));
+""" % (os.path.join(ROOT, "js"), str(tmp_path / "out.rgb"), str(tmp_path / "in.yuv"), str(tmp_path / "out.yuv"), str(tmp_path / "in.rgb"))
+    r = subprocess.run([NODE, "-e", js], capture_output=True, text=True)
+    assert r.returncode == 0, r.stdout + r.stderr
+    got = np.frombuffer((tmp_path / "out.rgb").read_bytes(), np.uint8).reshape(2, -1)
+    assert np.array_equal(got, oracle.run_chain(tts.parse_vf("format=rgb24", 64, 48), yuv))
+    got = np.frombuffer((tmp_path / "out.yuv").read_bytes(), np.uint8).reshape(2, -1)
+    assert np.array_equal(got, oracle.run_chain(tts.parse_vf("scale=96:72", 64, 48, in_fmt="rgb24"), rgb))
 
 
 @pytest.mark.gpu
