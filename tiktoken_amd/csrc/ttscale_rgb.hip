@@ -776,7 +776,7 @@ __global__ __launch_bounds__(kScratchThreads) void rgb_scratch_convert4_kernel(c
 {
     static_assert(PX == 4 || PX == 8, "pixels a thread");
     const int frame = a.frame0 + int(blockIdx.y), t = int(threadIdx.x) & (a.tpr - 1);
-    uint8_t *fb = a.dst + size_t(frame) * a.addr.dst_pitch + a.addr.dst_plane[0];
+    uint8_t *fb = a.dst + (a.addr.use_table ? size_t(a.addr.dst_tab[0][frame]) : size_t(frame) * a.addr.dst_pitch + a.addr.dst_plane[0]);
     const int cy = int(blockIdx.x) * (kScratchThreads / a.tpr) + int(threadIdx.x) / a.tpr;   // canvas row
     const bool row_ok = cy < a.canvas_h;
     uint8_t *crow = fb + size_t(row_ok ? cy : 0) * a.dst_stride;
@@ -1843,8 +1843,11 @@ int rgb_scratch_convert(const RgbPlan *p, uint8_t *dst, int dst_stride, int n, c
     a.coef = p->coef;
     a.addr = addr;
     // four pixels a thread through dword accesses where every picture row starts on a dword and holds whole quads
-    const bool quad = !addr.use_table && p->pw % 4 == 0 && (reinterpret_cast<uintptr_t>(dst) & 3u) == 0 && addr.dst_pitch % 4 == 0 &&
-                      addr.dst_plane[0] % 4 == 0 && dst_stride % 4 == 0 && (p->px * p->bpp) % 4 == 0;
+    bool quad = p->pw % 4 == 0 && (reinterpret_cast<uintptr_t>(dst) & 3u) == 0 && dst_stride % 4 == 0 && (p->px * p->bpp) % 4 == 0;
+    if (quad && addr.use_table) {                                  // per-frame pointers (at most kMaxTableFrames a launch)
+        for (int i = 0; i < n && quad; ++i) quad = addr.dst_tab[0][i] % 4 == 0;
+    } else if (quad)
+        quad = addr.dst_pitch % 4 == 0 && addr.dst_plane[0] % 4 == 0;
     const int px_unit = !quad ? 1 : p->pw % 8 == 0 && !p->convert4 ? 8 : 4;
     const int units = p->pw / px_unit;                            // per row; about two units a thread (six pixels without dword accesses) on narrow pictures
     a.tpr = units <= 64 * (quad ? 2 : 6) ? 64 : units <= 128 * (quad ? 2 : 6) ? 128 : 256;
