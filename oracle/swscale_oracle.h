@@ -77,9 +77,14 @@ int tto_sws_yuv420_to_rgb(const uint8_t *sy, const uint8_t *su, const uint8_t *s
 int tto_run_chain_rgb(const tto_chain *c, const uint8_t *sy, const uint8_t *su, const uint8_t *sv,
                       int sys, int sus, int svs, uint8_t *dst, int dstride);
 
-/* One swscale context packed rgb24 (sw x sh, sw even) -> yuv420p (dw x dh), C path, default flags:
- * libswscale/input.c rgb24ToY_c / rgb24ToUV_half_c (14-bit samples), swscale.c hScale16To15_c, output.c
- * yuv2planeX_8_c.  Chroma: ceil(sw / 2) x sh samples scaled to ceil(dw / 2) x ceil(dh / 2). */
+/* sws_init_context()'s chrSrcHSubSample for a packed-RGB source and a 4:2:0 destination, default flags:
+ * 1 (chroma read at half width, rgb24ToUV_half_c) iff (dw >> 1) <= (sw >> 1), else 0 (rgb24ToUV_c per pixel) */
+int tto_rgb_in_half_chroma(int sw, int dw);
+
+/* One swscale context packed rgb24 (sw x sh) -> yuv420p (dw x dh), C path, default flags:
+ * libswscale/input.c rgb24ToY_c / rgb24ToUV_half_c or rgb24ToUV_c (14-bit samples), swscale.c hScale16To15_c,
+ * output.c yuv2planeX_8_c.  Chroma: ceil(sw / 2) x sh samples (sw even) when the width does not grow, else
+ * sw x sh, scaled to ceil(dw / 2) x ceil(dh / 2). */
 int tto_sws_rgb24_to_yuv420(const uint8_t *src, int sstride, int sw, int sh,
                             uint8_t *dy, uint8_t *du, uint8_t *dv, int dys, int dus, int dvs, int dw, int dh, int alg);
 

@@ -304,6 +304,8 @@ RGBIN_CASES = [
     ("format=yuv420p", 64, 48),                        # conversion only
     ("crop=32:21:5:3", 64, 48),                        # crop on RGB, then the conversion pass (odd height out)
     ("scale=200:150,crop=100:74:34:20,pad=132:100:8:6:color=red", 100, 80),
+    ("scale=96:54", 63, 36),                           # an odd source width: fine where the picture widens (chroma is read per pixel there, not per pair)
+    ("scale=64:80", 64, 36),                           # width kept, height enlarged: chroma stays on pixel pairs
 ]
 
 
@@ -349,14 +351,17 @@ RGBIN_STRIP_CASES = [
     ("scale=168:96", 64, 36),                          # a partial wave, odd ratios per axis
     ("scale=720:1280:flags=bilinear", 480, 854),       # 2 taps: windows padded to four
     ("scale=1000:700,crop=800:500:100:101", 640, 360), # crop at an odd row inside the enlargement
+    ("scale=1096:618", 1000, 562),                     # 1.096x: chroma shrinks 1.82 : 1 across and down (8 taps), 8 pixels a lane
+    ("scale=264:200", 131, 99),                        # an odd source width and height
 ]
 
 
 @pytest.mark.parametrize("vf,iw,ih", RGBIN_STRIP_CASES)
 def test_rgb24_input_enlargements_strip_walk(tts, oracle, monkeypatch, vf, iw, ih):
-    """rgb24 in, enlarged: rgbin_strip_kernel (the wave converts its run of pixels once per source row into LDS, lanes
-    filter 8 luma + 4 + 4 chroma columns from there into register rings); the tiled kernel (TTS_NO_RGBIN_STRIP=1)
-    and the oracle give the same bytes; one frame and batches cut into several row segments."""
+    """rgb24 in, widened: rgbin_strip_kernel (lanes are (frame, strip) pairs; the wave converts its runs of pixels once
+    per source row into LDS -- chroma per pixel: rgb24ToUV_c -- and lanes filter 8 luma + 4 + 4 chroma columns from there
+    into register rings); the tiled kernel (TTS_NO_RGBIN_STRIP=1) and the oracle give the same bytes; one frame and
+    batches whose waves straddle frames, cut into several row segments."""
     import torch
     strip = tts.Plan.from_vf(vf, iw, ih, in_fmt="rgb24")
     assert strip.kernel_name(0).startswith("rgbin_strip"), strip.kernel_name(0)
@@ -500,6 +505,6 @@ def test_rgb24_input_host_path_and_rejections(tts, oracle):
     plan = tts.Plan.from_vf("scale=96:54", 64, 36, in_fmt="rgb24")
     src = rgb_frames("zone", 64, 36, 5)
     assert np.array_equal(plan.run_host(src), oracle.run_chain(plan.geom, src))
-    for vf, iw in (("scale=96:54,format=rgb24", 64), ("scale=96:54", 63), ("pad=80:60", 64), ("format=yuvj420p", 64)):
+    for vf, iw in (("scale=96:54,format=rgb24", 64), ("scale=48:27", 63), ("format=yuv420p", 63), ("pad=80:60", 64), ("format=yuvj420p", 64)):
         with pytest.raises(tts.TtsError, match="UNSUPPORTED"):
             tts.Plan.from_vf(vf, iw, 36, in_fmt="rgb24")

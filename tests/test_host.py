@@ -132,6 +132,10 @@ def test_parse_vf_rgb24_input(tts):
         tts.parse_vf("scale=10:10,format=rgb24", 64, 36, in_fmt="rgb24")
     with pytest.raises(tts.TtsError, match="UNSUPPORTED"):
         tts.parse_vf("crop=31:20", 64, 36, in_fmt="rgb24")              # odd width into the pair-averaging chroma reader
+    with pytest.raises(tts.TtsError, match="UNSUPPORTED"):
+        tts.parse_vf("crop=31:20,scale=24:20", 64, 36, in_fmt="rgb24")  # ... a shrink reads pairs too
+    # a widening reads chroma per pixel (sws_init_context: chrSrcHSubSample stays 0): an odd width is fine there
+    assert tts.parse_vf("crop=31:20,scale=48:30", 64, 36, in_fmt="rgb24").as_dict()["pre_w"] == 31
 
 
 def test_frame_bytes(tts):

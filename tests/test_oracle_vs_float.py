@@ -167,3 +167,35 @@ def test_rgb24_input_is_bt601_within_a_level(tts, oracle):
     cr = 128 + 224.0 / 255 * (0.5 * pair(r) - 0.419 * pair(gg) - 0.081 * pair(b))
     vm = axis_matrix(h, h // 2, "bicubic")
     assert np.abs(u - np.clip(vm @ cb, 0, 255)).max() <= 2.0 and np.abs(v - np.clip(vm @ cr, 0, 255)).max() <= 2.0
+
+
+def test_rgb24_input_widened_reads_chroma_per_pixel(tts, oracle):
+    """rgb24 in, widened (480x854 -> 720x1280 in miniature): sws_init_context() keeps chrSrcHSubSample = 0 when the
+    chroma output is wider than half the source, so chroma is one BT.601 difference sample PER PIXEL (rgb24ToUV_c),
+    shrunk src_w -> ceil(dst_w / 2) across and src_h -> ceil(dst_h / 2) down by the cubic -- against the float
+    resampler, within 2 levels; the pair-averaging reading (round 2's oracle) differs from it by more than that on
+    noise, which the last assertion shows so that the test can tell the two apart."""
+    iw, ih, ow, oh = 48, 40, 72, 60
+    g = tts.parse_vf("scale=%d:%d" % (ow, oh), iw, ih, in_fmt="rgb24")
+    rng = np.random.default_rng(5)
+    rgb = rng.integers(0, 256, (1, ih, iw, 3), dtype=np.uint8)
+    y, u, v = synth.split(oracle.run_chain(g, rgb.reshape(1, -1))[0], ow, oh)
+    r, gg, b = (rgb[0, :, :, k].astype(np.float64) for k in range(3))
+    cb = 128 + 224.0 / 255 * (-0.169 * r - 0.331 * gg + 0.5 * b)
+    cr = 128 + 224.0 / 255 * (0.5 * r - 0.419 * gg - 0.081 * b)
+    hm, vm = axis_matrix(iw, ow // 2, "bicubic"), axis_matrix(ih, oh // 2, "bicubic")
+    fu, fv = np.clip(vm @ (cb @ hm.T), 0, 255), np.clip(vm @ (cr @ hm.T), 0, 255)
+    assert np.abs(u - fu).max() <= 2.0 and np.abs(v - fv).max() <= 2.0, (np.abs(u - fu).max(), np.abs(v - fv).max())
+    pair = lambda p: (p[:, 0::2] + p[:, 1::2]) / 2
+    hm2 = axis_matrix(iw // 2, ow // 2, "bicubic")
+    assert np.abs(u - np.clip(vm @ (pair(cb) @ hm2.T), 0, 255)).max() > 4.0
+    lum = 16 + 219.0 / 255 * (0.299 * r + 0.587 * gg + 0.114 * b)
+    fy = np.clip(axis_matrix(ih, oh, "bicubic") @ (lum @ axis_matrix(iw, ow, "bicubic").T), 0, 255)
+    assert np.abs(y - fy)[4:, 4:].max() <= 2.0
+
+
+def test_rgb24_input_chroma_rule(oracle):
+    """(dst_w >> 1) <= (src_w >> 1) picks the pixel-pair reader: the conversion alone, every shrink, and a widening
+    by one column of an even width; everything wider reads chroma per pixel."""
+    L = oracle.lib()
+    assert [L.tto_rgb_in_half_chroma(sw, dw) for sw, dw in ((64, 64), (64, 32), (64, 65), (64, 66), (1920, 3413), (480, 720), (63, 64), (63, 63))] == [1, 1, 1, 0, 0, 0, 0, 1]

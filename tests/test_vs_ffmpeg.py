@@ -8,7 +8,9 @@ web/src/tests/video/portrait.test.js:78,95-96) and BASELINE.json's portrait chai
 tests/synth.py:
   * `-sws_flags bicubic+accurate_rnd+bitexact` (swscale's C path): the oracle must match to 0 LSB;
   * default flags (SIMD paths): at most 1 LSB (north_star's bound).
-Packed-RGB chains run with `bitexact` only (accurate_rnd would switch the unscaled converter off) and are held
+Packed-RGB INPUT chains (`-pix_fmt rgb24` before `-i`) are in the list too: the conversion alone, a shrink and
+three widenings -- they are what would settle which chroma reader (rgb24ToUV_half_c / rgb24ToUV_c) swscale takes.
+Packed-RGB output chains run with `bitexact` only (accurate_rnd would switch the unscaled converter off) and are held
 to 0 LSB as well; the default-flags bound for them is 2 LSB (swscale's SIMD yuv2rgb differs from its C tables).
 The `-m gpu` variant diffs libttscale itself (through the C ABI) against the same FFmpeg outputs.
 """
@@ -28,7 +30,7 @@ PORTRAIT = "scale=1080:1920:force_original_aspect_ratio=increase,crop=1080:1920"
 THUMB_REF = "scale=320x180:force_original_aspect_ratio=decrease,pad=320x180:-1:-1:color=black,format=yuv420p"
 WEB = "scale='min(720,iw)':'min(1280,ih)':force_original_aspect_ratio=decrease"
 
-# (chain, iw, ih, output pix_fmt)
+# (chain, iw, ih, output pix_fmt[, input pix_fmt])
 CHAINS = [
     ("scale=w=720:h=1280", 480, 854, "yuv420p"),
     (THUMB_REF, 720, 1280, "yuv420p"),
@@ -43,7 +45,30 @@ CHAINS = [
     (PORTRAIT + ",format=rgb24", 1920, 1080, "rgb24"),
     ("scale=320x180:force_original_aspect_ratio=decrease,pad=320x180:-1:-1:color=black,format=rgb24", 720, 1280, "rgb24"),
     ("format=rgb24", 64, 48, "rgb24"),
+    # packed rgb24 INPUT (`-pix_fmt rgb24` in front of `-i`; SURVEY.md 8f-1, north_star "YUV420<->RGB"): the conversion
+    # alone and a shrink read chroma from pixel pairs (rgb24ToUV_half_c), every widening reads it per pixel
+    # (rgb24ToUV_c) -- sws_init_context()'s chrSrcHSubSample rule as restated in oracle/swscale_oracle.c, which is
+    # exactly what these chains would settle
+    ("format=yuv420p", 64, 48, "yuv420p", "rgb24"),
+    (PORTRAIT, 1920, 1080, "yuv420p", "rgb24"),
+    ("scale=w=720:h=1280", 480, 854, "yuv420p", "rgb24"),
+    ("scale=320:568:flags=area", 1080, 1920, "yuv420p", "rgb24"),
+    ("scale=96:54", 63, 36, "yuv420p", "rgb24"),
 ]
+CHAINS = [c if len(c) == 5 else c + ("yuv420p",) for c in CHAINS]
+
+
+def source_frames(pattern, iw, ih, n, in_fmt):
+    """Seeded test frames in the chain's input format: packed I420, or packed rgb24 built from the same generator
+    (three full-size planes interleaved)."""
+    if in_fmt == "yuv420p":
+        return synth.frames(pattern, iw, ih, n)
+    y = synth.frames(pattern, 2 * iw, 2 * ih, n)
+    out = np.empty((n, ih, iw, 3), np.uint8)
+    for i in range(n):
+        a, b, c = synth.split(y[i], 2 * iw, 2 * ih)
+        out[i, :, :, 0] = a[::2, ::2]; out[i, :, :, 1] = b; out[i, :, :, 2] = c
+    return out.reshape(n, -1)
 
 
 def with_flags(chain, flags):
@@ -59,12 +84,12 @@ def with_flags(chain, flags):
     return ",".join(out)
 
 
-def run_ffmpeg(tmp_path, chain, iw, ih, pix_fmt, frames, flags):
+def run_ffmpeg(tmp_path, chain, iw, ih, pix_fmt, frames, flags, in_fmt="yuv420p"):
     src = tmp_path / "in.yuv"
     dst = tmp_path / "out.raw"
     frames.tofile(src)
     for attempt in (chain, chain.replace("pad=320x180:-1:-1", "pad=320:180:-1:-1")):
-        cmd = [FFMPEG, "-v", "error", "-y", "-f", "rawvideo", "-pix_fmt", "yuv420p", "-s", "%dx%d" % (iw, ih), "-i", str(src),
+        cmd = [FFMPEG, "-v", "error", "-y", "-f", "rawvideo", "-pix_fmt", in_fmt, "-s", "%dx%d" % (iw, ih), "-i", str(src),
                "-vf", with_flags(attempt, flags), "-sws_flags", flags, "-f", "rawvideo", "-pix_fmt", pix_fmt, str(dst)]
         r = subprocess.run(cmd, capture_output=True, text=True)
         if r.returncode == 0:
@@ -82,31 +107,31 @@ def diff_report(name, got, want):
 
 
 @needs_ffmpeg
-@pytest.mark.parametrize("chain,iw,ih,pix_fmt", CHAINS)
-def test_oracle_vs_ffmpeg(oracle, tts, tmp_path, chain, iw, ih, pix_fmt):
-    rgb = pix_fmt == "rgb24"
-    geom = tts.parse_vf(chain, iw, ih)
+@pytest.mark.parametrize("chain,iw,ih,pix_fmt,in_fmt", CHAINS)
+def test_oracle_vs_ffmpeg(oracle, tts, tmp_path, chain, iw, ih, pix_fmt, in_fmt):
+    rgb = pix_fmt == "rgb24" or in_fmt == "rgb24"
+    geom = tts.parse_vf(chain, iw, ih, in_fmt=in_fmt)
     for pattern in ("random", "limited", "zone", "impulse"):
-        frames = synth.frames(pattern, iw, ih, 2)
+        frames = source_frames(pattern, iw, ih, 2, in_fmt)
         ours = oracle.run_chain(geom, frames).ravel()
-        exact = run_ffmpeg(tmp_path, chain, iw, ih, pix_fmt, frames, "bicubic+bitexact" if rgb else "bicubic+accurate_rnd+bitexact")
-        assert diff_report("oracle vs ffmpeg C path [%s, %s]" % (chain, pattern), ours, exact) == 0
-        default = run_ffmpeg(tmp_path, chain, iw, ih, pix_fmt, frames, "bicubic")
-        assert diff_report("oracle vs ffmpeg default flags [%s, %s]" % (chain, pattern), ours, default) <= (2 if rgb else 1)
+        exact = run_ffmpeg(tmp_path, chain, iw, ih, pix_fmt, frames, "bicubic+bitexact" if pix_fmt == "rgb24" else "bicubic+accurate_rnd+bitexact", in_fmt)
+        assert diff_report("oracle vs ffmpeg C path [%s, %s in, %s]" % (chain, in_fmt, pattern), ours, exact) == 0
+        default = run_ffmpeg(tmp_path, chain, iw, ih, pix_fmt, frames, "bicubic", in_fmt)
+        assert diff_report("oracle vs ffmpeg default flags [%s, %s in, %s]" % (chain, in_fmt, pattern), ours, default) <= (2 if rgb else 1)
 
 
 @needs_ffmpeg
 @pytest.mark.gpu
-@pytest.mark.parametrize("chain,iw,ih,pix_fmt", CHAINS)
-def test_hip_vs_ffmpeg(tts, tmp_path, chain, iw, ih, pix_fmt):
+@pytest.mark.parametrize("chain,iw,ih,pix_fmt,in_fmt", CHAINS)
+def test_hip_vs_ffmpeg(tts, tmp_path, chain, iw, ih, pix_fmt, in_fmt):
     import torch
-    rgb = pix_fmt == "rgb24"
-    plan = tts.Plan.from_vf(chain, iw, ih)
-    frames = synth.frames("random", iw, ih, 2)
+    rgb = pix_fmt == "rgb24" or in_fmt == "rgb24"
+    plan = tts.Plan.from_vf(chain, iw, ih, in_fmt=in_fmt)
+    frames = source_frames("random", iw, ih, 2, in_fmt)
     ours = plan.run_batch(torch.from_numpy(frames).cuda()).cpu().numpy().ravel()
-    exact = run_ffmpeg(tmp_path, chain, iw, ih, pix_fmt, frames, "bicubic+bitexact" if rgb else "bicubic+accurate_rnd+bitexact")
+    exact = run_ffmpeg(tmp_path, chain, iw, ih, pix_fmt, frames, "bicubic+bitexact" if pix_fmt == "rgb24" else "bicubic+accurate_rnd+bitexact", in_fmt)
     assert diff_report("libttscale vs ffmpeg C path [%s]" % chain, ours, exact) == 0
-    default = run_ffmpeg(tmp_path, chain, iw, ih, pix_fmt, frames, "bicubic")
+    default = run_ffmpeg(tmp_path, chain, iw, ih, pix_fmt, frames, "bicubic", in_fmt)
     assert diff_report("libttscale vs ffmpeg default flags [%s]" % chain, ours, default) <= (2 if rgb else 1)
 
 

@@ -23,6 +23,12 @@ bool build_axis_filter(int src, int dst, int one, int alg, AxisFilter &out);
 bool scale_output_size(int iw, int ih, int w, int h, int foar, int fdb, int &ow, int &oh);
 int  crop_origin(int in, int out, double value, bool has_value, int sub = 2);   // sub: chroma grid of the link (2 yuv420p, 1 RGB)
 
+// Packed-RGB source into a 4:2:0 destination (sws_init_context(): "drop every other pixel for chroma calculation
+// unless user wants full chroma"): chroma is read at half width (rgb24ToUV_half_c, pixel-pair sums) only when the
+// chroma output is no wider than half the source, (dst_w >> 1) <= (src_w >> 1) -- the conversion alone and every
+// horizontal shrink; an enlargement reads one chroma sample per pixel (rgb24ToUV_c) and shrinks src_w -> ceil(dst_w / 2).
+inline bool rgb_in_half_chroma(int src_w, int dst_w) { return (dst_w >> 1) <= (src_w >> 1); }
+
 // Validate a resolved geometry; returns TTS_OK or an error.
 int  check_geom(const tts_geom &g);
 

@@ -926,6 +926,7 @@ struct RgbInArgs {
     int32_t frame0;
     int32_t coef[9];                   // ry gy by, ru gu bu, rv gv bv
     int32_t  only_plane;               // >= 0: the launch produces this destination plane alone
+    int32_t  chr_half;                 // 1: chroma samples are pixel-pair sums (rgb24ToUV_half_c), 0: one per pixel (rgb24ToUV_c); filter.h rgb_in_half_chroma()
     uint32_t src_origin, src_extent;   // bytes from a frame's first byte to the pre-cropped origin / to one past its last byte
     FrameAddr addr;
 };
@@ -972,9 +973,12 @@ __global__ __launch_bounds__(kBlock) void rgbin_generic_kernel(const RgbInArgs a
                 if (ci == 0) {
                     const uint8_t *q = row + 3 * (hp + k);
                     s14 = (cr * q[0] + cg * q[1] + cb * q[2] + (32 << 14) + (1 << 8)) >> 9;
-                } else {
+                } else if (a.chr_half) {
                     const uint8_t *q = row + 6 * (hp + k);
                     s14 = (cr * (q[0] + q[3]) + cg * (q[1] + q[4]) + cb * (q[2] + q[5]) + (256 << 15) + (1 << 9)) >> 10;
+                } else {
+                    const uint8_t *q = row + 3 * (hp + k);
+                    s14 = (cr * q[0] + cg * q[1] + cb * q[2] + (256 << 14) + (1 << 8)) >> 9;
                 }
                 acc += s14 * int(hc[k]);
             }
@@ -1034,7 +1038,8 @@ __global__ __launch_bounds__(kBlock) void rgbin_tile_kernel(const RgbInTileArgs 
     uint8_t *raw = reinterpret_cast<uint8_t *>(rgbin_lds) + ((size_t(sym) * (sxm + 64) + size_t(t.th[ci]) * (vt + 1)) * 2 + 3 & ~size_t(3));   // [sy_max][raw_w] source bytes
     const int wave = __builtin_amdgcn_readfirstlane(int(threadIdx.x >> 6)), lane = int(threadIdx.x & 63);
     const int waves = int(blockDim.x >> 6);
-    const int nb = ci ? 6 : 3;                                      // bytes per source sample: a pixel, a pixel pair
+    const int nb = ci && a.chr_half ? 6 : 3;                        // bytes per source sample: a pixel, a pixel pair
+    const int bias = ci ? (256 << 14) + (1 << 8) : (32 << 14) + (1 << 8);   // rgb24ToUV_c / rgb24ToY_c
     int sxlo = 0, nsx = 0, sylo = 0, nsy = 0;
     if (any) {
         const int vxa = a.ox[ci] + ix0 - a.px[ci], vxb = a.ox[ci] + ix1 - 1 - a.px[ci];
@@ -1074,7 +1079,7 @@ __global__ __launch_bounds__(kBlock) void rgbin_tile_kernel(const RgbInTileArgs 
             const uint8_t *q0 = raw + r * raww + int(reinterpret_cast<uintptr_t>(g0) & 3u);
             for (int c = lane; c < nsx; c += 64) {
                 const uint8_t *q = q0 + nb * c;
-                const int v = ci == 0 ? (cr * q[0] + cg * q[1] + cb * q[2] + (32 << 14) + (1 << 8)) >> 9
+                const int v = nb == 3 ? (cr * q[0] + cg * q[1] + cb * q[2] + bias) >> 9
                                       : (cr * (q[0] + q[3]) + cg * (q[1] + q[4]) + cb * (q[2] + q[5]) + (256 << 15) + (1 << 9)) >> 10;
                 s14[r * sxm + c] = int16_t(v);
             }
@@ -1265,77 +1270,96 @@ __global__ __launch_bounds__(kBlock) void rgbin_walk_kernel(const RgbInWalkArgs 
 }
 
 // ---- packed rgb24 in, enlarged: the strip walk on 16-bit samples -----------------------------------------------
-// rgbin_tile_kernel spends its time between barriers.  For enlargements (at most 4 horizontal taps,
-// at most 4 vertical luma taps: the portrait chains from an RGB source) a lane owns 8 luma output columns and the 4
-// chroma columns under them and walks a segment of SOURCE rows, as rgbin_walk_kernel does:
-//   per source row the wave converts the run of pixels its lanes' windows need ONCE -- lane j the pixels 8j .. 8j + 7
-//   of the run (rgb24ToY_c, rgb24ToUV_half_c on its four pairs) -- into three int16 rows in the wave's own LDS;
-//   every lane then reads each column's 4-tap window as three aligned dwords, one v_perm selector per column
-//   undoing the window's halfword parity, and runs hScale16To15_c as two v_dot2 (>> 13, clip to 15 bits) into
-//   register rings kept by ring slot (luma: source row & 3; chroma: & 7 -- an RGB source has chroma on every row,
-//   so that plane shrinks 2 : 1 more than luma and wants up to 8 rows);
+// rgbin_tile_kernel spends its time between barriers.  For horizontal enlargements (at most 4 luma taps
+// per axis: the portrait chains and scale=w=720:h=1280 from an RGB source) a lane owns 8 luma output columns and the 4
+// chroma columns under them and walks a segment of SOURCE rows, as rgbin_walk_kernel does.  An enlargement reads chroma
+// at FULL width (filter.h rgb_in_half_chroma(): rgb24ToUV_c, one sample per pixel), so the chroma planes shrink -- by up
+// to 2 : 1 across (5-8 taps) and, an RGB source having chroma on every row, by 2 : 1 more than luma down the picture:
+//   lanes are the flattened (frame, strip) index -- a 1080-column picture has 135 strips, 2.1 waves a row: per row a
+//   third of the lanes would idle -- so a wave's 64 strips may lie in two (narrow pictures: several) frames; what each
+//   lane converts and where its strip's windows start in the wave's LDS rows comes from a host table per wave start;
+//   per source row the wave converts the runs of pixels its lanes' windows need ONCE, lane i PXL pixels of them, into
+//   three int16 rows (Y, U, V) in the wave's own LDS -- in float: 8-bit channels times 15-bit coefficients, scaled by
+//   2^-9, are exact in fp32's 24 bits, so rgb24ToY_c / rgb24ToUV_c's (sum + bias) >> 9 is three v_pk_fma_f32 per pixel
+//   PAIR and plane, and adding 2^23 - 1/2 to (2 sum + 1) / 1024 leaves floor(sum / 512) in the low mantissa bits (the
+//   1 / 1024 keeps the sum off the rounding ties); each row is stored TWICE, the second copy one sample on, so that
+//   every tap pair of every window is one aligned dword whatever the window's parity;
+//   hScale16To15_c is then two v_dot2 per luma column and CHD per chroma column (>> 13, clip) into register rings kept
+//   by ring slot (luma: source row & 3; chroma: & 7);
 //   output rows whose last source row this was leave: luma 8 sums of 2 v_dot2, chroma 4 + 4 sums of 4, packed.
 // No barrier: a wave's LDS rows are its own, its LDS operations complete in order.
 struct RgbInStripArgs {
     const uint8_t *src;
     uint8_t       *dst;
     const int32_t *tab;
-    uint32_t o_run, o_strip, o_lastl, o_vcol, o_lastc, o_vcoc;      // dword offsets into tab
-    int32_t strips, wpr, oh, och, lvt, cvt, h;                       // 8-column strips a row, waves a row; output rows; vertical taps; source rows
+    uint32_t o_strip, o_wave, o_lastl, o_vcol, o_lastc, o_vcoc;        // dword offsets into tab
+    int32_t strips, total, nframes;                                    // 8-column strips a row; lanes = nframes x strips
+    int32_t oh, och, lvt, cvt, h;                                      // output rows; vertical taps; source rows
     int32_t seg_rows, nseg;
     int32_t src_stride, dst_stride[2];
     uint32_t src_origin, src_extent;
-    int32_t coef[9];
-    int32_t frame0;
+    float cf[3][4];                                                    // per plane: coefficients of R, G, B (x 2^-9) and (2 bias + 1) / 1024
     FrameAddr addr;
 };
 
-constexpr int kRgbInStripRun = 512;                                   // pixels a wave converts per source row at most (8 a lane)
-constexpr int kRgbInStripYB = kRgbInStripRun / 2 + 4, kRgbInStripCB = kRgbInStripRun / 4 + 4;   // dwords of one copy of a luma / chroma row (the odd copy starts one dword in)
+typedef float f32x2_t __attribute__((ext_vector_type(2)));
 
-// (register budget for 3 waves a SIMD: 152 VGPRs; cut to 128 the compiler spills 15 and the kernel is a fifth slower)
-// PXL: pixels of the run a lane converts per row -- 8, or 6 / 4 where the waves' runs are that short (the portrait chain
-// reads 290 pixels a wave: with 8 a lane 27 of the 64 lanes would convert for nothing).
-template <int PXL>
+// PXL: pixels of the wave's runs a lane converts per row (the host takes the smallest of 4 / 6 / 8 that covers every
+// wave's runs: all 64 lanes execute the conversion); CHD: tap pairs of a chroma window (taps <= 4, 6, 8).
+template <int PXL, int CHD>
 __global__ __launch_bounds__(kBlock, 3) void rgbin_strip_kernel(const RgbInStripArgs a)
 {
+    static_assert(PXL == 4 || PXL == 6 || PXL == 8, "pixels a lane converts");
+    constexpr int NP = PXL / 2, NDW = (3 * PXL + 6) / 4;             // pixel pairs; aligned dwords that hold a lane's 3 PXL bytes at any phase
+    constexpr int CB = 32 * PXL + 8;                                 // dwords of one copy of a row (64 PXL samples + slack: windows read whole tap pairs; the odd copy starts one dword in)
+    constexpr int ST = 28 + 4 * CHD;                                 // words of a strip's table entry
     // every row twice: as pairs (s0 s1)(s2 s3).. and, one halfword on, as (s1 s2)(s3 s4)..: a window that starts on an
     // odd sample reads the second copy, so that every tap pair of every window is ONE aligned dword (no v_perm)
-    __shared__ uint32_t ylds[kBlock / 64][2 * kRgbInStripYB], ulds[kBlock / 64][2 * kRgbInStripCB], vlds[kBlock / 64][2 * kRgbInStripCB];
+    __shared__ uint32_t lds[kBlock / 64][3][2 * CB];
     const int wave = __builtin_amdgcn_readfirstlane(int(threadIdx.x >> 6)), lane = int(threadIdx.x & 63);
     const int wid = int(blockIdx.x) * (kBlock / 64) + wave;
-    const int seg = wid / a.wpr, wx = wid - seg * a.wpr;
-    if (seg >= a.nseg) return;                                     // (whole waves; no barrier in this kernel)
-    const int s0 = wx * 64 + lane;
-    const bool live = s0 < a.strips;
-    const int strip = min(s0, a.strips - 1);                       // dead lanes shadow the last strip and store nothing
-    const int frame = a.frame0 + int(blockIdx.z);
+    if (wid > (a.total - 1) / 64) return;                          // (whole waves; no barrier in this kernel)
+    const int g0 = wid * 64, seg = int(blockIdx.y);
+    const int nlive = min(64, a.total - g0);
+    const bool live = lane < nlive;
+    const int lc = min(lane, nlive - 1);                           // dead lanes shadow the last live one and store nothing
+    const int fA = g0 / a.strips, sA = g0 - fA * a.strips;         // wave-uniform: the wave's first frame, its first strip there
+    const int32_t *WC = a.tab + a.o_wave + 4 * (size_t(sA) * 64 + lane), *WS = a.tab + a.o_wave + 4 * (size_t(sA) * 64 + lc);
+    const int cpx = WC[0], cfr = fA + WC[1];                       // what this lane converts: first pixel (< 0: nothing), frame
+    const int frame = fA + WS[2], adj = WS[3];                     // this lane's strip: its frame, LDS sample of pixel 0 of that frame's row
+    const int strip = sA + lc - WS[2] * a.strips;
+    const bool conv = cpx >= 0 && cfr < a.nframes;
     const uint8_t *fb;
     uint8_t *dy, *du, *dv;
     if (a.addr.use_table) {
-        fb = a.src + a.addr.src_tab[0][frame];
+        fb = a.src + a.addr.src_tab[0][conv ? cfr : 0];
         dy = a.dst + a.addr.dst_tab[0][frame]; du = a.dst + a.addr.dst_tab[1][frame]; dv = a.dst + a.addr.dst_tab[2][frame];
     } else {
-        fb = a.src + size_t(frame) * a.addr.src_pitch + a.addr.src_plane[0];
+        fb = a.src + size_t(conv ? cfr : 0) * a.addr.src_pitch + a.addr.src_plane[0];
         uint8_t *dpf = a.dst + size_t(frame) * a.addr.dst_pitch;
         dy = dpf + a.addr.dst_plane[0]; du = dpf + a.addr.dst_plane[1]; dv = dpf + a.addr.dst_plane[2];
     }
     dy += 8 * size_t(strip); du += 4 * size_t(strip); dv += 4 * size_t(strip);
     const uintptr_t lo = reinterpret_cast<uintptr_t>(fb), hi = lo + a.src_extent;
-    const int run0 = a.tab[a.o_run + 2 * wx], run_px = a.tab[a.o_run + 2 * wx + 1];      // wave-uniform
-    static_assert(PXL == 4 || PXL == 6 || PXL == 8, "pixels a lane converts");
-    constexpr int NP = PXL / 2, NDW = (3 * PXL + 6) / 4;             // pixel pairs; aligned dwords that hold a lane's 3 PXL bytes at any phase
-    const bool conv = PXL * lane < run_px;
-    const uint8_t *pcol = fb + a.src_origin + 3 * size_t(run0 + PXL * lane);
+    const uint8_t *pcol = fb + a.src_origin + 3 * size_t(conv ? cpx : 0);
     // this lane's windows and taps
-    int li[8], ci[4];                                              // first dword of each window, in the copy its parity picks (host)
-    uint32_t lt[8][2], ct[4][2];
+    int li[8], ci[4];                                              // first dword of each window, in the copy its parity picks
+    uint32_t lt[8][2], ct[4][CHD];
     {
-        const int32_t *T = a.tab + a.o_strip + 36 * size_t(strip);
+        const int32_t *T = a.tab + a.o_strip + size_t(ST) * strip;
 #pragma unroll
-        for (int c = 0; c < 8; ++c) { li[c] = T[c]; lt[c][0] = uint32_t(T[8 + 2 * c]); lt[c][1] = uint32_t(T[9 + 2 * c]); }
+        for (int c = 0; c < 8; ++c) {
+            const int h = T[c] + adj;
+            li[c] = (h & 1) ? CB + 1 + (h >> 1) : (h >> 1);
+            lt[c][0] = uint32_t(T[8 + 2 * c]); lt[c][1] = uint32_t(T[9 + 2 * c]);
+        }
 #pragma unroll
-        for (int j = 0; j < 4; ++j) { ci[j] = T[24 + j]; ct[j][0] = uint32_t(T[28 + 2 * j]); ct[j][1] = uint32_t(T[29 + 2 * j]); }
+        for (int j = 0; j < 4; ++j) {
+            const int h = T[24 + j] + adj;
+            ci[j] = (h & 1) ? CB + 1 + (h >> 1) : (h >> 1);
+#pragma unroll
+            for (int k = 0; k < CHD; ++k) ct[j][k] = uint32_t(T[28 + CHD * j + k]);
+        }
     }
     const int32_t *lastl = a.tab + a.o_lastl, *lastc = a.tab + a.o_lastc;
     const uint32_t *vcol = reinterpret_cast<const uint32_t *>(a.tab + a.o_vcol), *vcoc = reinterpret_cast<const uint32_t *>(a.tab + a.o_vcoc);
@@ -1348,7 +1372,9 @@ __global__ __launch_bounds__(kBlock, 3) void rgbin_strip_kernel(const RgbInStrip
     if (yc < yce) { rstart = min(rstart, int(lastc[yc]) - (a.cvt - 1)); rlast = max(rlast, int(lastc[yce - 1])); }
     rstart = max(rstart, 0);
     int nl = yl < yle ? int(lastl[yl]) : -1, nc = yc < yce ? int(lastc[yc]) : -1;
-    const int ry = a.coef[0], gy = a.coef[1], by = a.coef[2], ru = a.coef[3], gu = a.coef[4], bu = a.coef[5], rv = a.coef[6], gv = a.coef[7], bv = a.coef[8];
+    f32x2_t cR[3], cG[3], cB[3], c0[3];
+#pragma unroll
+    for (int p = 0; p < 3; ++p) { cR[p] = a.cf[p][0]; cG[p] = a.cf[p][1]; cB[p] = a.cf[p][2]; c0[p] = a.cf[p][3]; }
     uint32_t ringl[8][2], ringu[4][4], ringv[4][4];
 #pragma unroll
     for (int i = 0; i < 16; ++i) { (&ringl[0][0])[i] = 0; (&ringu[0][0])[i] = 0; (&ringv[0][0])[i] = 0; }
@@ -1376,66 +1402,57 @@ __global__ __launch_bounds__(kBlock, 3) void rgbin_strip_kernel(const RgbInStrip
         for (int s = 0; s < 8; ++s) {
             const int r = r0 + s;
             if (r < rstart || r > rlast) continue;                 // wave-uniform
-            // ---- convert this lane's PXL pixels of the run
+            // ---- convert this lane's PXL pixels of the wave's runs
             {
                 const uint32_t ph = uint32_t(reinterpret_cast<uintptr_t>(pcol + size_t(r) * a.src_stride) & 3u);
                 uint32_t w[NDW - 1];
 #pragma unroll
                 for (int k = 0; k < NDW - 1; ++k) w[k] = __builtin_amdgcn_alignbyte(nx[k + 1], nx[k], ph);
                 fetch(min(r + 1, rlast), nx);
-                int R[PXL], G[PXL], B[PXL];
-#pragma unroll
-                for (int i = 0; i < PXL; ++i) {
-                    const int b0 = 3 * i;
-                    R[i] = int((w[b0 >> 2] >> (8 * (b0 & 3))) & 255u);
-                    G[i] = int((w[(b0 + 1) >> 2] >> (8 * ((b0 + 1) & 3))) & 255u);
-                    B[i] = int((w[(b0 + 2) >> 2] >> (8 * ((b0 + 2) & 3))) & 255u);
-                }
-                uint32_t yy[NP];
+                auto ub = [&](int b) { return float((w[b >> 2] >> (8 * (b & 3))) & 255u); };   // v_cvt_f32_ubyteN
+                uint32_t pk[3][NP];
 #pragma unroll
                 for (int i = 0; i < NP; ++i) {
-                    const int y0 = (__mul24(ry, R[2 * i]) + __mul24(gy, G[2 * i]) + __mul24(by, B[2 * i]) + (32 << 14) + (1 << 8)) >> 9;
-                    const int y1 = (__mul24(ry, R[2 * i + 1]) + __mul24(gy, G[2 * i + 1]) + __mul24(by, B[2 * i + 1]) + (32 << 14) + (1 << 8)) >> 9;
-                    yy[i] = uint32_t(y0) | uint32_t(y1) << 16;                      // (14-bit values: no sign to keep)
-                }
-                int u14[NP], v14[NP];
+                    const f32x2_t R = {ub(6 * i), ub(6 * i + 3)}, G = {ub(6 * i + 1), ub(6 * i + 4)}, B = {ub(6 * i + 2), ub(6 * i + 5)};
 #pragma unroll
-                for (int j = 0; j < NP; ++j) {
-                    const int sr = R[2 * j] + R[2 * j + 1], sg = G[2 * j] + G[2 * j + 1], sb = B[2 * j] + B[2 * j + 1];
-                    u14[j] = (__mul24(ru, sr) + __mul24(gu, sg) + __mul24(bu, sb) + (256 << 15) + (1 << 9)) >> 10;
-                    v14[j] = (__mul24(rv, sr) + __mul24(gv, sg) + __mul24(bv, sb) + (256 << 15) + (1 << 9)) >> 10;
+                    for (int p = 0; p < 3; ++p) {
+                        f32x2_t t = R * cR[p] + (G * cG[p] + (B * cB[p] + c0[p]));      // exact: (2 sum + 1) / 1024
+                        t += 8388607.5f;                                              // 2^23 + floor(sum / 512), exactly
+                        const float t0 = t.x, t1 = t.y;                               // (__builtin_bit_cast of a vector ELEMENT reads element 0 whichever is named: copy out first)
+                        pk[p][i] = __builtin_amdgcn_perm(__builtin_bit_cast(uint32_t, t1), __builtin_bit_cast(uint32_t, t0), 0x05040100);
+                    }
                 }
                 if (conv) {
-                    // even copy, then the odd one: dword m = (s[2m + 1], s[2m + 2]); its first and last halfword belong to the neighbours' dwords
 #pragma unroll
-                    for (int k = 0; k < NP; ++k) ylds[wave][NP * lane + k] = yy[k];
-                    uint32_t *yb = &ylds[wave][kRgbInStripYB + 1 + NP * lane];
-                    reinterpret_cast<uint16_t *>(yb - 1)[1] = uint16_t(yy[0]);
+                    for (int p = 0; p < 3; ++p) {
+                        // even copy, then the odd one: dword m = (s[2m + 1], s[2m + 2]); its first and last halfword belong to the neighbours' dwords
+                        uint32_t *ea = &lds[wave][p][NP * lane], *ob = &lds[wave][p][CB + 1 + NP * lane];
 #pragma unroll
-                    for (int k = 0; k < NP - 1; ++k) yb[k] = __builtin_amdgcn_perm(yy[k + 1], yy[k], 0x05040302);
-                    reinterpret_cast<uint16_t *>(yb + NP - 1)[0] = uint16_t(yy[NP - 1] >> 16);
-                    // chroma (NP samples a lane: an odd count leaves lanes on either parity): halfword stores
-                    uint16_t *ua = reinterpret_cast<uint16_t *>(&ulds[wave][0]) + NP * lane, *ub = reinterpret_cast<uint16_t *>(&ulds[wave][kRgbInStripCB + 1]) + NP * lane - 1;
-                    uint16_t *va = reinterpret_cast<uint16_t *>(&vlds[wave][0]) + NP * lane, *vb = reinterpret_cast<uint16_t *>(&vlds[wave][kRgbInStripCB + 1]) + NP * lane - 1;
+                        for (int k = 0; k < NP; ++k) ea[k] = pk[p][k];
+                        reinterpret_cast<uint16_t *>(ob - 1)[1] = uint16_t(pk[p][0]);
 #pragma unroll
-                    for (int k = 0; k < NP; ++k) { ua[k] = uint16_t(u14[k]); ub[k] = uint16_t(u14[k]); va[k] = uint16_t(v14[k]); vb[k] = uint16_t(v14[k]); }
+                        for (int k = 0; k < NP - 1; ++k) ob[k] = __builtin_amdgcn_perm(pk[p][k + 1], pk[p][k], 0x05040302);
+                        reinterpret_cast<uint16_t *>(ob + NP - 1)[0] = uint16_t(pk[p][NP - 1] >> 16);
+                    }
                 }
             }
             __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
             __builtin_amdgcn_wave_barrier();
             __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
             // ---- hScale16To15_c from the wave's rows into the rings
+            const uint32_t *Y = lds[wave][0], *U = lds[wave][1], *V = lds[wave][2];
 #pragma unroll
             for (int c = 0; c < 8; ++c) {
-                const int acc = dot2(ylds[wave][li[c]], lt[c][0], dot2(ylds[wave][li[c] + 1], lt[c][1], 0)) >> 13;
+                const int acc = dot2(Y[li[c]], lt[c][0], dot2(Y[li[c] + 1], lt[c][1], 0)) >> 13;
                 const uint32_t t = uint32_t(min(acc, 32767));
                 ringl[c][(s & 3) / 2] = (s & 1) ? __builtin_amdgcn_perm(t, ringl[c][(s & 3) / 2], 0x05040100) : __builtin_amdgcn_perm(ringl[c][(s & 3) / 2], t, 0x07060100);
             }
 #pragma unroll
             for (int j = 0; j < 4; ++j) {
-                const int au = dot2(ulds[wave][ci[j]], ct[j][0], dot2(ulds[wave][ci[j] + 1], ct[j][1], 0)) >> 13;
-                const int av = dot2(vlds[wave][ci[j]], ct[j][0], dot2(vlds[wave][ci[j] + 1], ct[j][1], 0)) >> 13;
-                const uint32_t tu = uint32_t(min(au, 32767)), tv = uint32_t(min(av, 32767));
+                int au = 0, av = 0;
+#pragma unroll
+                for (int k = 0; k < CHD; ++k) { au = dot2(U[ci[j] + k], ct[j][k], au); av = dot2(V[ci[j] + k], ct[j][k], av); }
+                const uint32_t tu = uint32_t(min(au >> 13, 32767)), tv = uint32_t(min(av >> 13, 32767));
                 ringu[j][s / 2] = (s & 1) ? __builtin_amdgcn_perm(tu, ringu[j][s / 2], 0x05040100) : __builtin_amdgcn_perm(ringu[j][s / 2], tu, 0x07060100);
                 ringv[j][s / 2] = (s & 1) ? __builtin_amdgcn_perm(tv, ringv[j][s / 2], 0x05040100) : __builtin_amdgcn_perm(ringv[j][s / 2], tv, 0x07060100);
             }
@@ -1867,6 +1884,7 @@ namespace tts {
 
 struct RgbInPlan {
     tts_geom g{};
+    bool half = true;                  // chroma read as pixel-pair sums (no horizontal enlargement), else one sample per pixel
     AxisFilter lh, lv, ch, cv;
     int32_t *d_pos[4] = {nullptr, nullptr, nullptr, nullptr};
     int16_t *d_taps[4] = {nullptr, nullptr, nullptr, nullptr};
@@ -1877,11 +1895,13 @@ struct RgbInPlan {
     // rgbin_walk_kernel (the conversion alone): per chroma output row its last source row, then its taps by ring slot
     bool walk = false;
     int32_t *d_walk = nullptr;
-    // rgbin_strip_kernel (enlargements): runs per wave column, per-strip windows and taps, vertical tables
+    // rgbin_strip_kernel (horizontal enlargements): per-strip windows and taps, per-wave-start conversion / placement
+    // table, vertical tables
     bool strip = false;
     int32_t *d_strip = nullptr;
-    uint32_t so_run = 0, so_strip = 0, so_lastl = 0, so_vcol = 0, so_lastc = 0, so_vcoc = 0;
-    int strips = 0, wpr = 0, pxl = 8;
+    uint32_t so_strip = 0, so_wave = 0, so_lastl = 0, so_vcol = 0, so_lastc = 0, so_vcoc = 0;
+    int strips = 0, pxl = 8, chd = 2;
+    int seg_knob = 0;                  // TTS_RGBIN_SEG at plan creation: row segments a launch (0: the launch decides)
     char name[96] = "";
 };
 
@@ -1924,16 +1944,18 @@ static bool rgbin_tile_shape(const RgbInRect &r, const AxisFilter &h, const Axis
 int rgbin_plan_create(const tts_geom &g, RgbInPlan **out)
 {
     *out = nullptr;
-    if (g.in_fmt != TTS_FMT_RGB24 || g.out_fmt != TTS_FMT_YUV420P || g.out_range != TTS_RANGE_KEEP || (g.pre_w & 1)) {
-        set_last_error("rgb24 in: the chain must hand out yuv420p (no range step) and read an even width");
+    const bool half = rgb_in_half_chroma(g.pre_w, g.sc_w);           // sws_init_context()'s chrSrcHSubSample for this context
+    if (g.in_fmt != TTS_FMT_RGB24 || g.out_fmt != TTS_FMT_YUV420P || g.out_range != TTS_RANGE_KEEP || (half && (g.pre_w & 1))) {
+        set_last_error("rgb24 in: the chain must hand out yuv420p (no range step) and, unless it widens the picture, read an even width");
         return TTS_ERR_UNSUPPORTED;
     }
     RgbInPlan *p = new (std::nothrow) RgbInPlan();
     if (!p) return TTS_ERR_INITIALIZATION_FAILED;
     p->g = g;
+    p->half = half;
     int rc = TTS_OK;
     if (!build_axis_filter(g.pre_w, g.sc_w, 1 << 14, g.alg, p->lh) || !build_axis_filter(g.pre_h, g.sc_h, 1 << 12, g.alg, p->lv) ||
-        !build_axis_filter(g.pre_w / 2, (g.sc_w + 1) >> 1, 1 << 14, g.alg, p->ch) || !build_axis_filter(g.pre_h, (g.sc_h + 1) >> 1, 1 << 12, g.alg, p->cv)) {
+        !build_axis_filter(half ? g.pre_w / 2 : g.pre_w, (g.sc_w + 1) >> 1, 1 << 14, g.alg, p->ch) || !build_axis_filter(g.pre_h, (g.sc_h + 1) >> 1, 1 << 12, g.alg, p->cv)) {
         set_last_error("filter tables"); rc = TTS_ERR_INVALID_INPUT;
     }
     const AxisFilter *f[4] = {&p->lh, &p->lv, &p->ch, &p->cv};
@@ -1945,11 +1967,11 @@ int rgbin_plan_create(const tts_geom &g, RgbInPlan **out)
         for (size_t budget : {size_t(32768), size_t(65536)})        // (64 KiB: the most a workgroup gets without opting in)
             if (!p->tiled)
                 p->tiled = rgbin_tile_shape(r0, p->lh, p->lv, 3, budget, p->th[0], p->sx_max[0], p->sy_max[0]) &&
-                           rgbin_tile_shape(r1, p->ch, p->cv, 6, budget, p->th[1], p->sx_max[1], p->sy_max[1]);
+                           rgbin_tile_shape(r1, p->ch, p->cv, half ? 6 : 3, budget, p->th[1], p->sx_max[1], p->sy_max[1]);
         if (p->tiled) {
             p->tiles_y[0] = (r0.canvas_h + p->th[0] - 1) / p->th[0]; p->tiles_y[1] = (r1.canvas_h + p->th[1] - 1) / p->th[1];
             const AxisFilter *vf[2] = {&p->lv, &p->cv};
-            for (int k = 0; k < 2; ++k) p->lds_bytes = std::max(p->lds_bytes, rgbin_tile_lds(p->sy_max[k], p->sx_max[k], p->th[k], vf[k]->size, k ? 6 : 3));
+            for (int k = 0; k < 2; ++k) p->lds_bytes = std::max(p->lds_bytes, rgbin_tile_lds(p->sy_max[k], p->sx_max[k], p->th[k], vf[k]->size, k && half ? 6 : 3));
         }
     }
     // The conversion alone (nothing in the chain resizes, crops or pads): the streaming walk.  Its arithmetic has the
@@ -1977,81 +1999,100 @@ int rgbin_plan_create(const tts_geom &g, RgbInPlan **out)
             else p->walk = true;
         }
     }
-    // Enlargements (<= 4 taps across, <= 4 luma taps down): the strip walk on 16-bit samples, if every wave's run of
-    // source pixels fits what its 64 lanes convert per row
+    // Horizontal enlargements (full-width chroma; <= 4 luma taps per axis, <= 8 chroma taps per axis): the strip walk on
+    // 16-bit samples, if every wave's runs of source pixels fit what its 64 lanes convert per row
     if (!rc && !p->walk && !std::getenv("TTS_FORCE_GENERIC") && !(std::getenv("TTS_NO_RGBIN_STRIP") && std::atoi(std::getenv("TTS_NO_RGBIN_STRIP")))) {
         auto monotone = [](const std::vector<int32_t> &v) { for (size_t i = 1; i < v.size(); ++i) if (v[i] < v[i - 1]) return false; return true; };
         const int lht = p->lh.size, cht = p->ch.size, lvt = p->lv.size, cvt = p->cv.size;
-        bool ok = !g.do_pad && g.out_w == g.crop_w && g.out_h == g.crop_h && g.out_w % 8 == 0 && g.out_w >= 8 && lht <= 4 && cht <= 4 && lvt <= 4 && cvt <= 8 &&
+        bool ok = !half && !g.do_pad && g.out_w == g.crop_w && g.out_h == g.crop_h && g.out_w % 8 == 0 && g.out_w >= 64 && lht <= 4 && cht <= 8 && lvt <= 4 && cvt <= 8 &&
                   g.pre_h >= 8 && monotone(p->lh.pos) && monotone(p->ch.pos) && monotone(p->lv.pos) && monotone(p->cv.pos);
         if (ok) {
             const int ox = g.crop_x, oy = g.crop_y, oxc = g.crop_x >> 1, oyc = g.crop_y >> 1;
-            const int strips = g.out_w / 8, wpr = (strips + 63) / 64, oh = g.out_h, och = (g.out_h + 1) >> 1;
+            const int strips = g.out_w / 8, oh = g.out_h, och = (g.out_h + 1) >> 1;
+            const int chd = cht <= 4 ? 2 : cht <= 6 ? 3 : 4, st = 28 + 4 * chd;
             ok = ox + g.out_w <= int(p->lh.pos.size()) && oxc + g.out_w / 2 <= int(p->ch.pos.size()) && oy + oh <= int(p->lv.pos.size()) && oyc + och <= int(p->cv.pos.size());
             std::vector<int32_t> t;
-            std::vector<int> run0(size_t(wpr), 0);
-            int max_len = 0;
-            p->so_run = 0;
-            t.resize(size_t(2) * wpr);
-            for (int wx = 0; wx < wpr && ok; ++wx) {
-                const int first = 64 * wx, last = std::min(strips, first + 64) - 1;
-                const int lmin = p->lh.pos[ox + 8 * first], lmax = p->lh.pos[ox + 8 * last + 7] + 4;
-                const int cmin = 2 * p->ch.pos[oxc + 4 * first], cmax = 2 * (p->ch.pos[oxc + 4 * last + 3] + 4);
-                run0[wx] = std::min(lmin, cmin) & ~1;
-                const int len = std::max(lmax, cmax) - run0[wx];
-                if (len > kRgbInStripRun) ok = false;
-                max_len = std::max(max_len, len);
-                t[2 * size_t(wx)] = run0[wx]; t[2 * size_t(wx) + 1] = len;
-            }
+            std::vector<int> slo(size_t(strips), 0), shi(size_t(strips), 0);     // source pixels a strip's windows touch: [lo, hi), lo even
             if (ok) {
                 auto pk = [](int a0, int a1) { return int32_t(uint32_t(uint16_t(int16_t(a0))) | uint32_t(uint16_t(int16_t(a1))) << 16); };
-                p->so_strip = uint32_t(t.size());
-                t.resize(t.size() + size_t(36) * strips, 0);
+                p->so_strip = 0;
+                t.resize(size_t(st) * strips, 0);
                 for (int sidx = 0; sidx < strips; ++sidx) {
-                    int32_t *T = t.data() + p->so_strip + size_t(36) * sidx;
-                    const int r0 = run0[sidx / 64];
+                    int32_t *T = t.data() + size_t(st) * sidx;
+                    int lo = INT32_MAX, hi = 0;
                     for (int c = 0; c < 8; ++c) {
                         const int vx = ox + 8 * sidx + c;
                         int tp[4] = {0, 0, 0, 0};
                         for (int k = 0; k < lht; ++k) tp[k] = p->lh.taps[size_t(vx) * lht + k];
-                        const int h = p->lh.pos[vx] - r0;                          // first sample of the window; odd: the second copy
-                        T[c] = (h & 1) ? kRgbInStripYB + 1 + (h >> 1) : (h >> 1);
+                        T[c] = p->lh.pos[vx];                                    // first sample of the window (a pixel of the pre-cropped row)
                         T[8 + 2 * c] = pk(tp[0], tp[1]); T[9 + 2 * c] = pk(tp[2], tp[3]);
+                        lo = std::min(lo, p->lh.pos[vx]); hi = std::max(hi, p->lh.pos[vx] + lht);
                     }
                     for (int j = 0; j < 4; ++j) {
                         const int vx = oxc + 4 * sidx + j;
-                        int tp[4] = {0, 0, 0, 0};
+                        int tp[8] = {0, 0, 0, 0, 0, 0, 0, 0};
                         for (int k = 0; k < cht; ++k) tp[k] = p->ch.taps[size_t(vx) * cht + k];
-                        const int h = p->ch.pos[vx] - r0 / 2;
-                        T[24 + j] = (h & 1) ? kRgbInStripCB + 1 + (h >> 1) : (h >> 1);
-                        T[28 + 2 * j] = pk(tp[0], tp[1]); T[29 + 2 * j] = pk(tp[2], tp[3]);
+                        T[24 + j] = p->ch.pos[vx];
+                        for (int k = 0; k < chd; ++k) T[28 + chd * j + k] = pk(tp[2 * k], tp[2 * k + 1]);
+                        lo = std::min(lo, p->ch.pos[vx]); hi = std::max(hi, p->ch.pos[vx] + cht);
                     }
+                    slo[sidx] = lo & ~1; shi[sidx] = hi;
                 }
-                p->so_lastl = uint32_t(t.size()); t.resize(t.size() + oh);
-                p->so_vcol = uint32_t(t.size()); t.resize(t.size() + size_t(2) * oh);
-                for (int y = 0; y < oh; ++y) {
-                    const int pos = p->lv.pos[oy + y];
-                    int slot[4] = {0, 0, 0, 0};
-                    for (int j = 0; j < lvt; ++j) slot[(pos + j) & 3] = p->lv.taps[size_t(oy + y) * lvt + j];
-                    t[p->so_lastl + y] = pos + lvt - 1;
-                    t[p->so_vcol + 2 * size_t(y)] = pk(slot[0], slot[1]); t[p->so_vcol + 2 * size_t(y) + 1] = pk(slot[2], slot[3]);
+                // per wave start sA (the wave's first strip inside its first frame) and lane: what the lane converts
+                // {first pixel or -1, frame - first frame} and where its strip lies {frame - first frame, LDS sample of
+                // pixel 0 of that frame's row}: a wave's 64 strips are cut into one piece per frame they lie in, every
+                // piece's run of pixels is dealt PXL a lane, piece after piece
+                p->so_wave = uint32_t(t.size());
+                t.resize(t.size() + size_t(4) * 64 * strips, 0);
+                int pxl = 0;
+                for (int cand : {4, 6, 8}) {
+                    bool fits = true;
+                    for (int sA = 0; sA < strips && fits; ++sA) {
+                        int32_t *W = t.data() + p->so_wave + size_t(4) * 64 * sA;
+                        for (int i = 0; i < 64; ++i) { W[4 * i] = -1; W[4 * i + 1] = 0; }
+                        int used = 0;                                          // conversion lanes dealt so far
+                        for (int i = 0, fd = 0; i < 64 && fits; ++fd) {
+                            const int first = fd ? 0 : sA, count = std::min(64 - i, strips - first), lastS = first + count - 1;
+                            const int lo = slo[first];
+                            int hi = 0;
+                            for (int q = first; q <= lastS; ++q) hi = std::max(hi, shi[q]);
+                            const int lanes = (hi - lo + cand - 1) / cand;
+                            if (used + lanes > 64) { fits = false; break; }
+                            for (int q = 0; q < lanes; ++q) { W[4 * (used + q)] = lo + cand * q; W[4 * (used + q) + 1] = fd; }
+                            for (int q = 0; q < count; ++q) { W[4 * (i + q) + 2] = fd; W[4 * (i + q) + 3] = cand * used - lo; }
+                            used += lanes; i += count;
+                        }
+                    }
+                    if (fits) { pxl = cand; break; }
                 }
-                p->so_lastc = uint32_t(t.size()); t.resize(t.size() + och);
-                p->so_vcoc = uint32_t(t.size()); t.resize(t.size() + size_t(4) * och);
-                for (int y = 0; y < och; ++y) {
-                    const int pos = p->cv.pos[oyc + y];
-                    int slot[8] = {0, 0, 0, 0, 0, 0, 0, 0};
-                    for (int j = 0; j < cvt; ++j) slot[(pos + j) & 7] = p->cv.taps[size_t(oyc + y) * cvt + j];
-                    t[p->so_lastc + y] = pos + cvt - 1;
-                    for (int k = 0; k < 4; ++k) t[p->so_vcoc + 4 * size_t(y) + k] = pk(slot[2 * k], slot[2 * k + 1]);
+                ok = pxl != 0;
+                if (ok) {
+                    p->so_lastl = uint32_t(t.size()); t.resize(t.size() + oh);
+                    p->so_vcol = uint32_t(t.size()); t.resize(t.size() + size_t(2) * oh);
+                    for (int y = 0; y < oh; ++y) {
+                        const int pos = p->lv.pos[oy + y];
+                        int slot[4] = {0, 0, 0, 0};
+                        for (int j = 0; j < lvt; ++j) slot[(pos + j) & 3] = p->lv.taps[size_t(oy + y) * lvt + j];
+                        t[p->so_lastl + y] = pos + lvt - 1;
+                        t[p->so_vcol + 2 * size_t(y)] = pk(slot[0], slot[1]); t[p->so_vcol + 2 * size_t(y) + 1] = pk(slot[2], slot[3]);
+                    }
+                    p->so_lastc = uint32_t(t.size()); t.resize(t.size() + och);
+                    p->so_vcoc = uint32_t(t.size()); t.resize(t.size() + size_t(4) * och);
+                    for (int y = 0; y < och; ++y) {
+                        const int pos = p->cv.pos[oyc + y];
+                        int slot[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+                        for (int j = 0; j < cvt; ++j) slot[(pos + j) & 7] = p->cv.taps[size_t(oyc + y) * cvt + j];
+                        t[p->so_lastc + y] = pos + cvt - 1;
+                        for (int k = 0; k < 4; ++k) t[p->so_vcoc + 4 * size_t(y) + k] = pk(slot[2 * k], slot[2 * k + 1]);
+                    }
+                    if (!upload_vec(p->d_strip, t)) { set_last_error("table upload failed (hipMalloc / hipMemcpy)"); rc = TTS_ERR_INITIALIZATION_FAILED; }
+                    else { p->strip = true; p->strips = strips; p->pxl = pxl; p->chd = chd; p->seg_knob = std::getenv("TTS_RGBIN_SEG") ? std::atoi(std::getenv("TTS_RGBIN_SEG")) : 0; }
                 }
-                if (!upload_vec(p->d_strip, t)) { set_last_error("table upload failed (hipMalloc / hipMemcpy)"); rc = TTS_ERR_INITIALIZATION_FAILED; }
-                else { p->strip = true; p->strips = strips; p->wpr = wpr; p->pxl = max_len <= 256 ? 4 : max_len <= 384 ? 6 : 8; }
             }
         }
     }
     if (p->walk) std::snprintf(p->name, sizeof p->name, "rgbin_walk<%d>", p->cv.size);
-    else if (p->strip) std::snprintf(p->name, sizeof p->name, "rgbin_strip<%d,%d,%d,%d,%dpx>", p->lh.size, p->lv.size, p->ch.size, p->cv.size, p->pxl);
+    else if (p->strip) std::snprintf(p->name, sizeof p->name, "rgbin_strip<%d,%d,%d,%d,%dpx>", p->lh.size, p->lv.size, p->ch.size, p->cv.size, p->pxl);   // luma taps across / down, chroma taps across / down
     else if (p->tiled) std::snprintf(p->name, sizeof p->name, "rgbin_tile<%d,%d>", p->th[0], p->th[1]);
     else std::snprintf(p->name, sizeof p->name, "rgbin_generic<%d,%d,%d,%d>", p->lh.size, p->lv.size, p->ch.size, p->cv.size);
     if (rc) { rgbin_plan_destroy(p); return rc; }
@@ -2086,6 +2127,7 @@ int rgbin_launch(const RgbInPlan *p, const uint8_t *src, uint8_t *dst, int n, in
     }
     a.src_stride = src_stride;
     a.only_plane = only_plane;
+    a.chr_half = p->half ? 1 : 0;
     a.src_origin = uint32_t(g.pre_y) * uint32_t(src_stride) + uint32_t(g.pre_x) * 3u;
     a.src_extent = uint32_t(size_t(g.in_h - 1) * size_t(src_stride) + size_t(g.in_w) * 3);
     a.fill[0] = g.fill_y; a.fill[1] = g.fill_u; a.fill[2] = g.fill_v;
@@ -2130,7 +2172,7 @@ int rgbin_launch(const RgbInPlan *p, const uint8_t *src, uint8_t *dst, int n, in
         return rc;
     }
     // enlargements: the strip walk on 16-bit samples, where the output rows lie on the grid its stores need
-    bool strip = p->strip && only_plane < 0 && reinterpret_cast<uintptr_t>(dst) % 8 == 0 && dst_stride[0] % 8 == 0 && dst_stride[1] % 4 == 0;
+    bool strip = p->strip && only_plane < 0 && reinterpret_cast<uintptr_t>(dst) % 8 == 0 && dst_stride[0] % 8 == 0 && dst_stride[1] % 4 == 0 && int64_t(n) * p->strips < (int64_t(1) << 30);
     if (strip && addr.use_table) {
         for (int i = 0; i < n && strip; ++i) strip = addr.dst_tab[0][i] % 8 == 0 && addr.dst_tab[1][i] % 4 == 0 && addr.dst_tab[2][i] % 4 == 0;
     } else if (strip)
@@ -2138,24 +2180,30 @@ int rgbin_launch(const RgbInPlan *p, const uint8_t *src, uint8_t *dst, int n, in
     if (strip) {
         RgbInStripArgs w{};
         w.src = src; w.dst = dst; w.tab = p->d_strip;
-        w.o_run = p->so_run; w.o_strip = p->so_strip; w.o_lastl = p->so_lastl; w.o_vcol = p->so_vcol; w.o_lastc = p->so_lastc; w.o_vcoc = p->so_vcoc;
-        w.strips = p->strips; w.wpr = p->wpr; w.oh = g.out_h; w.och = (g.out_h + 1) >> 1; w.lvt = p->lv.size; w.cvt = p->cv.size; w.h = g.pre_h;
+        w.o_strip = p->so_strip; w.o_wave = p->so_wave; w.o_lastl = p->so_lastl; w.o_vcol = p->so_vcol; w.o_lastc = p->so_lastc; w.o_vcoc = p->so_vcoc;
+        w.strips = p->strips; w.total = n * p->strips; w.nframes = n;
+        w.oh = g.out_h; w.och = (g.out_h + 1) >> 1; w.lvt = p->lv.size; w.cvt = p->cv.size; w.h = g.pre_h;
         w.src_stride = src_stride; w.dst_stride[0] = dst_stride[0]; w.dst_stride[1] = dst_stride[1];
         w.src_origin = a.src_origin; w.src_extent = a.src_extent;
-        for (int i = 0; i < 9; ++i) w.coef[i] = coef[i];
+        // rgb24ToY_c: (ry r + gy g + by b + (32 << 14) + (1 << 8)) >> 9, rgb24ToUV_c: (... + (256 << 14) + (1 << 8)) >> 9, in the
+        // kernel's exact float form: coefficients x 2^-9, constant (2 bias + 1) / 1024
+        for (int pl = 0; pl < 3; ++pl) {
+            for (int k = 0; k < 3; ++k) w.cf[pl][k] = float(coef[3 * pl + k]) / 512.0f;
+            w.cf[pl][3] = float(2 * ((pl ? 256 << 14 : 32 << 14) + (1 << 8)) + 1) / 1024.0f;
+        }
         w.addr = addr;
-        // row segments of about 24 source rows whatever the batch (each starts up to 7 rows early; 16 and 40 measured 1-3 %
-        // slower at 300 and 1,200 frames of 1080p), down to 16 where that is what fills the chip for eight rounds
-        const int64_t fill = (int64_t(8) * 3072 + int64_t(p->wpr) * n - 1) / (int64_t(p->wpr) * n);
-        const int nseg = int(std::max<int64_t>(1, std::min<int64_t>(std::max<int64_t>((g.pre_h + 12) / 24, fill), std::max(1, g.pre_h / 16))));
+        // row segments: enough workgroups for about four rounds of the chip's resident waves (3 a SIMD), none shorter than
+        // 16 source rows (each starts up to 7 rows early to fill the chroma ring)
+        const int64_t waves = (int64_t(w.total) + 63) / 64;
+        const int seg_env = p->seg_knob;
+        int nseg = int(std::max<int64_t>(1, std::min<int64_t>((int64_t(4) * 3072 + waves - 1) / waves, std::max(1, g.pre_h / 16))));
+        if (seg_env > 0) nseg = std::max(1, std::min(seg_env, g.pre_h / 8));
         w.seg_rows = (g.pre_h + nseg - 1) / nseg;
         w.nseg = (g.pre_h + w.seg_rows - 1) / w.seg_rows;
-        for (int f0 = 0; f0 < n && !rc; f0 += 65535) {
-            w.frame0 = f0;
-            rc = launch_rgb("rgbin_strip_kernel", p->pxl == 4 ? rgbin_strip_kernel<4> : p->pxl == 6 ? rgbin_strip_kernel<6> : rgbin_strip_kernel<8>, dim3(unsigned((p->wpr * w.nseg + kBlock / 64 - 1) / (kBlock / 64)), 1, unsigned(std::min(65535, n - f0))),
-                            dim3(kBlock), 0, st, w);
-        }
-        return rc;
+        auto fn = p->pxl == 4 ? (p->chd == 2 ? rgbin_strip_kernel<4, 2> : p->chd == 3 ? rgbin_strip_kernel<4, 3> : rgbin_strip_kernel<4, 4>)
+                : p->pxl == 6 ? (p->chd == 2 ? rgbin_strip_kernel<6, 2> : p->chd == 3 ? rgbin_strip_kernel<6, 3> : rgbin_strip_kernel<6, 4>)
+                              : (p->chd == 2 ? rgbin_strip_kernel<8, 2> : p->chd == 3 ? rgbin_strip_kernel<8, 3> : rgbin_strip_kernel<8, 4>);
+        return launch_rgb("rgbin_strip_kernel", fn, dim3(unsigned((waves + kBlock / 64 - 1) / (kBlock / 64)), unsigned(w.nseg), 1), dim3(kBlock), 0, st, w);
     }
     for (int f0 = 0; f0 < n && !rc; f0 += 21845) {          // grid.z = frames x 3 planes
         const int nf = std::min(21845, n - f0);
@@ -2164,7 +2212,7 @@ int rgbin_launch(const RgbInPlan *p, const uint8_t *src, uint8_t *dst, int n, in
             RgbInTileArgs t{};
             t.g = a;
             for (int k = 0; k < 2; ++k) { t.th[k] = p->th[k]; t.sx_max[k] = p->sx_max[k]; t.sy_max[k] = p->sy_max[k]; t.tiles_y[k] = p->tiles_y[k]; }
-            for (int k = 0; k < 2; ++k) t.raw_w[k] = rgbin_raw_w(p->sx_max[k], k ? 6 : 3);
+            for (int k = 0; k < 2; ++k) t.raw_w[k] = rgbin_raw_w(p->sx_max[k], k && p->half ? 6 : 3);
             const bool t8 = std::max(std::max(a.lht, a.lvt), std::max(a.cht, a.cvt)) <= 8;
             rc = launch_rgb("rgbin_tile_kernel", t8 ? rgbin_tile_kernel<8> : rgbin_tile_kernel<0>,
                             dim3((g.out_w + 63) / 64, std::max(p->tiles_y[0], p->tiles_y[1]), nf * 3), dim3(kBlock), p->lds_bytes, st, t);
