@@ -306,6 +306,7 @@ RGBIN_CASES = [
     ("scale=200:150,crop=100:74:34:20,pad=132:100:8:6:color=red", 100, 80),
     ("scale=96:54", 63, 36),                           # an odd source width: fine where the picture widens (chroma is read per pixel there, not per pair)
     ("scale=64:80", 64, 36),                           # width kept, height enlarged: chroma stays on pixel pairs
+    ("scale=264:200", 131, 99),                        # odd width, widened: off the strip walk's grid (its lanes convert pixel pairs)
 ]
 
 
@@ -352,7 +353,7 @@ RGBIN_STRIP_CASES = [
     ("scale=720:1280:flags=bilinear", 480, 854),       # 2 taps: windows padded to four
     ("scale=1000:700,crop=800:500:100:101", 640, 360), # crop at an odd row inside the enlargement
     ("scale=1096:618", 1000, 562),                     # 1.096x: chroma shrinks 1.82 : 1 across and down (8 taps), 8 pixels a lane
-    ("scale=264:200", 131, 99),                        # an odd source width and height
+    ("scale=264:200", 130, 99),                        # an odd source height
 ]
 
 

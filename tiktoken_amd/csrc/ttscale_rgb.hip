@@ -1289,15 +1289,12 @@ __global__ __launch_bounds__(kBlock) void rgbin_walk_kernel(const RgbInWalkArgs 
 //   output rows whose last source row this was leave: luma 8 sums of 2 v_dot2, chroma 4 + 4 sums of 4, packed.
 // No barrier: a wave's LDS rows are its own, its LDS operations complete in order.
 struct RgbInStripArgs {
-    const uint8_t *src;
-    uint8_t       *dst;
-    const int32_t *tab;
     uint32_t o_strip, o_wave, o_lastl, o_vcol, o_lastc, o_vcoc;        // dword offsets into tab
     int32_t strips, total, nframes;                                    // 8-column strips a row; lanes = nframes x strips
     int32_t oh, och, lvt, cvt, h;                                      // output rows; vertical taps; source rows
     int32_t seg_rows, nseg;
     int32_t src_stride, dst_stride[2];
-    uint32_t src_origin, src_extent;
+    uint32_t src_origin;
     float cf[3][4];                                                    // per plane: coefficients of R, G, B (x 2^-9) and (2 bias + 1) / 1024
     FrameAddr addr;
 };
@@ -1306,8 +1303,13 @@ typedef float f32x2_t __attribute__((ext_vector_type(2)));
 
 // PXL: pixels of the wave's runs a lane converts per row (the host takes the smallest of 4 / 6 / 8 that covers every
 // wave's runs: all 64 lanes execute the conversion); CHD: tap pairs of a chroma window (taps <= 4, 6, 8).
+// src / dst / tab are __restrict__ kernel arguments so that the wave-uniform table reads (vertical taps, last source
+// row of an output row) are scalar loads: as vector loads each output row waited out two dependent round trips to
+// memory -- `s_waitcnt vmcnt(0)` in front of a v_readfirstlane -- which is where the first version spent 65 % of its
+// wave cycles.
 template <int PXL, int CHD>
-__global__ __launch_bounds__(kBlock, 3) void rgbin_strip_kernel(const RgbInStripArgs a)
+__global__ __launch_bounds__(kBlock, 3) void rgbin_strip_kernel(const uint8_t *__restrict__ src, uint8_t *__restrict__ dst,
+                                                                const int32_t *__restrict__ tab, const RgbInStripArgs a)
 {
     static_assert(PXL == 4 || PXL == 6 || PXL == 8, "pixels a lane converts");
     constexpr int NP = PXL / 2, NDW = (3 * PXL + 6) / 4;             // pixel pairs; aligned dwords that hold a lane's 3 PXL bytes at any phase
@@ -1324,29 +1326,35 @@ __global__ __launch_bounds__(kBlock, 3) void rgbin_strip_kernel(const RgbInStrip
     const bool live = lane < nlive;
     const int lc = min(lane, nlive - 1);                           // dead lanes shadow the last live one and store nothing
     const int fA = g0 / a.strips, sA = g0 - fA * a.strips;         // wave-uniform: the wave's first frame, its first strip there
-    const int32_t *WC = a.tab + a.o_wave + 4 * (size_t(sA) * 64 + lane), *WS = a.tab + a.o_wave + 4 * (size_t(sA) * 64 + lc);
-    const int cpx = WC[0], cfr = fA + WC[1];                       // what this lane converts: first pixel (< 0: nothing), frame
+    const int32_t *WC = tab + a.o_wave + 4 * (size_t(sA) * 64 + lane), *WS = tab + a.o_wave + 4 * (size_t(sA) * 64 + lc);
+    const int cpx = WC[0], clds = WC[1] >> 8, cfr = fA + (WC[1] & 255);   // what this lane converts: first pixel (< 0: nothing), where it goes in the LDS rows, frame
     const int frame = fA + WS[2], adj = WS[3];                     // this lane's strip: its frame, LDS sample of pixel 0 of that frame's row
     const int strip = sA + lc - WS[2] * a.strips;
     const bool conv = cpx >= 0 && cfr < a.nframes;
-    const uint8_t *fb;
+    // source bytes are addressed from the wave's first frame (a wave-uniform base) by 32-bit lane offsets
+    const uint8_t *sbase;
+    uint32_t loff;
     uint8_t *dy, *du, *dv;
     if (a.addr.use_table) {
-        fb = a.src + a.addr.src_tab[0][conv ? cfr : 0];
-        dy = a.dst + a.addr.dst_tab[0][frame]; du = a.dst + a.addr.dst_tab[1][frame]; dv = a.dst + a.addr.dst_tab[2][frame];
+        sbase = src;
+        loff = a.addr.src_tab[0][conv ? cfr : fA];
+        dy = dst + a.addr.dst_tab[0][frame]; du = dst + a.addr.dst_tab[1][frame]; dv = dst + a.addr.dst_tab[2][frame];
     } else {
-        fb = a.src + size_t(conv ? cfr : 0) * a.addr.src_pitch + a.addr.src_plane[0];
-        uint8_t *dpf = a.dst + size_t(frame) * a.addr.dst_pitch;
+        sbase = src + size_t(fA) * a.addr.src_pitch + a.addr.src_plane[0];
+        loff = uint32_t(conv ? cfr - fA : 0) * a.addr.src_pitch;
+        uint8_t *dpf = dst + size_t(frame) * a.addr.dst_pitch;
         dy = dpf + a.addr.dst_plane[0]; du = dpf + a.addr.dst_plane[1]; dv = dpf + a.addr.dst_plane[2];
     }
     dy += 8 * size_t(strip); du += 4 * size_t(strip); dv += 4 * size_t(strip);
-    const uintptr_t lo = reinterpret_cast<uintptr_t>(fb), hi = lo + a.src_extent;
-    const uint8_t *pcol = fb + a.src_origin + 3 * size_t(conv ? cpx : 0);
+    // byte offset of this lane's first pixel of row 0 from the dword-aligned base (idle lanes read pixel 0: mapped memory)
+    const uint32_t mis = uint32_t(reinterpret_cast<uintptr_t>(sbase) & 3u);
+    const uint8_t *sbase4 = sbase - mis;
+    const uint32_t off0 = mis + loff + a.src_origin + 3u * uint32_t(conv ? cpx : 0);
     // this lane's windows and taps
     int li[8], ci[4];                                              // first dword of each window, in the copy its parity picks
     uint32_t lt[8][2], ct[4][CHD];
     {
-        const int32_t *T = a.tab + a.o_strip + size_t(ST) * strip;
+        const int32_t *T = tab + a.o_strip + size_t(ST) * strip;
 #pragma unroll
         for (int c = 0; c < 8; ++c) {
             const int h = T[c] + adj;
@@ -1361,8 +1369,8 @@ __global__ __launch_bounds__(kBlock, 3) void rgbin_strip_kernel(const RgbInStrip
             for (int k = 0; k < CHD; ++k) ct[j][k] = uint32_t(T[28 + CHD * j + k]);
         }
     }
-    const int32_t *lastl = a.tab + a.o_lastl, *lastc = a.tab + a.o_lastc;
-    const uint32_t *vcol = reinterpret_cast<const uint32_t *>(a.tab + a.o_vcol), *vcoc = reinterpret_cast<const uint32_t *>(a.tab + a.o_vcoc);
+    const int32_t *lastl = tab + a.o_lastl, *lastc = tab + a.o_lastc;
+    const uint32_t *vcol = reinterpret_cast<const uint32_t *>(tab + a.o_vcol), *vcoc = reinterpret_cast<const uint32_t *>(tab + a.o_vcoc);
     const int ra = seg * a.seg_rows, rb = min(ra + a.seg_rows, a.h);
     int yl = rgbin_lower_bound(lastl, a.oh, ra), yc = rgbin_lower_bound(lastc, a.och, ra);
     const int yle = rgbin_lower_bound(lastl, a.oh, rb), yce = rgbin_lower_bound(lastc, a.och, rb);
@@ -1371,29 +1379,38 @@ __global__ __launch_bounds__(kBlock, 3) void rgbin_strip_kernel(const RgbInStrip
     if (yl < yle) { rstart = min(rstart, int(lastl[yl]) - (a.lvt - 1)); rlast = max(rlast, int(lastl[yle - 1])); }
     if (yc < yce) { rstart = min(rstart, int(lastc[yc]) - (a.cvt - 1)); rlast = max(rlast, int(lastc[yce - 1])); }
     rstart = max(rstart, 0);
-    int nl = yl < yle ? int(lastl[yl]) : -1, nc = yc < yce ? int(lastc[yc]) : -1;
+    // the next output row of each plane class: its last source row and its taps, read (scalar loads) one output row ahead
+    int nl = -1, nc = -1;
+    uint32_t kl[2] = {0, 0}, kc[4] = {0, 0, 0, 0};
+    auto next_luma = [&]() {
+        nl = -1;
+        if (yl < yle) { nl = lastl[yl]; kl[0] = vcol[2 * yl]; kl[1] = vcol[2 * yl + 1]; }
+    };
+    auto next_chroma = [&]() {
+        nc = -1;
+        if (yc < yce) {
+            nc = lastc[yc];
+#pragma unroll
+            for (int k = 0; k < 4; ++k) kc[k] = vcoc[4 * yc + k];
+        }
+    };
+    next_luma(); next_chroma();
     f32x2_t cR[3], cG[3], cB[3], c0[3];
 #pragma unroll
     for (int p = 0; p < 3; ++p) { cR[p] = a.cf[p][0]; cG[p] = a.cf[p][1]; cB[p] = a.cf[p][2]; c0[p] = a.cf[p][3]; }
     uint32_t ringl[8][2], ringu[4][4], ringv[4][4];
 #pragma unroll
     for (int i = 0; i < 16; ++i) { (&ringl[0][0])[i] = 0; (&ringu[0][0])[i] = 0; (&ringv[0][0])[i] = 0; }
-    // a lane's bytes of a source row as the aligned dwords that hold them; outside the frame: byte by byte
+    // A lane's 3 PXL bytes of a source row as the aligned dwords that hold them.  Every dword read holds at least one byte
+    // of the lane's pixels (the host keeps those inside the frame), so it lies in a mapped page: the last of the NDW is
+    // needed only at the larger byte phases, elsewhere the one before it is read again.
     auto fetch = [&](int r, uint32_t (&raw)[NDW]) {
-        const uintptr_t p = reinterpret_cast<uintptr_t>(pcol + size_t(r) * a.src_stride), pa = p & ~uintptr_t(3);
-        if (!conv) { for (int k = 0; k < NDW; ++k) raw[k] = 0; return; }
-        if (pa >= lo && pa + 4 * NDW <= hi) {
-            const uint32_t *q = reinterpret_cast<const uint32_t *>(pa);
+        const uint32_t o = off0 + uint32_t(r) * uint32_t(a.src_stride), oa = o & ~3u;
+        const uint32_t *q = reinterpret_cast<const uint32_t *>(sbase4 + oa);
 #pragma unroll
-            for (int k = 0; k < NDW; ++k) raw[k] = q[k];
-        } else {
-#pragma unroll
-            for (int k = 0; k < NDW; ++k) {
-                uint32_t w = 0;
-                for (int b = 0; b < 4; ++b) { const uintptr_t q = pa + 4 * k + b; if (q >= lo && q < hi) w |= uint32_t(*reinterpret_cast<const uint8_t *>(q)) << (8 * b); }
-                raw[k] = w;
-            }
-        }
+        for (int k = 0; k < NDW - 1; ++k) raw[k] = q[k];
+        const bool need_last = (o & 3u) + 3u * PXL > 4u * (NDW - 1);
+        raw[NDW - 1] = *reinterpret_cast<const uint32_t *>(sbase4 + (oa + (need_last ? 4u * (NDW - 1) : 4u * (NDW - 2))));
     };
     uint32_t nx[NDW];
     fetch(rstart, nx);
@@ -1404,7 +1421,7 @@ __global__ __launch_bounds__(kBlock, 3) void rgbin_strip_kernel(const RgbInStrip
             if (r < rstart || r > rlast) continue;                 // wave-uniform
             // ---- convert this lane's PXL pixels of the wave's runs
             {
-                const uint32_t ph = uint32_t(reinterpret_cast<uintptr_t>(pcol + size_t(r) * a.src_stride) & 3u);
+                const uint32_t ph = (off0 + uint32_t(r) * uint32_t(a.src_stride)) & 3u;
                 uint32_t w[NDW - 1];
 #pragma unroll
                 for (int k = 0; k < NDW - 1; ++k) w[k] = __builtin_amdgcn_alignbyte(nx[k + 1], nx[k], ph);
@@ -1426,7 +1443,7 @@ __global__ __launch_bounds__(kBlock, 3) void rgbin_strip_kernel(const RgbInStrip
 #pragma unroll
                     for (int p = 0; p < 3; ++p) {
                         // even copy, then the odd one: dword m = (s[2m + 1], s[2m + 2]); its first and last halfword belong to the neighbours' dwords
-                        uint32_t *ea = &lds[wave][p][NP * lane], *ob = &lds[wave][p][CB + 1 + NP * lane];
+                        uint32_t *ea = &lds[wave][p][clds], *ob = &lds[wave][p][CB + 1 + clds];
 #pragma unroll
                         for (int k = 0; k < NP; ++k) ea[k] = pk[p][k];
                         reinterpret_cast<uint16_t *>(ob - 1)[1] = uint16_t(pk[p][0]);
@@ -1460,25 +1477,21 @@ __global__ __launch_bounds__(kBlock, 3) void rgbin_strip_kernel(const RgbInStrip
             __builtin_amdgcn_wave_barrier();
             // ---- output rows this source row completes
             while (nl == r) {                                      // wave-uniform
-                const uint32_t k0 = uni(vcol[2 * yl]), k1 = uni(vcol[2 * yl + 1]);
                 int v[8];
 #pragma unroll
-                for (int c = 0; c < 8; ++c) v[c] = dot2(ringl[c][1], k1, dot2(ringl[c][0], k0, 64 << 12));
+                for (int c = 0; c < 8; ++c) v[c] = dot2(ringl[c][1], kl[1], dot2(ringl[c][0], kl[0], 64 << 12));
                 const u32x2_t o = {pack4<19>(v[0], v[1], v[2], v[3]), pack4<19>(v[4], v[5], v[6], v[7])};
                 if (live) *reinterpret_cast<u32x2_t *>(dy + size_t(yl) * a.dst_stride[0]) = o;
                 ++yl;
-                nl = yl < yle ? int(lastl[yl]) : -1;
+                next_luma();
             }
             while (nc == r) {
-                uint32_t vk[4];
-#pragma unroll
-                for (int k = 0; k < 4; ++k) vk[k] = uni(vcoc[4 * yc + k]);
                 int au[4], av[4];
 #pragma unroll
                 for (int j = 0; j < 4; ++j) {
                     int tu = 64 << 12, tv = 64 << 12;
 #pragma unroll
-                    for (int k = 0; k < 4; ++k) { tu = dot2(ringu[j][k], vk[k], tu); tv = dot2(ringv[j][k], vk[k], tv); }
+                    for (int k = 0; k < 4; ++k) { tu = dot2(ringu[j][k], kc[k], tu); tv = dot2(ringv[j][k], kc[k], tv); }
                     au[j] = tu; av[j] = tv;
                 }
                 const uint32_t ou = pack4<19>(au[0], au[1], au[2], au[3]), ov = pack4<19>(av[0], av[1], av[2], av[3]);
@@ -1487,7 +1500,7 @@ __global__ __launch_bounds__(kBlock, 3) void rgbin_strip_kernel(const RgbInStrip
                     *reinterpret_cast<uint32_t *>(dv + size_t(yc) * a.dst_stride[1]) = ov;
                 }
                 ++yc;
-                nc = yc < yce ? int(lastc[yc]) : -1;
+                next_chroma();
             }
         }
     }
@@ -2004,7 +2017,7 @@ int rgbin_plan_create(const tts_geom &g, RgbInPlan **out)
     if (!rc && !p->walk && !std::getenv("TTS_FORCE_GENERIC") && !(std::getenv("TTS_NO_RGBIN_STRIP") && std::atoi(std::getenv("TTS_NO_RGBIN_STRIP")))) {
         auto monotone = [](const std::vector<int32_t> &v) { for (size_t i = 1; i < v.size(); ++i) if (v[i] < v[i - 1]) return false; return true; };
         const int lht = p->lh.size, cht = p->ch.size, lvt = p->lv.size, cvt = p->cv.size;
-        bool ok = !half && !g.do_pad && g.out_w == g.crop_w && g.out_h == g.crop_h && g.out_w % 8 == 0 && g.out_w >= 64 && lht <= 4 && cht <= 8 && lvt <= 4 && cvt <= 8 &&
+        bool ok = !half && !(g.pre_w & 1) && !g.do_pad && g.out_w == g.crop_w && g.out_h == g.crop_h && g.out_w % 8 == 0 && g.out_w >= 64 && lht <= 4 && cht <= 8 && lvt <= 4 && cvt <= 8 &&
                   g.pre_h >= 8 && monotone(p->lh.pos) && monotone(p->ch.pos) && monotone(p->lv.pos) && monotone(p->cv.pos);
         if (ok) {
             const int ox = g.crop_x, oy = g.crop_y, oxc = g.crop_x >> 1, oyc = g.crop_y >> 1;
@@ -2045,20 +2058,27 @@ int rgbin_plan_create(const tts_geom &g, RgbInPlan **out)
                 p->so_wave = uint32_t(t.size());
                 t.resize(t.size() + size_t(4) * 64 * strips, 0);
                 int pxl = 0;
+                const int avail = g.in_w - g.pre_x;                              // pixels from the pre-cropped origin to the end of a source row: a lane's PXL pixels stay inside them
                 for (int cand : {4, 6, 8}) {
-                    bool fits = true;
+                    bool fits = avail >= cand;
                     for (int sA = 0; sA < strips && fits; ++sA) {
                         int32_t *W = t.data() + p->so_wave + size_t(4) * 64 * sA;
                         for (int i = 0; i < 64; ++i) { W[4 * i] = -1; W[4 * i + 1] = 0; }
                         int used = 0;                                          // conversion lanes dealt so far
                         for (int i = 0, fd = 0; i < 64 && fits; ++fd) {
                             const int first = fd ? 0 : sA, count = std::min(64 - i, strips - first), lastS = first + count - 1;
-                            const int lo = slo[first];
+                            // (a piece shorter than a lane's pixels at the end of a row starts early enough for its first lane to stay inside the row)
+                            const int lo = std::min(slo[first], (avail - cand) & ~1);
                             int hi = 0;
                             for (int q = first; q <= lastS; ++q) hi = std::max(hi, shi[q]);
                             const int lanes = (hi - lo + cand - 1) / cand;
-                            if (used + lanes > 64) { fits = false; break; }
-                            for (int q = 0; q < lanes; ++q) { W[4 * (used + q)] = lo + cand * q; W[4 * (used + q) + 1] = fd; }
+                            if (used + lanes > 64 || fd > 255) { fits = false; break; }
+                            for (int q = 0; q < lanes; ++q) {
+                                // a lane whose pixels would pass the end of the row is slid back over its neighbour's (same values, written twice)
+                                const int px = std::min(lo + cand * q, (avail - cand) & ~1);
+                                W[4 * (used + q)] = px;
+                                W[4 * (used + q) + 1] = int32_t(uint32_t((cand * used + (px - lo)) / 2) << 8 | uint32_t(fd));   // first LDS dword of the lane's samples | frame - first frame
+                            }
                             for (int q = 0; q < count; ++q) { W[4 * (i + q) + 2] = fd; W[4 * (i + q) + 3] = cand * used - lo; }
                             used += lanes; i += count;
                         }
@@ -2179,12 +2199,11 @@ int rgbin_launch(const RgbInPlan *p, const uint8_t *src, uint8_t *dst, int n, in
         strip = addr.dst_pitch % 8 == 0 && addr.dst_plane[0] % 8 == 0 && addr.dst_plane[1] % 4 == 0 && addr.dst_plane[2] % 4 == 0;
     if (strip) {
         RgbInStripArgs w{};
-        w.src = src; w.dst = dst; w.tab = p->d_strip;
         w.o_strip = p->so_strip; w.o_wave = p->so_wave; w.o_lastl = p->so_lastl; w.o_vcol = p->so_vcol; w.o_lastc = p->so_lastc; w.o_vcoc = p->so_vcoc;
         w.strips = p->strips; w.total = n * p->strips; w.nframes = n;
         w.oh = g.out_h; w.och = (g.out_h + 1) >> 1; w.lvt = p->lv.size; w.cvt = p->cv.size; w.h = g.pre_h;
         w.src_stride = src_stride; w.dst_stride[0] = dst_stride[0]; w.dst_stride[1] = dst_stride[1];
-        w.src_origin = a.src_origin; w.src_extent = a.src_extent;
+        w.src_origin = a.src_origin;
         // rgb24ToY_c: (ry r + gy g + by b + (32 << 14) + (1 << 8)) >> 9, rgb24ToUV_c: (... + (256 << 14) + (1 << 8)) >> 9, in the
         // kernel's exact float form: coefficients x 2^-9, constant (2 bias + 1) / 1024
         for (int pl = 0; pl < 3; ++pl) {
@@ -2203,7 +2222,7 @@ int rgbin_launch(const RgbInPlan *p, const uint8_t *src, uint8_t *dst, int n, in
         auto fn = p->pxl == 4 ? (p->chd == 2 ? rgbin_strip_kernel<4, 2> : p->chd == 3 ? rgbin_strip_kernel<4, 3> : rgbin_strip_kernel<4, 4>)
                 : p->pxl == 6 ? (p->chd == 2 ? rgbin_strip_kernel<6, 2> : p->chd == 3 ? rgbin_strip_kernel<6, 3> : rgbin_strip_kernel<6, 4>)
                               : (p->chd == 2 ? rgbin_strip_kernel<8, 2> : p->chd == 3 ? rgbin_strip_kernel<8, 3> : rgbin_strip_kernel<8, 4>);
-        return launch_rgb("rgbin_strip_kernel", fn, dim3(unsigned((waves + kBlock / 64 - 1) / (kBlock / 64)), unsigned(w.nseg), 1), dim3(kBlock), 0, st, w);
+        return launch_rgb("rgbin_strip_kernel", fn, dim3(unsigned((waves + kBlock / 64 - 1) / (kBlock / 64)), unsigned(w.nseg), 1), dim3(kBlock), 0, st, src, dst, static_cast<const int32_t *>(p->d_strip), w);
     }
     for (int f0 = 0; f0 < n && !rc; f0 += 21845) {          // grid.z = frames x 3 planes
         const int nf = std::min(21845, n - f0);
