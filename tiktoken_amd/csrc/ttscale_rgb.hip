@@ -1148,10 +1148,9 @@ __global__ __launch_bounds__(kBlock) void rgbin_tile_kernel(const RgbInTileArgs 
 // the ring with the row's taps arranged by ring slot (host table), two packs, 4 + 4 bytes out.  Segments start up
 // to 7 rows early to fill the ring.  The host sends here only what fits (rgbin_plan_create / rgbin_launch).
 struct RgbInWalkArgs {
-    const uint8_t *src;
-    uint8_t       *dst;
-    const int32_t *last;               // [ny]: last source row of chroma output row y
-    const uint32_t *vco;               // [ny][4]: its taps by ring slot (source row & 7), as int16 pairs
+    // (the table -- [ny] last source row of chroma output row y, then [ny][4] its taps by ring slot (source row & 7) as
+    // int16 pairs -- and the frames are __restrict__ kernel arguments of their own: wave-uniform table reads are then
+    // scalar loads instead of a vector load, a full wait and a v_readfirstlane per chroma output row)
     int32_t w, h, ny, vt;              // picture, chroma output rows, vertical chroma taps (<= 8)
     int32_t seg_rows, nseg;
     int32_t src_stride, dst_stride[2];
@@ -1168,8 +1167,10 @@ __device__ __forceinline__ int rgbin_lower_bound(const int32_t *last, int n, int
     return lo;
 }
 
-__global__ __launch_bounds__(kBlock) void rgbin_walk_kernel(const RgbInWalkArgs a)
+__global__ __launch_bounds__(kBlock) void rgbin_walk_kernel(const uint8_t *__restrict__ src, uint8_t *__restrict__ dst, const int32_t *__restrict__ tab, const RgbInWalkArgs a)
 {
+    const int32_t *last = tab;
+    const uint32_t *vco = reinterpret_cast<const uint32_t *>(tab + a.ny);
     const int wave = __builtin_amdgcn_readfirstlane(int(threadIdx.x >> 6)), lane = int(threadIdx.x & 63);
     const int units = a.w >> 3, wpr = (units + 63) >> 6;           // 8-pixel units, waves across the picture
     const int wid = int(blockIdx.x) * (kBlock / 64) + wave;
@@ -1181,20 +1182,20 @@ __global__ __launch_bounds__(kBlock) void rgbin_walk_kernel(const RgbInWalkArgs 
     const uint8_t *sp;
     uint8_t *dy, *du, *dv;
     if (a.addr.use_table) {                                        // tts_run: per-frame offsets (at most kMaxTableFrames a launch: frame0 is 0)
-        sp = a.src + a.addr.src_tab[0][frame];
-        dy = a.dst + a.addr.dst_tab[0][frame]; du = a.dst + a.addr.dst_tab[1][frame]; dv = a.dst + a.addr.dst_tab[2][frame];
+        sp = src + a.addr.src_tab[0][frame];
+        dy = dst + a.addr.dst_tab[0][frame]; du = dst + a.addr.dst_tab[1][frame]; dv = dst + a.addr.dst_tab[2][frame];
     } else {
-        sp = a.src + size_t(frame) * a.addr.src_pitch + a.addr.src_plane[0];
-        uint8_t *dpf = a.dst + size_t(frame) * a.addr.dst_pitch;
+        sp = src + size_t(frame) * a.addr.src_pitch + a.addr.src_plane[0];
+        uint8_t *dpf = dst + size_t(frame) * a.addr.dst_pitch;
         dy = dpf + a.addr.dst_plane[0]; du = dpf + a.addr.dst_plane[1]; dv = dpf + a.addr.dst_plane[2];
     }
     sp += a.src_origin + 24 * size_t(u);
     dy += 8 * size_t(u); du += 4 * size_t(u); dv += 4 * size_t(u);
     const int ra = seg * a.seg_rows, rb = min(ra + a.seg_rows, a.h);
-    int y = rgbin_lower_bound(a.last, a.ny, ra);
-    const int yend = rgbin_lower_bound(a.last, a.ny, rb);
-    const int rstart = y < yend ? min(int(a.last[y]) - (a.vt - 1), ra) : ra;
-    int next_last = y < yend ? int(a.last[y]) : -1;
+    int y = rgbin_lower_bound(last, a.ny, ra);
+    const int yend = rgbin_lower_bound(last, a.ny, rb);
+    const int rstart = y < yend ? min(int(last[y]) - (a.vt - 1), ra) : ra;
+    int next_last = y < yend ? int(last[y]) : -1;
     const int ry = a.coef[0], gy = a.coef[1], by = a.coef[2], ru = a.coef[3], gu = a.coef[4], bu = a.coef[5], rv = a.coef[6], gv = a.coef[7], bv = a.coef[8];
     uint32_t ring[2][4][4];                                        // plane, chroma column, row pair (slots 2k, 2k + 1)
 #pragma unroll
@@ -1246,7 +1247,7 @@ __global__ __launch_bounds__(kBlock) void rgbin_walk_kernel(const RgbInWalkArgs 
             while (next_last == r) {                               // wave-uniform: chroma output rows this source row completes
                 uint32_t vk[4];
 #pragma unroll
-                for (int k = 0; k < 4; ++k) vk[k] = uni(a.vco[4 * y + k]);
+                for (int k = 0; k < 4; ++k) vk[k] = uni(vco[4 * y + k]);
                 int acc[2][4];
 #pragma unroll
                 for (int pl = 0; pl < 2; ++pl)
@@ -1263,7 +1264,7 @@ __global__ __launch_bounds__(kBlock) void rgbin_walk_kernel(const RgbInWalkArgs 
                     *reinterpret_cast<uint32_t *>(dv + size_t(y) * a.dst_stride[1]) = ov;
                 }
                 ++y;
-                next_last = y < yend ? int(a.last[y]) : -1;
+                next_last = y < yend ? int(last[y]) : -1;
             }
         }
     }
@@ -2170,9 +2171,7 @@ int rgbin_launch(const RgbInPlan *p, const uint8_t *src, uint8_t *dst, int n, in
                addr.dst_plane[1] % 4 == 0 && addr.dst_plane[2] % 4 == 0;
     if (walk) {
         RgbInWalkArgs w{};
-        w.src = src; w.dst = dst;
         w.ny = (g.sc_h + 1) >> 1;
-        w.last = p->d_walk; w.vco = reinterpret_cast<const uint32_t *>(p->d_walk + w.ny);
         w.w = g.pre_w; w.h = g.pre_h; w.vt = p->cv.size;
         w.src_stride = src_stride; w.dst_stride[0] = dst_stride[0]; w.dst_stride[1] = dst_stride[1];
         w.src_origin = a.src_origin;
@@ -2187,7 +2186,7 @@ int rgbin_launch(const RgbInPlan *p, const uint8_t *src, uint8_t *dst, int n, in
         for (int f0 = 0; f0 < n && !rc; f0 += 65535) {
             w.frame0 = f0;
             rc = launch_rgb("rgbin_walk_kernel", rgbin_walk_kernel, dim3(unsigned((wpr * w.nseg + kBlock / 64 - 1) / (kBlock / 64)), 1, unsigned(std::min(65535, n - f0))),
-                            dim3(kBlock), 0, st, w);
+                            dim3(kBlock), 0, st, src, dst, static_cast<const int32_t *>(p->d_walk), w);
         }
         return rc;
     }
