@@ -29,16 +29,44 @@ IN_W, IN_H = 1920, 1080
 # minimum source window read once (608x1080 luma window + chroma) + output written once
 ALGO_BYTES_PER_FRAME = 4_095_360
 HBM_PEAK_GBS = 8000.0        # /opt/skills/guides/MI355X_MICROARCH.md: 8.0 TB/s spec
-KERNEL_SOURCES = ("ttscale_kernels.h", "ttscale_plan.h", "ttscale_device.h")
+def kernel_sources():
+    """Every file the shipped library is built from (csrc/Makefile: HIPSRCS, CXXSRCS, HDRS): a change in any of them --
+    chunking in ttscale.hip, a tap table in filter.cpp, an RGB kernel -- may alter launches and traffic."""
+    d = os.path.join(ROOT, "tiktoken_amd", "csrc")
+    names = sorted(n for n in os.listdir(d) if n.endswith((".hip", ".h", ".cpp")) and n != "ttscale_cli.cpp")
+    return [os.path.join(d, n) for n in names] + [os.path.join(ROOT, "include", "ttscale.h")]
 
 
 def kernel_sources_hash():
     """What profiles/traffic.json is stamped with: the PMC figure is only quoted for the code it was measured on."""
     h = hashlib.sha256()
-    for name in KERNEL_SOURCES:
-        with open(os.path.join(ROOT, "tiktoken_amd", "csrc", name), "rb") as f:
-            h.update(f.read())
+    for path in kernel_sources():
+        with open(path, "rb") as f:
+            h.update(os.path.basename(path).encode() + b"\0" + f.read())
     return h.hexdigest()[:16]
+
+
+def visible_gpus():
+    """GPUs this process may use, counted WITHOUT touching the HIP runtime (the parent of the ranks must not initialise
+    the GPU; torch.cuda.device_count() falls back to hipGetDeviceCount where amdsmi is missing): KFD's topology in
+    sysfs lists one node per device, GPUs being those with SIMDs; a *_VISIBLE_DEVICES list narrows it."""
+    n = 0
+    top = "/sys/class/kfd/kfd/topology/nodes"
+    try:
+        for node in os.listdir(top):
+            try:
+                with open(os.path.join(top, node, "properties")) as f:
+                    props = dict(line.split()[:2] for line in f if len(line.split()) >= 2)
+                n += int(props.get("simd_count", "0")) > 0
+            except OSError:
+                pass
+    except OSError:
+        return None
+    for var in ("ROCR_VISIBLE_DEVICES", "HIP_VISIBLE_DEVICES", "CUDA_VISIBLE_DEVICES"):
+        v = os.environ.get(var)
+        if v is not None:
+            n = min(n, len([x for x in v.split(",") if x.strip() != ""]))
+    return n
 
 
 def _port_worker(args):
@@ -110,11 +138,10 @@ def cpu_baseline(geom, budget_s=9.0):
 
 def spawn_ranks(args):
     """`python bench.py --gpus N` without a launcher: start N ranks (one per GPU) and relay their output.
-    Nothing here may initialise the GPU: torch.cuda.device_count() does not (it asks the driver's sysfs / NVML side)."""
+    Nothing here may initialise the GPU: the devices are counted from sysfs (visible_gpus)."""
     import socket
-    import torch
-    have = torch.cuda.device_count()
-    if have < args.gpus:
+    have = visible_gpus()
+    if have is not None and have < args.gpus:
         sys.stderr.write("bench.py: --gpus %d but this node shows %d GPU(s); refusing to report n_gpus=%d for fewer devices\n"
                          % (args.gpus, have, args.gpus))
         return 2

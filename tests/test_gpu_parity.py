@@ -590,7 +590,7 @@ def test_runs_under_hip_graph_capture(tts, oracle):
     graph = torch.cuda.CUDAGraph()
     with torch.cuda.graph(graph):
         st = torch.cuda.current_stream().cuda_stream
-        plan.run_batch(d_a, o_a, stream=st)              # fill + column walk + range pass: three dependent launches
+        plan.run_batch(d_a, o_a, stream=st)              # pad border + column walk + range step: ONE launch since round 2
         plan2.run_batch(d_b, o_b, stream=st)
     for rep in range(3):
         a2 = np.roll(a, rep + 1, axis=0) ^ np.uint8(rep)

@@ -89,6 +89,8 @@ static int build_classes(tts_plan *p, const tts_geom &g, bool full_v, bool force
     return rc;
 }
 
+namespace { int scratch_for_device(int dev, unsigned char **out); }
+
 int tts_plan_create(const tts_geom *g, tts_plan **out)
 {
     if (!g || !out) return TTS_ERR_INVALID_INPUT;
@@ -104,6 +106,9 @@ int tts_plan_create(const tts_geom *g, tts_plan **out)
     p->knobs.read();
     int cus = 0;
     if (hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) == hipSuccess && cus > 0) p->n_cus = cus;
+    // tts_run_host_static's scratch: its device address is looked up here, at set-up, so that the entry point itself does no
+    // first-call runtime work (a failure is kept for that call to report)
+    { unsigned char *scratch_base = nullptr; (void)scratch_for_device(dev, &scratch_base); }
     if (g->in_fmt == TTS_FMT_RGB24) {
         rc = tts::rgbin_plan_create(*g, &p->rgbin);            // (sets the error text itself)
         if (rc) { tts_plan_destroy(p); return rc; }

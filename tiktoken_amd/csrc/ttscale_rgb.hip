@@ -1543,6 +1543,8 @@ struct RgbPlan {
     bool strip_lds = false;            // ... with the source rows staged through LDS (the runs of any 64 strips fit a 1 KiB slot per plane)
     uint32_t *d_tab = nullptr;
     RgbStripArgs strip{};              // table offsets and constants; per-launch fields are filled in by rgb_launch
+    int strip_occ[4] = {1, 1, 1, 1};   // resident workgroups per CU of the plan's rgb_strip_kernel instantiations [lds * 2 + xp], asked at plan creation on the plan's device
+    bool no_xp = false;                // TTS_NO_XP at plan creation (A/B knob: no whole-sector store exchange)
     struct Seg { int seg_rows, nseg; uint32_t seginfo; };
     std::vector<Seg> segs;
     bool two_stage = false;            // kGeneric: yuv420p scale, then the unscaled converter over the finished canvas
@@ -1555,6 +1557,10 @@ struct RgbPlan {
     RgbCoef coef{};
     char name[96] = "";
 };
+
+typedef void (*rgb_strip_fn)(const uint8_t *, uint8_t *, const uint32_t *, const RgbStripArgs);
+static const rgb_strip_fn rgb_strip_fns[8] = {rgb_strip_kernel<3, false, false>, rgb_strip_kernel<3, false, true>, rgb_strip_kernel<3, true, false>, rgb_strip_kernel<3, true, true>,
+                                              rgb_strip_kernel<4, false, false>, rgb_strip_kernel<4, false, true>, rgb_strip_kernel<4, true, false>, rgb_strip_kernel<4, true, true>};
 
 // Tables of the fused strip walk, if this geometry can take it.
 static bool build_rgb_strip(RgbPlan *p)
@@ -1731,7 +1737,13 @@ int rgb_plan_create(const tts_geom &g, int n_cus, RgbPlan **out)
         for (int i = 0; i < 4 && !rc; ++i)
             if (!upload_vec(p->d_pos[i], f[i]->pos) || !upload_vec(p->d_taps[i], f[i]->taps)) { set_last_error("table upload failed (hipMalloc / hipMemcpy)"); rc = TTS_ERR_INITIALIZATION_FAILED; }
         std::snprintf(p->name, sizeof p->name, "rgb_generic<%d,%d,%d,%d>", p->lh.size, p->lv.size, p->ch.size, p->cv.size);
-        if (!rc && (p->strip_ok = build_rgb_strip(p))) std::snprintf(p->name, sizeof p->name, "rgb_strip<%d,%s>", p->bpp, p->strip_lds ? "lds" : "regs");
+        if (!rc && (p->strip_ok = build_rgb_strip(p))) {
+            std::snprintf(p->name, sizeof p->name, "rgb_strip<%d,%s>", p->bpp, p->strip_lds ? "lds" : "regs");
+            // per-plan, per-device launch facts (they used to sit in function statics of rgb_launch, shared by every thread and GPU)
+            for (int v = 0; v < 4; ++v)
+                if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&p->strip_occ[v], rgb_strip_fns[(p->bpp == 4) * 4 + v], kBlock, 0) != hipSuccess || p->strip_occ[v] < 1) p->strip_occ[v] = 1;
+            p->no_xp = std::getenv("TTS_NO_XP") && std::atoi(std::getenv("TTS_NO_XP"));
+        }
     }
     if (rc) { rgb_plan_destroy(p); return rc; }
     *out = p;
@@ -1764,16 +1776,9 @@ int rgb_launch(const RgbPlan *p, const uint8_t *src, uint8_t *dst, int n, const 
             const bool lds = p->strip_lds && !addr.use_table && src_span >= 4096u;
             // whole-sector stores: rgba always (a chunk never leaves its lane); rgb24 where a wave's strips wrap
             // over frames at most once and no last strip is slid over its neighbour (one held-back chunk at most)
-            const bool no_xp = std::getenv("TTS_NO_XP") && std::atoi(std::getenv("TTS_NO_XP"));
-            const bool xp = !no_xp && (p->bpp == 4 || (p->strip.pw % 8 == 0 && p->strip.strips >= 64));
-            typedef void (*rgb_fn)(const uint8_t *, uint8_t *, const uint32_t *, const RgbStripArgs);
-            static const rgb_fn fns[8] = {rgb_strip_kernel<3, false, false>, rgb_strip_kernel<3, false, true>, rgb_strip_kernel<3, true, false>, rgb_strip_kernel<3, true, true>,
-                                          rgb_strip_kernel<4, false, false>, rgb_strip_kernel<4, false, true>, rgb_strip_kernel<4, true, false>, rgb_strip_kernel<4, true, true>};
-            const int which = (p->bpp == 4) * 4 + lds * 2 + xp;
-            rgb_fn fn = fns[which];
-            static int per_cu[8] = {0, 0, 0, 0, 0, 0, 0, 0};   // resident workgroups per CU, asked once per instantiation
-            int &occ = per_cu[which];
-            if (!occ && (hipOccupancyMaxActiveBlocksPerMultiprocessor(&occ, fn, kBlock, 0) != hipSuccess || occ < 1)) occ = 1;
+            const bool xp = !p->no_xp && (p->bpp == 4 || (p->strip.pw % 8 == 0 && p->strip.strips >= 64));
+            rgb_strip_fn fn = rgb_strip_fns[(p->bpp == 4) * 4 + lds * 2 + xp];
+            const int occ = p->strip_occ[lds * 2 + xp];
             // the longest segment <= 96 rows that still leaves 3 workgroups per resident slot, else the shortest
             const double slots = double(p->n_cus) * occ;
             const int64_t sblocks = (items + kBlock - 1) / kBlock;

@@ -233,6 +233,8 @@ class Plan:
         """numpy uint8 [n, in_bytes] on the host -> numpy [n, out_bytes] (`out`, if given: a C-contiguous
         uint8 array of that size, e.g. a view of pinned memory); pipelined through HBM in chunks."""
         src = np.ascontiguousarray(src, dtype=np.uint8)
+        if src.size % self.in_bytes:
+            raise TtsError(-1, "src holds %d bytes: not a whole number of %d-byte frames" % (src.size, self.in_bytes))
         n = src.size // self.in_bytes
         if out is not None and not (out.dtype == np.uint8 and out.flags.c_contiguous and out.size == n * self.out_bytes):
             raise TtsError(-1, "out must be a C-contiguous uint8 array of n*out_bytes")
@@ -245,7 +247,11 @@ class Plan:
         """tts_run_host_static: like run_host, staged through the library's static device scratch (no
         allocation) on `stream`, NOT synchronised: `out` (required; pinned memory makes the copies
         asynchronous) is complete once the stream has passed the call."""
-        src = np.ascontiguousarray(src, dtype=np.uint8)
+        # (the call returns before its copies have run: a converted temporary of `src` would be freed under them)
+        if not (isinstance(src, np.ndarray) and src.dtype == np.uint8 and src.flags.c_contiguous):
+            raise TtsError(-1, "src must be a C-contiguous uint8 array (it is read after the call returns)")
+        if src.size % self.in_bytes:
+            raise TtsError(-1, "src holds %d bytes: not a whole number of %d-byte frames" % (src.size, self.in_bytes))
         n = src.size // self.in_bytes
         if not (out.dtype == np.uint8 and out.flags.c_contiguous and out.size == n * self.out_bytes):
             raise TtsError(-1, "out must be a C-contiguous uint8 array of n*out_bytes")
