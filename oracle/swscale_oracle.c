@@ -418,15 +418,23 @@ static void tto_fill_gv_table(int *table, int64_t inc)
     }
 }
 
-/* yuv2rgb.c ff_yuv2rgb_c_init_tables(c, ff_yuv2rgb_coeffs[SWS_CS_DEFAULT = ITU601], fullRange = 0,
- * brightness 0, contrast = saturation = 1 << 16), bpp 24 (the 32 bpp tables hold the same bytes shifted) */
-static void tto_yuv2rgb_init(tto_yuv2rgb *t)
+/* yuv2rgb.c ff_yuv2rgb_c_init_tables(c, ff_yuv2rgb_coeffs[SWS_CS_DEFAULT = ITU601], fullRange = the SOURCE's range
+ * (0 for yuv420p, 1 for yuvj420p), brightness 0, contrast = saturation = 1 << 16), bpp 24 (the 32 bpp tables hold the
+ * same bytes shifted) */
+static void tto_yuv2rgb_init(tto_yuv2rgb *t, int full_range)
 {
-    const int yoffs = 326 + TTO_RGB_LUMA_HEADROOM;            /* fullRange ? 384 : 326 */
+    const int yoffs = (full_range ? 384 : 326) + TTO_RGB_LUMA_HEADROOM;
     int64_t crv = 104597, cbu = 132201, cgu = -25675, cgv = -53279;   /* ITU-R BT.601 */
     int64_t cy = 1 << 16, oy = 0, yb;
-    cy = (cy * 255) / 219;                                     /* !fullRange */
-    oy = 16 << 16;
+    if (!full_range) {
+        cy = (cy * 255) / 219;
+        oy = 16 << 16;
+    } else {                                                   /* a yuvj420p source (c->srcRange = 1) */
+        crv = (crv * 224) / 255;
+        cbu = (cbu * 224) / 255;
+        cgu = (cgu * 224) / 255;
+        cgv = (cgv * 224) / 255;
+    }
     /* contrast, saturation = 1.0 and brightness = 0 leave cy, c?? and oy as they are */
     crv = ((crv * (1 << 16)) + 0x8000) / cy;                   /* "scale coefficients by cy" */
     cbu = ((cbu * (1 << 16)) + 0x8000) / cy;
@@ -475,12 +483,21 @@ static void tto_hscale_plane(const uint8_t *src, int sstride, int sh, const tto_
 int tto_sws_yuv420_to_rgb(const uint8_t *sy, const uint8_t *su, const uint8_t *sv, int sys, int sus, int svs,
                           int sw, int sh, uint8_t *dst, int dstride, int dw, int dh, int alg, int fmt)
 {
+    return tto_sws_yuv420_to_rgb_range(sy, su, sv, sys, sus, svs, sw, sh, dst, dstride, dw, dh, alg, fmt, 0);
+}
+
+/* vscale.c packed_vscale(): "chr_filter[2 * y + 1] + chr_filter[2 * y] == 4096 && chr_filter[2 * y + 1] <= 4096U" */
+static int tto_two_tap_ok(const int16_t *t) { return (int)t[0] + (int)t[1] == 4096 && (uint16_t)t[1] <= 4096u; }
+
+int tto_sws_yuv420_to_rgb_range(const uint8_t *sy, const uint8_t *su, const uint8_t *sv, int sys, int sus, int svs,
+                                int sw, int sh, uint8_t *dst, int dstride, int dw, int dh, int alg, int fmt, int full_range)
+{
     const int bpp = (fmt == TTO_FMT_RGBA || fmt == TTO_FMT_BGRA) ? 4 : 3;
     tto_yuv2rgb *t;
     int rc = 0;
     if (fmt < TTO_FMT_RGB24 || fmt > TTO_FMT_BGRA || sw < 1 || sh < 1 || dw < 1 || dh < 1) return -1;
     t = (tto_yuv2rgb *)malloc(sizeof(*t));
-    tto_yuv2rgb_init(t);
+    tto_yuv2rgb_init(t, full_range);
 
     if (sw == dw && sh == dh && !(dh & 1)) {
         /* swscale_unscaled.c ff_get_unscaled_swscale(): yuv420p -> RGB, no accurate_rnd, even height ->
@@ -504,9 +521,6 @@ int tto_sws_yuv420_to_rgb(const uint8_t *sy, const uint8_t *su, const uint8_t *s
         int16_t *ty, *tu, *tv;
         if (tto_filter_init(&lh, sw, dw, 1 << 14, alg) || tto_filter_init(&lv, sh, dh, 1 << 12, alg) ||
             tto_filter_init(&ch, csw, cdw, 1 << 14, alg) || tto_filter_init(&cv, csh, dh, 1 << 12, alg)) { free(t); return -1; }
-        /* vscale.c packed_vscale(): yuv2packed1 when the luma filter has 1 tap and chroma 1-2, yuv2packed2
-         * when both have 2; everything else yuv2packedX, which is what follows */
-        if (lv.size <= 2 && cv.size <= 2) rc = -2;
         ty = (int16_t *)malloc((size_t)dw * sh * sizeof(int16_t));
         tu = (int16_t *)malloc((size_t)cdw * csh * sizeof(int16_t));
         tv = (int16_t *)malloc((size_t)cdw * csh * sizeof(int16_t));
@@ -519,9 +533,39 @@ int tto_sws_yuv420_to_rgb(const uint8_t *sy, const uint8_t *su, const uint8_t *s
             /* output.c yuv2rgb_X_c_template() */
             const int16_t *lf = lv.coef + (size_t)lv.size * y, *cf = cv.coef + (size_t)cv.size * y;
             const int lp = lv.pos[y], cp = cv.pos[y];
+            /* vscale.c packed_vscale(), decided PER OUTPUT ROW from its taps (chroma rows = output rows: RGB has no
+             * vertical chroma subsampling):
+             *   1: luma 1 tap and chroma 1 tap, or chroma 2 taps that sum to 4096 with a non-negative second one
+             *      -> yuv2packed1 = output.c yuv2rgb_1_c_template(uvalpha = 0 / the second chroma tap);
+             *   2: luma and chroma 2 such taps -> yuv2packed2 = yuv2rgb_2_c_template(yalpha, uvalpha = the second taps);
+             *   0: everything else -> yuv2packedX = yuv2rgb_X_c_template. */
+            int writer = 0, uvalpha = 0, yalpha = 0;
+            if (lv.size == 1 && cv.size == 1) writer = 1;
+            else if (lv.size == 1 && cv.size == 2 && tto_two_tap_ok(cf)) { writer = 1; uvalpha = cf[1]; }
+            else if (lv.size == 2 && cv.size == 2 && tto_two_tap_ok(lf) && tto_two_tap_ok(cf)) { writer = 2; yalpha = lf[1]; uvalpha = cf[1]; }
             for (int i = 0; i < ((dw + 1) >> 1) && !rc; i++) {
                 int Y1 = 1 << 18, Y2 = 1 << 18, U = 1 << 18, V = 1 << 18;
                 const int has2 = i * 2 + 1 < dw;             /* (swscale computes and writes it into the row's padding) */
+                if (writer == 1) {
+                    /* yuv2rgb_1_c_template(): no filtering down the picture; chroma from the first line alone
+                     * (uvalpha < 2048) or the plain average of the two */
+                    Y1 = (ty[(size_t)lp * dw + i * 2] + 64) >> 7;
+                    Y2 = has2 ? (ty[(size_t)lp * dw + i * 2 + 1] + 64) >> 7 : 0;
+                    if (uvalpha < 2048) {
+                        U = (tu[(size_t)cp * cdw + i] + 64) >> 7;
+                        V = (tv[(size_t)cp * cdw + i] + 64) >> 7;
+                    } else {
+                        U = (tu[(size_t)cp * cdw + i] + tu[(size_t)(cp + 1) * cdw + i] + 128) >> 8;
+                        V = (tv[(size_t)cp * cdw + i] + tv[(size_t)(cp + 1) * cdw + i] + 128) >> 8;
+                    }
+                } else if (writer == 2) {
+                    /* yuv2rgb_2_c_template(): (line0 * (4096 - alpha) + line1 * alpha) >> 19, no rounding term */
+                    const int ya1 = 4096 - yalpha, ua1 = 4096 - uvalpha;
+                    Y1 = (ty[(size_t)lp * dw + i * 2] * ya1 + ty[(size_t)(lp + 1) * dw + i * 2] * yalpha) >> 19;
+                    Y2 = has2 ? (ty[(size_t)lp * dw + i * 2 + 1] * ya1 + ty[(size_t)(lp + 1) * dw + i * 2 + 1] * yalpha) >> 19 : 0;
+                    U = (tu[(size_t)cp * cdw + i] * ua1 + tu[(size_t)(cp + 1) * cdw + i] * uvalpha) >> 19;
+                    V = (tv[(size_t)cp * cdw + i] * ua1 + tv[(size_t)(cp + 1) * cdw + i] * uvalpha) >> 19;
+                } else {
                 for (int j = 0; j < lv.size; j++) {
                     Y1 += ty[(size_t)(lp + j) * dw + i * 2] * lf[j];
                     if (has2) Y2 += ty[(size_t)(lp + j) * dw + i * 2 + 1] * lf[j];
@@ -531,6 +575,7 @@ int tto_sws_yuv420_to_rgb(const uint8_t *sy, const uint8_t *su, const uint8_t *s
                     V += tv[(size_t)(cp + j) * cdw + i] * cf[j];
                 }
                 Y1 >>= 19; Y2 >>= 19; U >>= 19; V >>= 19;
+                }
                 if (U < -TTO_RGB_HEADROOM || U >= 256 + TTO_RGB_HEADROOM || V < -TTO_RGB_HEADROOM || V >= 256 + TTO_RGB_HEADROOM) { rc = -1; break; }
                 rc = tto_rgb_put(t, dst + (size_t)y * dstride + (size_t)(i * 2) * bpp, fmt, Y1, U, V);
                 if (has2 && !rc) rc = tto_rgb_put(t, dst + (size_t)y * dstride + (size_t)(i * 2 + 1) * bpp, fmt, Y2, U, V);
@@ -555,13 +600,15 @@ int tto_run_chain_rgb(const tto_chain *c, const uint8_t *sy, const uint8_t *su, 
         const int ow = c->out_w, oh = c->out_h, cw = (ow + 1) >> 1, chh = (oh + 1) >> 1;
         uint8_t *buf = (uint8_t *)malloc((size_t)ow * oh + 2 * (size_t)cw * chh);
         uint8_t *py = buf, *pu = buf + (size_t)ow * oh, *pv = pu + (size_t)cw * chh;
-        y.out_fmt = 0; y.rgb_stage = 0; y.out_range = 0;
+        /* `format=yuvj420p,format=rgb24`: the range pass of tto_run_chain() first (borders included), then the conversion
+         * pass reads a FULL-range source: its yuv2rgb tables are built with fullRange = 1 */
+        y.out_fmt = 0; y.rgb_stage = 0;
         rc = tto_run_chain(&y, sy, su, sv, sys, sus, svs, py, pu, pv, ow, cw, cw);
-        if (!rc) rc = tto_sws_yuv420_to_rgb(py, pu, pv, ow, cw, cw, ow, oh, dst, dstride, ow, oh, c->alg, c->out_fmt);
+        if (!rc) rc = tto_sws_yuv420_to_rgb_range(py, pu, pv, ow, cw, cw, ow, oh, dst, dstride, ow, oh, c->alg, c->out_fmt, c->out_range == 1);
         free(buf);
         return rc;
     }
-    if (c->rgb_stage != 1) return -1;
+    if (c->rgb_stage != 1 || c->out_range) return -1;
     {
         /* the chain's scale writes RGB (sc_w x sc_h, from the pre-cropped source); vf_crop and vf_pad then
          * work on RGB pixels: offsets and sizes are not rounded to a chroma grid */

@@ -68,10 +68,17 @@ int tto_run_chain(const tto_chain *c,
 /* One swscale context yuv420p (sw x sh) -> packed RGB (dw x dh), C path, default flags (no
  * full_chroma_int, no accurate_rnd): libswscale/yuv2rgb.c tables + output.c yuv2rgb_X_c_template, or the
  * unscaled converter yuv2rgb_c_24_rgb & co. when the sizes match and dh is even.
- * Returns 0, -1 on bad arguments, -2 where swscale takes a path that is not restated here (the 1- / 2-tap
- * packed writers yuv2rgb_1 / yuv2rgb_2; the unscaled converter on an odd width). */
+ * Rows whose vertical filters have 1 - 2 taps go through yuv2rgb_1_c_template / yuv2rgb_2_c_template as
+ * vscale.c packed_vscale() picks them, per output row.
+ * Returns 0, -1 on bad arguments, -2 where swscale's result is not defined (the unscaled converter never writes
+ * the last column of an odd width: the byte is whatever the destination held). */
 int tto_sws_yuv420_to_rgb(const uint8_t *sy, const uint8_t *su, const uint8_t *sv, int sys, int sus, int svs,
                           int sw, int sh, uint8_t *dst, int dstride, int dw, int dh, int alg, int fmt);
+
+/* the same for a source of the given range: full_range = 1 for yuvj420p (the tables of ff_yuv2rgb_c_init_tables() are
+ * then built with fullRange = 1: no luma stretch, chroma coefficients x 224 / 255, table origin 384) */
+int tto_sws_yuv420_to_rgb_range(const uint8_t *sy, const uint8_t *su, const uint8_t *sv, int sys, int sus, int svs,
+                                int sw, int sh, uint8_t *dst, int dstride, int dw, int dh, int alg, int fmt, int full_range);
 
 /* a chain that ends in packed RGB (c->out_fmt != 0): dst holds out_h rows of out_w * bpp bytes */
 int tto_run_chain_rgb(const tto_chain *c, const uint8_t *sy, const uint8_t *su, const uint8_t *sv,

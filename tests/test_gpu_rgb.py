@@ -35,6 +35,18 @@ CASES = [
     ("scale=64:48,crop=31:21:5:3,format=rgb24", 64, 48),
     ("crop=32:20,pad=64:48:-1:-1:color=white,format=bgr24", 64, 48),   # yuv crop + pad, converted with the borders
     ("pad=80:60:-1:-1,format=rgb24", 63, 47),          # odd picture in a yuv pad: its last column goes to the fill
+    # vertical filters of 1-2 taps on luma AND chroma: vscale.c packed_vscale() takes yuv2packed2 (both 2 taps) or
+    # yuv2packed1 (luma 1 tap, chroma 1-2) row by row, not the 19-bit sums of yuv2packedX (round 2 refused these)
+    ("scale=128:96:flags=bilinear,format=rgb24", 64, 48),      # both axes enlarged, 2 taps each: yuv2rgb_2_c_template
+    ("scale=101:77:flags=bilinear,format=bgra", 64, 48),       # odd sizes, folded edge rows
+    ("scale=128:48:flags=bilinear,format=rgb24", 64, 48),      # height kept: luma 1 tap, chroma 2 (24 -> 48 rows): yuv2rgb_1_c_template, chroma from one line or the plain average
+    ("scale=128:96:flags=area,format=rgb24", 64, 48),          # area enlarging is swscale's bilinear
+    ("scale=96:48,format=rgb24", 64, 48),                      # height kept, bicubic: luma 1 tap, chroma 4: yuv2packedX after all
+    # packed RGB from a full-range link: the range pass, then a conversion pass over a yuvj420p source (full-range tables)
+    ("format=yuvj420p,format=rgb24", 64, 48),
+    ("format=yuvj420p,format=bgra", 64, 47),                   # odd height: the conversion pass is the general scaler
+    (THUMB + ",format=yuv420p,format=yuvj420p,format=rgb24", 720, 1280),   # src/services/video.js:329-334's chain as the mjpeg encoder gets it, as pixels
+    ("crop=32:20:4:2,pad=64:48:-1:-1:color=white,format=yuvj420p,format=bgr24", 64, 48),
 ]
 
 
@@ -282,12 +294,13 @@ def test_rgb_strided_rows_and_frame_pointers(tts, oracle):
 
 
 def test_rgb_unsupported_paths_say_so(tts):
-    # both vertical filters at 2 taps: swscale's yuv2packed2 writer, not restated
-    with pytest.raises(tts.TtsError, match="UNSUPPORTED"):
-        tts.Plan.from_vf("scale=128:96:flags=bilinear,format=rgb24", 64, 48)
-    # unscaled converter on an odd width
+    # the unscaled converter on an odd width and an even height: swscale's yuv2rgb_c_24_rgb never writes the last column
+    # (its loops go 8, 4, 2 pixels at a time), so the reference result is whatever the frame buffer held: nothing to match
     with pytest.raises(tts.TtsError, match="UNSUPPORTED"):
         tts.Plan.from_vf("format=rgb24", 63, 48)
+    # a range step inside the scaler that writes RGB (yuvj pinned BEFORE the scale) is not a chain libavfilter builds this way
+    with pytest.raises(tts.TtsError, match="UNSUPPORTED"):
+        tts.Plan.from_vf("format=yuvj420p,scale=128:96,format=rgb24", 64, 48)
 
 
 # ---- the other direction: packed rgb24 in, yuv420p out ---------------------------------------------------

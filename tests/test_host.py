@@ -87,7 +87,7 @@ def test_parse_vf(tts, vf, iw, ih, want):
 
 @pytest.mark.parametrize("vf,name", [
     ("hflip", "INVALID_FORMAT"), ("scale=abc:def", "INVALID_FORMAT"), ("scale=10:10:flags=lanczos", "UNSUPPORTED"),
-    ("format=gray", "UNSUPPORTED"), ("format=rgb24,crop=10:10", "UNSUPPORTED"), ("format=yuvj420p,format=rgb24", "UNSUPPORTED"),
+    ("format=gray", "UNSUPPORTED"), ("format=rgb24,crop=10:10", "UNSUPPORTED"), ("format=yuvj420p,scale=64:36,format=rgb24", "UNSUPPORTED"),
     ("crop=4000:10", "INVALID_INPUT"), ("pad=10:10", "INVALID_INPUT"),
     ("scale=64:64,scale=32:32", "UNSUPPORTED"), ("scale=100:100:unknown=1", "INVALID_FORMAT"),
 ])
@@ -136,6 +136,12 @@ def test_parse_vf_rgb24_input(tts):
         tts.parse_vf("crop=31:20,scale=24:20", 64, 36, in_fmt="rgb24")  # ... a shrink reads pairs too
     # a widening reads chroma per pixel (sws_init_context: chrSrcHSubSample stays 0): an odd width is fine there
     assert tts.parse_vf("crop=31:20,scale=48:30", 64, 36, in_fmt="rgb24").as_dict()["pre_w"] == 31
+
+
+def test_parse_vf_rgb_from_a_full_range_link(tts):
+    # `format=yuvj420p,format=rgb24`: the range pass stays in out_range, the conversion pass sits at the end
+    g = tts.parse_vf("crop=32:20,format=yuvj420p,format=bgra", 64, 48).as_dict()
+    assert (g["out_range"], g["out_fmt"], g["rgb_stage"], g["out_w"], g["out_h"]) == (1, 4, 2, 32, 20)
 
 
 def test_frame_bytes(tts):

@@ -199,3 +199,21 @@ def test_rgb24_input_chroma_rule(oracle):
     by one column of an even width; everything wider reads chroma per pixel."""
     L = oracle.lib()
     assert [L.tto_rgb_in_half_chroma(sw, dw) for sw, dw in ((64, 64), (64, 32), (64, 65), (64, 66), (1920, 3413), (480, 720), (63, 64), (63, 63))] == [1, 1, 1, 0, 0, 0, 0, 1]
+
+
+def test_rgb_from_full_range_is_the_jfif_matrix(tts, oracle):
+    """format=yuvj420p,format=rgb24: the conversion pass reads a FULL-range source, so swscale builds its tables with
+    fullRange = 1 -- no luma stretch, chroma coefficients x 224 / 255: R = Y + 1.402 (V - 128),
+    G = Y - 0.344 (U - 128) - 0.714 (V - 128), B = Y + 1.772 (U - 128), the JFIF matrix -- applied to the planes the
+    range pass leaves (the oracle's own `format=yuvj420p` output).  STATED BOUND: 2 levels (two floored chroma
+    products, two floored table offsets and one rounding: 1.54 measured); a limited-range table on this source would be off by up to 16 + 14 % of the level."""
+    w, h = 64, 48
+    src = synth.frames("random", w, h, 2)
+    rgb = oracle.run_chain(tts.parse_vf("format=yuvj420p,format=rgb24", w, h), src).reshape(2, h, w, 3).astype(np.float64)
+    yuvj = oracle.run_chain(tts.parse_vf("format=yuvj420p", w, h), src)
+    for i in range(2):
+        y, u, v = (p.astype(np.float64) for p in synth.split(yuvj[i], w, h))
+        u = np.repeat(np.repeat(u, 2, 0), 2, 1) - 128
+        v = np.repeat(np.repeat(v, 2, 0), 2, 1) - 128
+        ref = np.clip(np.stack([y + 1.402 * v, y - 0.344136 * u - 0.714136 * v, y + 1.772 * u], -1), 0, 255)
+        assert np.abs(rgb[i] - ref).max() <= 2.0, np.abs(rgb[i] - ref).max()

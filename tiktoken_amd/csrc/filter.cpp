@@ -234,7 +234,8 @@ int check_geom(const tts_geom &g)
     if (g.out_range < TTS_RANGE_KEEP || g.out_range > TTS_RANGE_TO_LIMITED) return TTS_ERR_INVALID_INPUT;
     if (g.out_fmt < TTS_FMT_YUV420P || g.out_fmt > TTS_FMT_BGRA) return TTS_ERR_INVALID_INPUT;
     if ((g.out_fmt == TTS_FMT_YUV420P) != (g.rgb_stage == TTS_RGB_NONE) || g.rgb_stage < 0 || g.rgb_stage > TTS_RGB_AT_END) return TTS_ERR_INVALID_INPUT;
-    if (g.out_fmt != TTS_FMT_YUV420P && g.out_range != TTS_RANGE_KEEP) return TTS_ERR_UNSUPPORTED;
+    // packed RGB from a full-range link (`format=yuvj420p,format=rgb24`): the range pass, then a conversion pass of its own
+    if (g.out_fmt != TTS_FMT_YUV420P && g.out_range != TTS_RANGE_KEEP && !(g.out_range == TTS_RANGE_TO_FULL && g.rgb_stage == TTS_RGB_AT_END)) return TTS_ERR_UNSUPPORTED;
     if (g.fill_rgb & ~0xffffff) return TTS_ERR_INVALID_INPUT;
     // crop and pad behind an RGB-writing scale work on RGB pixels: no chroma grid
     if (g.rgb_stage == TTS_RGB_AT_SCALE) even = [](int) { return true; };

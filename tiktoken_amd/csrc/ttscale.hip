@@ -122,7 +122,7 @@ int tts_plan_create(const tts_geom *g, tts_plan **out)
         // every output row, luma unclipped) whose column walk writes into the RGB frame, converted in place.
         // Anything that does not qualify -- or whose classes do not both take the column walk -- stays with p->rgb.
         tts::RgbScratchLayout lay;
-        if (!p->knobs.no_rgb_scratch && !tts::rgb_plan_is_strip(p->rgb) && tts::rgb_scratch_layout(*g, g->out_w * (g->out_fmt >= TTS_FMT_RGBA ? 4 : 3), lay)) {
+        if (!p->knobs.no_rgb_scratch && !tts::rgb_plan_is_strip(p->rgb) && !tts::rgb_plan_general_only(p->rgb) && tts::rgb_scratch_layout(*g, g->out_w * (g->out_fmt >= TTS_FMT_RGBA ? 4 : 3), lay)) {
             tts_plan *sp = new (std::nothrow) tts_plan();
             if (sp) {
                 tts_geom gp = *g;

@@ -19,7 +19,8 @@ struct RgbPlan;        // tables of one geometry whose output is packed RGB, on 
 int  rgb_plan_create(const tts_geom &g, int n_cus, RgbPlan **out);
 void rgb_plan_destroy(RgbPlan *p);
 const char *rgb_plan_kernel_name(const RgbPlan *p);
-bool rgb_plan_is_strip(const RgbPlan *p);          // the fused strip kernel takes this geometry (<= 4 taps an axis)
+bool rgb_plan_is_strip(const RgbPlan *p);
+bool rgb_plan_general_only(const RgbPlan *p);   // rows through swscale's 1- / 2-line writers, or a full-range source: no fused or in-place path          // the fused strip kernel takes this geometry (<= 4 taps an axis)
 
 // One launch set: frames [0, n) addressed by `addr` relative to (src, dst); src_stride = luma / chroma row
 // pitch of the yuv420p source, dst_stride = bytes between RGB rows.  Asynchronous on st.

@@ -44,14 +44,16 @@ struct RgbCoef {
     int32_t off_r, off_g, off_b;        // -(crv >> 9), -(cgu >> 9) - (cgv >> 9), -(cbu >> 9)
 };
 
-static RgbCoef rgb_coef()
+// full: the source is yuvj420p (ff_yuv2rgb_c_init_tables(fullRange = 1)): no luma stretch (cy = 1 << 16, no 16 << 16
+// offset), chroma coefficients x 224 / 255, table origin 384 instead of 326 -- the ramp is then y_table[384 + i] = i
+static RgbCoef rgb_coef(bool full = false)
 {
     RgbCoef c;
-    const int64_t cy = (int64_t(1) << 16) * 255 / 219;
-    auto scaled = [&](int64_t v) { return int32_t((v * (1 << 16) + 0x8000) / cy); };   // C division: truncates toward zero
+    const int64_t cy = full ? (int64_t(1) << 16) : (int64_t(1) << 16) * 255 / 219;
+    auto scaled = [&](int64_t v) { if (full) v = v * 224 / 255; return int32_t((v * (1 << 16) + 0x8000) / cy); };   // C division: truncates toward zero
     c.cy = int32_t(cy);
     c.crv = scaled(104597); c.cbu = scaled(132201); c.cgu = scaled(-25675); c.cgv = scaled(-53279);
-    c.k = int32_t(326 * cy - (int64_t(400) << 16) + 0x8000);
+    c.k = full ? 0x8000 : int32_t(326 * cy - (int64_t(400) << 16) + 0x8000);
     c.off_r = -(c.crv >> 9); c.off_b = -(c.cbu >> 9); c.off_g = -(c.cgu >> 9) - (c.cgv >> 9);
     return c;
 }
@@ -92,9 +94,19 @@ struct RgbFrameArgs {
     int32_t cpx, cpy, cpw, cph;        // yuv_pad: picture rectangle of the chroma planes
     int32_t fill[3];                   // yuv_pad: pad colour y, u, v
     int32_t frame0;                    // first frame of this launch (grid.z holds at most 65535 frames)
+    // `format=yuvj420p,format=rgb24`: the conversion pass reads the canvas the range pass left, sample by sample
+    // clip8((p * mul + add) >> shift) (filter.h range_affine), luma / chroma; coef then holds the full-range tables
+    int32_t rng_on, rng[2][3];
     RgbCoef coef;
     FrameAddr addr;
 };
+
+__device__ __forceinline__ int rgb_range(const RgbFrameArgs &a, int chroma, int p)
+{
+    if (!a.rng_on) return p;
+    const int v = (p * a.rng[chroma][0] + a.rng[chroma][1]) >> a.rng[chroma][2];
+    return v < 0 ? 0 : v > 255 ? 255 : v;
+}
 
 // base pointers of the frame a workgroup works on (grid.z = frame): 64-bit, per workgroup
 __device__ __forceinline__ void rgb_frame_bases(const RgbFrameArgs &a, int frame, const uint8_t *(&sp)[3], uint8_t *&dp)
@@ -139,13 +151,13 @@ __global__ __launch_bounds__(kBlock) void rgb_unscaled_kernel(const RgbFrameArgs
                 const size_t o = size_t((a.oy >> 1) + cy - a.cpy) * a.src_stride_c + ((a.ox >> 1) + cx - a.cpx);
                 U = sp[1][o]; V = sp[2][o];
             }
-            tts::rgb_pixel(a.coef, Y, U, V, r, g, b);
+            tts::rgb_pixel(a.coef, rgb_range(a, 0, Y), rgb_range(a, 1, U), rgb_range(a, 1, V), r, g, b);
         } else if (in_luma) {
             const int sx = a.ox + x - a.px, sy = a.oy + y - a.py;
             const int Y = sp[0][size_t(sy) * a.src_stride_y + sx];
             const int U = sp[1][size_t(sy >> 1) * a.src_stride_c + (sx >> 1)];
             const int V = sp[2][size_t(sy >> 1) * a.src_stride_c + (sx >> 1)];
-            tts::rgb_pixel(a.coef, Y, U, V, r, g, b);
+            tts::rgb_pixel(a.coef, rgb_range(a, 0, Y), rgb_range(a, 1, U), rgb_range(a, 1, V), r, g, b);
         }
         rgb_store_pixel(px + i * a.bpp, a.bpp, a.swap, r, g, b);
     }
@@ -174,22 +186,27 @@ struct RgbGenericArgs {
     int32_t cox, coy;                                  // two_stage: origin of the chroma picture rectangle (f.cp*) in the scaled chroma plane
 };
 
-__device__ __forceinline__ int rgb_hv(const uint8_t *plane, int stride, const int32_t *hpos, const int16_t *htaps, int ht,
+// hScale8To15_c for one output column of one source row (rng: the sample is read through the range step first)
+__device__ __forceinline__ int rgb_hrow(const RgbFrameArgs &f, int chroma, const uint8_t *row, const int16_t *hc, int ht)
+{
+    int acc = 0;
+    for (int k = 0; k < ht; ++k) acc += rgb_range(f, chroma, int(row[k])) * int(hc[k]);
+    acc >>= 7;
+    return acc < 32767 ? acc : 32767;
+}
+
+__device__ __forceinline__ int rgb_hv(const RgbFrameArgs &f, int chroma, const uint8_t *plane, int stride, const int32_t *hpos, const int16_t *htaps, int ht,
                                       const int32_t *vpos, const int16_t *vtaps, int vt, int vx, int vy)
 {
     const int hp = hpos[vx], vp = vpos[vy];
     const int16_t *hc = htaps + size_t(vx) * ht, *vc = vtaps + size_t(vy) * vt;
     int val = 1 << 18;
-    for (int j = 0; j < vt; ++j) {
-        const uint8_t *row = plane + size_t(vp + j) * size_t(stride) + hp;
-        int acc = 0;
-        for (int k = 0; k < ht; ++k) acc += int(row[k]) * int(hc[k]);
-        acc >>= 7;
-        acc = acc < 32767 ? acc : 32767;
-        val += acc * int(vc[j]);
-    }
+    for (int j = 0; j < vt; ++j) val += rgb_hrow(f, chroma, plane + size_t(vp + j) * size_t(stride) + hp, hc, ht) * int(vc[j]);
     return val >> 19;
 }
+
+// vscale.c packed_vscale(): two taps qualify for the 1- / 2-line writers when they sum to 4096 and the second is not negative
+__device__ __forceinline__ bool rgb_two_tap_ok(const int16_t *t) { return int(t[0]) + int(t[1]) == 4096 && uint16_t(t[1]) <= 4096u; }
 
 __global__ __launch_bounds__(kBlock) void rgb_generic_kernel(const RgbGenericArgs a)
 {
@@ -202,21 +219,52 @@ __global__ __launch_bounds__(kBlock) void rgb_generic_kernel(const RgbGenericArg
     rgb_frame_bases(f, f.frame0 + int(blockIdx.z), sp, dp);
     int r = f.border[0], g = f.border[1], b = f.border[2];
     if (a.two_stage) {
+        // (the scaling pass is the planar one: no range step inside it; the range pass, if any, runs on its clipped bytes)
+        RgbFrameArgs plain = f;
+        plain.rng_on = 0;
         auto clip8 = [](int v) { return v < 0 ? 0 : v > 255 ? 255 : v; };
         int Y = f.fill[0], U = f.fill[1], V = f.fill[2];
         if (y >= f.py && y < f.py + f.ph && x >= f.px && x < f.px + f.pw)
-            Y = clip8(rgb_hv(sp[0], f.src_stride_y, a.lhpos, a.lhtaps, a.lht, a.lvpos, a.lvtaps, a.lvt, f.ox + x - f.px, f.oy + y - f.py));
+            Y = clip8(rgb_hv(plain, 0, sp[0], f.src_stride_y, a.lhpos, a.lhtaps, a.lht, a.lvpos, a.lvtaps, a.lvt, f.ox + x - f.px, f.oy + y - f.py));
         const int cx = x >> 1, cy = y >> 1;
         if (cy >= f.cpy && cy < f.cpy + f.cph && cx >= f.cpx && cx < f.cpx + f.cpw) {
-            U = clip8(rgb_hv(sp[1], f.src_stride_c, a.chpos, a.chtaps, a.cht, a.cvpos, a.cvtaps, a.cvt, a.cox + cx - f.cpx, a.coy + cy - f.cpy));
-            V = clip8(rgb_hv(sp[2], f.src_stride_c, a.chpos, a.chtaps, a.cht, a.cvpos, a.cvtaps, a.cvt, a.cox + cx - f.cpx, a.coy + cy - f.cpy));
+            U = clip8(rgb_hv(plain, 1, sp[1], f.src_stride_c, a.chpos, a.chtaps, a.cht, a.cvpos, a.cvtaps, a.cvt, a.cox + cx - f.cpx, a.coy + cy - f.cpy));
+            V = clip8(rgb_hv(plain, 1, sp[2], f.src_stride_c, a.chpos, a.chtaps, a.cht, a.cvpos, a.cvtaps, a.cvt, a.cox + cx - f.cpx, a.coy + cy - f.cpy));
         }
-        tts::rgb_pixel(f.coef, Y, U, V, r, g, b);
+        tts::rgb_pixel(f.coef, rgb_range(f, 0, Y), rgb_range(f, 1, U), rgb_range(f, 1, V), r, g, b);
     } else if (y >= f.py && y < f.py + f.ph && x >= f.px && x < f.px + f.pw) {
         const int vx = f.ox + x - f.px, vy = f.oy + y - f.py;
-        const int Y = rgb_hv(sp[0], f.src_stride_y, a.lhpos, a.lhtaps, a.lht, a.lvpos, a.lvtaps, a.lvt, vx, vy);
-        const int U = rgb_hv(sp[1], f.src_stride_c, a.chpos, a.chtaps, a.cht, a.cvpos, a.cvtaps, a.cvt, vx >> 1, vy);
-        const int V = rgb_hv(sp[2], f.src_stride_c, a.chpos, a.chtaps, a.cht, a.cvpos, a.cvtaps, a.cvt, vx >> 1, vy);
+        // which of swscale's packed writers this output row takes (vscale.c packed_vscale(), decided per row from its taps)
+        const int16_t *lvc = a.lvtaps + size_t(vy) * a.lvt, *cvc = a.cvtaps + size_t(vy) * a.cvt;
+        int writer = 0, yalpha = 0, uvalpha = 0;
+        if (a.lvt == 1 && a.cvt == 1) writer = 1;
+        else if (a.lvt == 1 && a.cvt == 2 && rgb_two_tap_ok(cvc)) { writer = 1; uvalpha = cvc[1]; }
+        else if (a.lvt == 2 && a.cvt == 2 && rgb_two_tap_ok(lvc) && rgb_two_tap_ok(cvc)) { writer = 2; yalpha = lvc[1]; uvalpha = cvc[1]; }
+        int Y, U, V;
+        if (writer == 0) {                                     // yuv2rgb_X_c_template
+            Y = rgb_hv(f, 0, sp[0], f.src_stride_y, a.lhpos, a.lhtaps, a.lht, a.lvpos, a.lvtaps, a.lvt, vx, vy);
+            U = rgb_hv(f, 1, sp[1], f.src_stride_c, a.chpos, a.chtaps, a.cht, a.cvpos, a.cvtaps, a.cvt, vx >> 1, vy);
+            V = rgb_hv(f, 1, sp[2], f.src_stride_c, a.chpos, a.chtaps, a.cht, a.cvpos, a.cvtaps, a.cvt, vx >> 1, vy);
+        } else {
+            const int cxv = vx >> 1, lp = a.lvpos[vy], cp = a.cvpos[vy];
+            const int16_t *lh = a.lhtaps + size_t(vx) * a.lht, *chh = a.chtaps + size_t(cxv) * a.cht;
+            const uint8_t *ly = sp[0] + size_t(lp) * size_t(f.src_stride_y) + a.lhpos[vx];
+            const size_t co = size_t(cp) * size_t(f.src_stride_c) + a.chpos[cxv];
+            const int y0 = rgb_hrow(f, 0, ly, lh, a.lht);
+            const int u0 = rgb_hrow(f, 1, sp[1] + co, chh, a.cht), v0 = rgb_hrow(f, 1, sp[2] + co, chh, a.cht);
+            const bool two_c = writer == 2 || uvalpha >= 2048;  // (the second chroma line is read only where the writer uses it)
+            const int u1 = two_c ? rgb_hrow(f, 1, sp[1] + co + f.src_stride_c, chh, a.cht) : 0, v1 = two_c ? rgb_hrow(f, 1, sp[2] + co + f.src_stride_c, chh, a.cht) : 0;
+            if (writer == 1) {                                 // yuv2rgb_1_c_template: chroma from the first line (uvalpha < 2048) or the average of two
+                Y = (y0 + 64) >> 7;
+                U = two_c ? (u0 + u1 + 128) >> 8 : (u0 + 64) >> 7;
+                V = two_c ? (v0 + v1 + 128) >> 8 : (v0 + 64) >> 7;
+            } else {                                           // yuv2rgb_2_c_template: no rounding term
+                const int y1 = rgb_hrow(f, 0, ly + f.src_stride_y, lh, a.lht);
+                Y = (y0 * (4096 - yalpha) + y1 * yalpha) >> 19;
+                U = (u0 * (4096 - uvalpha) + u1 * uvalpha) >> 19;
+                V = (v0 * (4096 - uvalpha) + v1 * uvalpha) >> 19;
+            }
+        }
         tts::rgb_pixel(f.coef, Y, U, V, r, g, b);
     }
     rgb_store_pixel(dp + size_t(y) * f.dst_stride + size_t(x) * f.bpp, f.bpp, f.swap, r, g, b);
@@ -1555,6 +1603,9 @@ struct RgbPlan {
     int px = 0, py = 0, pw = 0, ph = 0, ox = 0, oy = 0;
     int border[3] = {0, 0, 0};
     RgbCoef coef{};
+    bool full = false;                 // the conversion pass reads a yuvj420p canvas: range step per sample (rng), full-range tables (coef)
+    int rng[2][3] = {{1, 0, 0}, {1, 0, 0}};
+    bool packed12 = false;             // some output rows take swscale's 1- / 2-line writers (vertical filters of 1-2 taps): the general kernel only
     char name[96] = "";
 };
 
@@ -1669,7 +1720,12 @@ int rgb_plan_create(const tts_geom &g, int n_cus, RgbPlan **out)
     p->g = g; p->n_cus = n_cus;
     p->bpp = g.out_fmt >= TTS_FMT_RGBA ? 4 : 3;
     p->swap = g.out_fmt == TTS_FMT_BGR24 || g.out_fmt == TTS_FMT_BGRA;
-    p->coef = rgb_coef();
+    const bool full = g.out_range == TTS_RANGE_TO_FULL;            // `format=yuvj420p,format=<rgb>`: range pass, then a conversion pass over a full-range source (AT_END only: check_geom)
+    p->coef = rgb_coef(full);
+    p->full = full;
+    if (full)
+        for (int k = 0; k < 2; ++k)
+            if (!range_affine(g.out_range, k == 1, p->rng[k][0], p->rng[k][1], p->rng[k][2])) { set_last_error("range step has no closed form"); delete p; return TTS_ERR_UNSUPPORTED; }
     p->convert4 = std::getenv("TTS_RGB_CONVERT4") && std::atoi(std::getenv("TTS_RGB_CONVERT4"));
     p->px = g.do_pad ? g.pad_x : 0; p->py = g.do_pad ? g.pad_y : 0;
     p->pw = g.crop_w; p->ph = g.crop_h; p->ox = g.crop_x; p->oy = g.crop_y;
@@ -1686,7 +1742,10 @@ int rgb_plan_create(const tts_geom &g, int n_cus, RgbPlan **out)
         ctx_sw = ctx_dw = g.out_w; ctx_sh = ctx_dh = g.out_h;
         if (g.do_pad) p->pw = g.crop_w & ~1;
         p->cpx = p->px >> 1; p->cpy = p->py >> 1; p->cpw = (p->pw + 1) >> 1; p->cph = (g.crop_h + 1) >> 1;
-        rgb_pixel(p->coef, g.fill_y, g.fill_u, g.fill_v, p->border[0], p->border[1], p->border[2]);
+        {   // the border as the conversion pass sees it: the yuv fill, through the range pass if there is one
+            auto rg = [&](int k, int v) { if (!full) return v; const int t = (v * p->rng[k][0] + p->rng[k][1]) >> p->rng[k][2]; return t < 0 ? 0 : t > 255 ? 255 : t; };
+            rgb_pixel(p->coef, rg(0, g.fill_y), rg(1, g.fill_u), rg(1, g.fill_v), p->border[0], p->border[1], p->border[2]);
+        }
     }
     int rc = TTS_OK;
     auto cs = [](int v) { return (v + 1) >> 1; };
@@ -1714,7 +1773,7 @@ int rgb_plan_create(const tts_geom &g, int n_cus, RgbPlan **out)
         if (ctx_dw & 1) { set_last_error("swscale's unscaled yuv420p -> RGB converter never writes the last column of an odd width: not supported"); rc = TTS_ERR_UNSUPPORTED; }
         // the streaming form where the geometry fits it (the addresses are checked per launch): no border, a
         // picture that is a multiple of 8 wide, its source rows on the dword grid
-        p->unscaled8 = !p->convert4 && (g.rgb_stage != TTS_RGB_AT_END || (p->cpx == 0 && p->cpy == 0 && 2 * p->cpw == p->pw && 2 * p->cph == p->ph)) && p->px == 0 && p->py == 0 && p->pw == g.out_w && p->ph == g.out_h &&
+        p->unscaled8 = !full && !p->convert4 && (g.rgb_stage != TTS_RGB_AT_END || (p->cpx == 0 && p->cpy == 0 && 2 * p->cpw == p->pw && 2 * p->cph == p->ph)) && p->px == 0 && p->py == 0 && p->pw == g.out_w && p->ph == g.out_h &&
                        p->pw % 8 == 0 && p->ph % 2 == 0 && p->ox % 8 == 0 && p->oy % 2 == 0 && g.pre_x % 8 == 0;
         std::snprintf(p->name, sizeof p->name, p->unscaled8 ? "rgb_unscaled8" : "rgb_unscaled");
     } else {
@@ -1727,17 +1786,14 @@ int rgb_plan_create(const tts_geom &g, int n_cus, RgbPlan **out)
                     !build_axis_filter(csw, cdw, 1 << 14, g.alg, p->ch) || !build_axis_filter(csh, ctx_dh, 1 << 12, g.alg, p->cv))) {
             set_last_error("filter tables"); rc = TTS_ERR_INVALID_INPUT;
         }
-        // vscale.c packed_vscale(): 1- and 2-tap vertical filters go to yuv2packed1 / yuv2packed2, whose
-        // arithmetic differs (no 19-bit sum); only yuv2packedX is restated
-        if (!rc && p->lv.size <= 2 && p->cv.size <= 2) {
-            set_last_error("vertical filters of 1-2 taps on both luma and chroma (swscale's yuv2packed1/2 writers) are not supported for RGB output");
-            rc = TTS_ERR_UNSUPPORTED;
-        }
+        // vscale.c packed_vscale(): rows whose vertical filters have 1-2 taps on both luma and chroma go to yuv2packed1 /
+        // yuv2packed2, whose arithmetic differs (no 19-bit sum): the general kernel decides per row, the fused ones stay out
+        p->packed12 = p->lv.size <= 2 && p->cv.size <= 2;
         const AxisFilter *f[4] = {&p->lh, &p->lv, &p->ch, &p->cv};
         for (int i = 0; i < 4 && !rc; ++i)
             if (!upload_vec(p->d_pos[i], f[i]->pos) || !upload_vec(p->d_taps[i], f[i]->taps)) { set_last_error("table upload failed (hipMalloc / hipMemcpy)"); rc = TTS_ERR_INITIALIZATION_FAILED; }
         std::snprintf(p->name, sizeof p->name, "rgb_generic<%d,%d,%d,%d>", p->lh.size, p->lv.size, p->ch.size, p->cv.size);
-        if (!rc && (p->strip_ok = build_rgb_strip(p))) {
+        if (!rc && !p->packed12 && !full && (p->strip_ok = build_rgb_strip(p))) {
             std::snprintf(p->name, sizeof p->name, "rgb_strip<%d,%s>", p->bpp, p->strip_lds ? "lds" : "regs");
             // per-plan, per-device launch facts (they used to sit in function statics of rgb_launch, shared by every thread and GPU)
             for (int v = 0; v < 4; ++v)
@@ -1760,6 +1816,7 @@ void rgb_plan_destroy(RgbPlan *p)
 
 const char *rgb_plan_kernel_name(const RgbPlan *p) { return p ? p->name : ""; }
 bool rgb_plan_is_strip(const RgbPlan *p) { return p && p->strip_ok; }
+bool rgb_plan_general_only(const RgbPlan *p) { return p && (p->packed12 || p->full); }
 
 int rgb_launch(const RgbPlan *p, const uint8_t *src, uint8_t *dst, int n, const int src_stride[2], int dst_stride,
                uint64_t src_span, uint64_t dst_span, const FrameAddr &addr, hipStream_t st)
@@ -1813,6 +1870,8 @@ int rgb_launch(const RgbPlan *p, const uint8_t *src, uint8_t *dst, int n, const 
     f.bpp = p->bpp; f.swap = p->swap;
     for (int i = 0; i < 3; ++i) f.border[i] = p->border[i];
     f.coef = p->coef; f.addr = addr;
+    f.rng_on = p->full ? 1 : 0;
+    for (int k = 0; k < 2; ++k) for (int i = 0; i < 3; ++i) f.rng[k][i] = p->rng[k][i];
     f.yuv_pad = p->g.rgb_stage == TTS_RGB_AT_END;
     f.cpx = p->cpx; f.cpy = p->cpy; f.cpw = p->cpw; f.cph = p->cph;
     f.fill[0] = p->g.fill_y; f.fill[1] = p->g.fill_u; f.fill[2] = p->g.fill_v;

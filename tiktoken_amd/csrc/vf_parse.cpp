@@ -279,7 +279,7 @@ int parse_vf(const char *vf, int iw, int ih, tts_geom &g, std::string &err, int 
     // the `format` filter, i.e. at the very end.  First pass over the chain: find that out, because every
     // filter between the conversion and the end then works on RGB pixels (no chroma grid to round to).
     try {
-        bool seen_scale = false, yuv_pinned = false, full_range = false;
+        bool seen_scale = false, yuv_pinned = false;
         for (const std::string &raw : split(vf, ',')) {
             const std::string f = trim(raw);
             if (f.empty()) continue;
@@ -291,8 +291,9 @@ int parse_vf(const char *vf, int iw, int ih, tts_geom &g, std::string &err, int 
             const std::string pf = format_arg(eq == std::string::npos ? "" : f.substr(eq + 1));
             const int fmt = parse_pix_fmt(pf);
             if (fmt < 0) { err = "format: only yuv420p, yuvj420p, rgb24, bgr24, rgba, bgra are supported"; return TTS_ERR_UNSUPPORTED; }
-            if (fmt == TTS_FMT_YUV420P) { yuv_pinned = true; full_range = pf == "yuvj420p"; continue; }
-            if (full_range) { err = "RGB from a full-range (yuvj420p) link is not supported"; return TTS_ERR_UNSUPPORTED; }
+            if (fmt == TTS_FMT_YUV420P) { yuv_pinned = true; continue; }
+            // (RGB from a full-range link, `format=yuvj420p,format=rgb24`: the range pass stays in out_range and the conversion
+            // pass behind it reads a yuvj420p source -- full-range yuv2rgb tables; yuv_pinned is set, so it sits at the end)
             g.out_fmt = fmt;
             g.rgb_stage = seen_scale && !yuv_pinned ? TTS_RGB_AT_SCALE : TTS_RGB_AT_END;
         }
