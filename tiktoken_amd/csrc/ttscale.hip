@@ -86,6 +86,7 @@ static int build_classes(tts_plan *p, const tts_geom &g, bool full_v, bool force
         }
     }
     if (rc == TTS_OK && !upload(p->d_tab, tab)) rc = TTS_ERR_INITIALIZATION_FAILED;
+    if (rc == TTS_OK && p->knobs.persist && !p->d_queue && hipMalloc(reinterpret_cast<void **>(&p->d_queue), 64) != hipSuccess) rc = TTS_ERR_INITIALIZATION_FAILED;
     return rc;
 }
 
@@ -161,6 +162,7 @@ void tts_plan_destroy(tts_plan *p)
     if (!p) return;
     free_class(p->cls[0]); free_class(p->cls[1]);
     (void)hipFree(p->d_tab);
+    (void)hipFree(p->d_queue);
     tts::rgb_plan_destroy(p->rgb);
     tts::rgbin_plan_destroy(p->rgbin);
     tts_plan_destroy(p->scratch);

@@ -54,6 +54,12 @@ struct StripArgs {
     RangeStep range;
     PadClass pad[2];
     uint32_t scaler_blocks;        // logical blocks [0, scaler_blocks) scale, the rest fill pad borders
+    // strip_lds_kernel as a work queue (TTS_PERSIST, an experiment: DESIGN.md 7 finding 2): the launch holds grid_scaler
+    // (<= scaler_blocks, a multiple of 8) scaler workgroups; one that has finished logical block b takes the next of ITS
+    // XCD's blocks (b = x mod 8 stays on XCD x, whose run of logical blocks xcd_remap keeps contiguous) from queue[x].
+    // queue == nullptr: one workgroup per logical block, grid_scaler == scaler_blocks.
+    uint32_t grid_scaler;
+    uint32_t *queue;
     int32_t  y16;                  // column walk only: class 0 (luma) stores its UNCLIPPED vertical sums as int16 (2 bytes a column): the
                                    // intermediate of the packed-RGB thumbnail path (ttscale_rgb.hip rgb_scratch_convert_kernel)
     uint64_t *dbg;                 // -DTTS_EXPERIMENTS builds: (start, end) clock of every workgroup of strip_lds_kernel; else null, unused
@@ -484,10 +490,12 @@ __global__ __launch_bounds__(kMaxLdsBlock, (GC == 4 && R == 4 && LW == 4) ? 8 : 
     extern __shared__ __attribute__((aligned(16))) uint8_t lds_raw[];      // (blockDim.x / 64) x D slots
     uint8_t (*lds)[D][kSlotBytes] = reinterpret_cast<uint8_t (*)[D][kSlotBytes]>(lds_raw);
 
-    if (blockIdx.x >= a.scaler_blocks) { pad_fill_blocks(a, dst, blockIdx.x - a.scaler_blocks); return; }   // (whole workgroups: no barrier is skipped; see strip_kernel)
-    uint32_t lb = xcd_remap(blockIdx.x, a.scaler_blocks);
+    if (blockIdx.x >= a.grid_scaler) { pad_fill_blocks(a, dst, blockIdx.x - a.grid_scaler); return; }   // (whole workgroups: no barrier is skipped; see strip_kernel)
+    __shared__ uint32_t next_item;
+    for (uint32_t item = blockIdx.x; item < a.scaler_blocks;) {    // (one pass unless the launch is a work queue: a.queue)
+    uint32_t lb = xcd_remap(item, a.scaler_blocks);
 #ifdef TTS_EXPERIMENTS
-    if (a.dbg && threadIdx.x == 0) a.dbg[2 * blockIdx.x] = __builtin_amdgcn_s_memrealtime();
+    if (a.dbg && threadIdx.x == 0) a.dbg[2 * item] = __builtin_amdgcn_s_memrealtime();
 #endif
     const int ci = lb >= a.c[0].nblocks ? 1 : 0;
     if (ci) lb -= a.c[0].nblocks;
@@ -730,8 +738,14 @@ __global__ __launch_bounds__(kMaxLdsBlock, (GC == 4 && R == 4 && LW == 4) ? 8 : 
         }
     }
 #ifdef TTS_EXPERIMENTS
-    if (a.dbg && threadIdx.x == 0) a.dbg[2 * blockIdx.x + 1] = __builtin_amdgcn_s_memrealtime();
+    if (a.dbg && threadIdx.x == 0) a.dbg[2 * item + 1] = __builtin_amdgcn_s_memrealtime();
 #endif
+    if (!a.queue) break;
+    __syncthreads();                                           // (every wave has consumed next_item of the previous round)
+    if (threadIdx.x == 0) next_item = a.grid_scaler + 8u * atomicAdd(&a.queue[blockIdx.x & 7u], 1u) + (blockIdx.x & 7u);
+    __syncthreads();
+    item = next_item;
+    }
 #endif
 }
 

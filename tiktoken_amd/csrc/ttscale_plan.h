@@ -106,6 +106,7 @@ struct Knobs {
     int col_d4 = 1;                   // column walk: v_dot4 on packed bytes with two-digit taps instead of v_perm + v_dot2: 0 never, 1 above 8 tap pairs, 2 wherever the tables exist
     int col_model = 1;                // column walk segment length: 0 = fill rule, 1 = busiest-CU model above 8 tap pairs, 2 = everywhere
     int host_chunk_mb = 128;          // tts_run_host: bytes (source + output) of one pipelined chunk
+    int persist = 0;                  // strip_lds_kernel as a work queue of resident workgroups (experiment; tenths of the resident slots to launch, 10 = all)
     void read()
     {
         strip_n = env_int("TTS_STRIP_N", 8); strip_d = env_int("TTS_STRIP_D", 0);
@@ -124,6 +125,7 @@ struct Knobs {
         no_rgb_scratch = env_int("TTS_NO_RGB_SCRATCH", 0);
         col_nc_launch = env_int("TTS_COL_NC_LAUNCH", 0);
         host_chunk_mb = std::max(1, env_int("TTS_HOST_CHUNK_MB", 128));
+        persist = std::max(0, env_int("TTS_PERSIST", 0));
     }
 };
 
@@ -153,6 +155,7 @@ struct tts_plan {
     Knobs knobs;
     ClassPlan cls[2];
     uint32_t *d_tab = nullptr;        // strip tables of both classes
+    uint32_t *d_queue = nullptr;      // TTS_PERSIST: per-XCD block counters of a work-queue launch (experiment: launches of one plan then take turns)
     tts::RgbPlan *rgb = nullptr;      // packed-RGB output (g.out_fmt != yuv420p): the plan of ttscale_rgb.hip; cls[] stay empty
     tts::RgbInPlan *rgbin = nullptr;  // packed rgb24 input (g.in_fmt): likewise
     // Packed-RGB thumbnails (many-tap shrinks written as RGB by the chain's scale): a planar plan of the same
@@ -935,6 +938,15 @@ int launch_all(const tts_plan *p, const uint8_t *src, uint8_t *dst, int n, const
             a.c[1] = a.c[0]; a.c[1].nblocks = 0;
         }
         a.scaler_blocks = a.c[0].nblocks + (merged ? a.c[1].nblocks : 0);
+        a.grid_scaler = a.scaler_blocks; a.queue = nullptr;
+        if (p->knobs.persist && ch.lds && p->d_queue) {
+            // work queue: as many workgroups as stay resident (x persist / 10), a multiple of 8; the rest of the logical blocks are taken from the per-XCD counters
+            const uint32_t slots = uint32_t(p->n_cus) * uint32_t(blocks_per_cu(fn, bs.threads, bs.lds_bytes)) * uint32_t(p->knobs.persist) / 10u & ~7u;
+            if (slots >= 8 && a.scaler_blocks > slots) {
+                if (hipMemsetAsync(p->d_queue, 0, 64, st) != hipSuccess) return TTS_ERR_PROCESSING_FAILED;
+                a.grid_scaler = slots; a.queue = p->d_queue;
+            }
+        }
 #ifdef TTS_EXPERIMENTS
         a.dbg = exp_dbg_buffer(a.scaler_blocks);
 #endif
@@ -944,7 +956,7 @@ int launch_all(const tts_plan *p, const uint8_t *src, uint8_t *dst, int n, const
             pad_class(ci, bs.threads, a.pad[0]);
             if (fuse_range && ci) { a.range.mul[0] = range.mul[1]; a.range.add[0] = range.add[1]; a.range.shift[0] = range.shift[1]; }   // (a single class rides in slot 0)
         }
-        const uint32_t blocks = a.scaler_blocks + a.pad[0].nblocks + a.pad[1].nblocks;
+        const uint32_t blocks = a.grid_scaler + a.pad[0].nblocks + a.pad[1].nblocks;
         if (const int rc = launch_checked("strip kernel", fn, dim3(blocks), dim3(bs.threads), bs.lds_bytes, st, src, dst, p->d_tab, a)) return rc;
         if (merged) break;
     }
@@ -1007,6 +1019,7 @@ int launch_all(const tts_plan *p, const uint8_t *src, uint8_t *dst, int n, const
                 a.c[1] = a.c[0]; a.c[1].nblocks = 0;
             }
             a.scaler_blocks = a.c[0].nblocks + (cmerged ? a.c[1].nblocks : 0);
+            a.grid_scaler = a.scaler_blocks; a.queue = nullptr;
             a.y16 = p->y16 && (cmerged || ci == 0);
 #ifdef TTS_EXPERIMENTS
             a.dbg = exp_dbg_buffer(a.scaler_blocks);
