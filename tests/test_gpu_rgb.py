@@ -158,11 +158,12 @@ STRIP16_CASES = [
 
 
 @pytest.mark.parametrize("vf,iw,ih,fmt", STRIP16_CASES)
-def test_rgb_small_shrinks_strip_kernel_with_16_bit_luma(tts, oracle, vf, iw, ih, fmt):
-    """5-8 taps an axis: the scratch planes come from the LDS strip kernels (their Y16 instantiations) instead of the
-    column walk; bytes as the oracle's."""
+def test_rgb_small_shrinks_strip_kernel_with_16_bit_luma(tts, oracle, monkeypatch, vf, iw, ih, fmt):
+    """5-8 taps an axis without the fused walk (TTS_NO_RGB_WALK=1: what per-frame pointers still run): the scratch planes
+    come from the LDS strip kernels (their Y16 instantiations) instead of the column walk; bytes as the oracle's."""
     import torch
     chain = vf + ",format=" + fmt
+    monkeypatch.setenv("TTS_NO_RGB_WALK", "1")
     fast = tts.Plan.from_vf(chain, iw, ih)
     name = fast.kernel_name(0)
     assert name.startswith("strip_lds") and name.endswith("+rgb_convert"), name
@@ -175,6 +176,39 @@ def test_rgb_small_shrinks_strip_kernel_with_16_bit_luma(tts, oracle, vf, iw, ih
         assert bad.size == 0, "%s %s: %d bytes differ, first at %d" % (chain, kind, bad.size, bad[0])
 
 
+WALK_CASES = STRIP16_CASES + [
+    ("scale=720:1280", 1080, 1920, "rgb24"),           # the web compress box (portrait.test.js:70-97) as pixels
+    ("scale=1080:1920:force_original_aspect_ratio=increase,crop=1080:1920", 3840, 2160, "rgb24"),   # 4K -> portrait: 1.125x, a crop behind the scale
+    ("scale=1280:720", 1920, 1080, "bgra"),
+    ("scale=644:362", 1280, 720, "rgb24"),             # not a multiple of 8 wide: the last strip slid left, no sector exchange
+    ("scale=330:250", 400, 300, "bgr24"),              # a wave's strips wrap over several frames
+    ("scale=1278:718,crop=1000:600:100:50", 1920, 1080, "rgba"),
+    ("scale=960:1080", 1920, 1080, "rgb24"),           # 2x across (8 taps), nothing down the picture: one-tap luma rows, two-tap chroma
+    ("scale=1920:600", 1920, 1080, "rgb24"),           # nothing across, 1.8x down
+    ("scale=1280:720:flags=bilinear", 1920, 1080, "rgb24"),
+    ("scale=1280:720:flags=area", 1920, 1080, "rgb24"),
+]
+
+
+@pytest.mark.parametrize("vf,iw,ih,fmt", WALK_CASES)
+def test_rgb_small_shrinks_fused_walk(tts, oracle, vf, iw, ih, fmt):
+    """5-8 taps an axis, packed batches: ONE kernel filters luma and chroma side by side and writes the pixels once
+    (rgb_walk_kernel); bytes as the oracle's, batches whose waves wrap over frames included."""
+    import torch
+    chain = vf + ",format=" + fmt
+    plan = tts.Plan.from_vf(chain, iw, ih)
+    name = plan.kernel_name(0)
+    n = 1 if iw * ih > 4_000_000 else 5
+    for kind in ("random", "impulse"):
+        src = synth.frames(kind, iw, ih, n)
+        got = plan.run_batch(torch.from_numpy(src).cuda()).cpu().numpy()
+        want = oracle.run_chain(plan.geom, src)
+        bad = np.flatnonzero(got != want)
+        assert bad.size == 0, "%s %s [%s]: %d bytes differ, first at %d (got %d want %d)" % (chain, kind, name, bad.size, bad[0], got.ravel()[bad[0]], want.ravel()[bad[0]])
+    if "flags" not in vf and "960:1080" not in vf and "1920:600" not in vf:
+        assert name.startswith("rgb_walk<"), name
+
+
 @pytest.mark.parametrize("vf,iw,ih,fmt", SCRATCH_CASES)
 def test_rgb_thumbnails_column_walk_and_in_place_conversion(tts, oracle, monkeypatch, vf, iw, ih, fmt):
     """Many-tap shrinks written as packed RGB: the planar column walk leaves unclipped 16-bit luma and chroma at
@@ -185,8 +219,9 @@ def test_rgb_thumbnails_column_walk_and_in_place_conversion(tts, oracle, monkeyp
     n = 1 if iw * ih > 4_000_000 else 5
     src = synth.frames("random", iw, ih, n)
     fast = tts.Plan.from_vf(chain, iw, ih)
-    assert fast.kernel_name(0).endswith("+rgb_convert"), fast.kernel_name(0)
+    assert fast.kernel_name(0).endswith("+rgb_convert") or fast.kernel_name(0).startswith("rgb_walk<"), fast.kernel_name(0)   # (5-8 taps: the fused walk)
     monkeypatch.setenv("TTS_NO_RGB_SCRATCH", "1")
+    monkeypatch.setenv("TTS_NO_RGB_WALK", "1")
     slow = tts.Plan.from_vf(chain, iw, ih)
     assert slow.kernel_name(0).startswith("rgb_generic"), slow.kernel_name(0)
     d = torch.from_numpy(src).cuda()

@@ -225,6 +225,7 @@ const char *tts_plan_kernel_name(const tts_plan *p, int plane_class)
 {
     static thread_local char buf[96];
     if (!p || plane_class < 0 || plane_class > 1) return "";
+    if (p->rgb && tts::rgb_plan_kernel_name(p->rgb)[4] == 'w') return tts::rgb_plan_kernel_name(p->rgb);   // "rgb_walk<...>": what packed batches run
     if (p->scratch) {                                       // (what packed batches run; pointers and padded rows: the generic kernel)
         static thread_local char sbuf[128];
         std::snprintf(sbuf, sizeof sbuf, "%s+rgb_convert", tts_plan_kernel_name(p->scratch, plane_class));
@@ -310,6 +311,8 @@ int run_batch_impl(const tts_plan *p, const void *src, size_t src_pitch, const i
     tts::RgbScratchLayout lay{};
     // (sources under 4 KiB go to the one-lane-per-sample kernel, which has no 16-bit store: not through the scratch pass)
     bool use_scratch = p->rgb && p->scratch && sbytes >= 4096 && tts::rgb_scratch_layout(g, dstride[0], lay);
+    // (5-8 taps an axis, packed batches: the fused walk writes the pixels at once)
+    if (use_scratch && tts::rgb_plan_walks(p->rgb, n_frames, uint64_t(n_frames - 1) * src_pitch + sbytes, uint32_t(src_pitch), uint32_t(dst_pitch))) use_scratch = false;
 rgb_generic:
     if (p->rgb && !use_scratch) {
         // The RGB kernels cover the whole canvas (borders included) and address every frame from its own base

@@ -13,6 +13,14 @@ namespace tts {
 // the calling thread's tts_last_error() text (defined in ttscale.hip)
 void set_last_error(const std::string &msg);
 
+// BT.601 limited-range (or, for a yuvj420p source, full-range) tables of ff_yuv2rgb_c_init_tables() as a closed form:
+// a channel is clip_u8(((Y + off) * cy + k) >> 16) with off = ((clip_u8(C) * inc) >> 16) - (inc >> 9) per chroma term
+struct RgbCoef {
+    int32_t cy, crv, cbu, cgu, cgv;     // cy = 65536 * 255 / 219; the chroma increments "scaled by cy"
+    int32_t k;                          // 326 cy - (400 << 16) + 0x8000
+    int32_t off_r, off_g, off_b;        // -(crv >> 9), -(cgu >> 9) - (cgv >> 9), -(cbu >> 9)
+};
+
 struct RgbPlan;        // tables of one geometry whose output is packed RGB, on the current device
 
 // TTS_OK, or why this geometry cannot go out as packed RGB (message through set_last_error)
@@ -26,6 +34,20 @@ bool rgb_plan_general_only(const RgbPlan *p);   // rows through swscale's 1- / 2
 // pitch of the yuv420p source, dst_stride = bytes between RGB rows.  Asynchronous on st.
 int rgb_launch(const RgbPlan *p, const uint8_t *src, uint8_t *dst, int n, const int src_stride[2], int dst_stride,
                uint64_t src_span, uint64_t dst_span, const FrameAddr &addr, hipStream_t st);
+
+// ---- packed-RGB output of a scale with 5-8 taps an axis: one fused walk (ttscale_rgbwalk.hip) ---------------
+struct AxisFilter;
+struct RgbWalkPlan;
+// nullptr: the geometry does not fit the walk (more than 8 taps, a pad, windows that do not group, runs too long for the LDS slots)
+RgbWalkPlan *rgb_walk_create(const tts_geom &g, const AxisFilter &lh, const AxisFilter &lv, const AxisFilter &ch, const AxisFilter &cv,
+                             int bpp, int swap, const RgbCoef &coef, int n_cus);
+void rgb_walk_destroy(RgbWalkPlan *p);
+const char *rgb_walk_name(const RgbWalkPlan *p);
+bool rgb_walk_takes(const RgbWalkPlan *p, int n, uint64_t src_span, const FrameAddr &addr);    // packed batches whose waves fit 32-bit offsets
+int rgb_walk_launch(const RgbWalkPlan *p, const uint8_t *src, uint8_t *dst, int n, const int src_stride[2], int dst_stride,
+                    uint64_t src_span, uint64_t dst_span, const FrameAddr &addr, hipStream_t st);
+// the plan's walk, if it has one and it takes this packed batch (then no in-place scheme, no general kernel)
+bool rgb_plan_walks(const RgbPlan *p, int n, uint64_t src_span, uint32_t src_pitch, uint32_t dst_pitch);
 
 // ---- packed-RGB shrinks: planar column walk into the destination frame, converted in place ---------------
 // Where the planar pass leaves its rows inside an RGB frame whose rows are dst_stride bytes apart (offsets from

@@ -37,13 +37,7 @@
 
 namespace tts {
 
-// BT.601 limited-range tables of ff_yuv2rgb_c_init_tables() as the closed form above
-struct RgbCoef {
-    int32_t cy, crv, cbu, cgu, cgv;     // cy = 65536 * 255 / 219; the chroma increments "scaled by cy"
-    int32_t k;                          // 326 cy - (400 << 16) + 0x8000
-    int32_t off_r, off_g, off_b;        // -(crv >> 9), -(cgu >> 9) - (cgv >> 9), -(cbu >> 9)
-};
-
+// (RgbCoef -- the tables of ff_yuv2rgb_c_init_tables() as the closed form above -- is declared in ttscale_rgb.h)
 // full: the source is yuvj420p (ff_yuv2rgb_c_init_tables(fullRange = 1)): no luma stretch (cy = 1 << 16, no 16 << 16
 // offset), chroma coefficients x 224 / 255, table origin 384 instead of 326 -- the ramp is then y_table[384 + i] = i
 static RgbCoef rgb_coef(bool full = false)
@@ -1606,6 +1600,7 @@ struct RgbPlan {
     bool full = false;                 // the conversion pass reads a yuvj420p canvas: range step per sample (rng), full-range tables (coef)
     int rng[2][3] = {{1, 0, 0}, {1, 0, 0}};
     bool packed12 = false;             // some output rows take swscale's 1- / 2-line writers (vertical filters of 1-2 taps): the general kernel only
+    RgbWalkPlan *walk = nullptr;       // 5-8 taps an axis: the fused walk of ttscale_rgbwalk.hip (packed batches)
     char name[96] = "";
 };
 
@@ -1800,6 +1795,7 @@ int rgb_plan_create(const tts_geom &g, int n_cus, RgbPlan **out)
                 if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&p->strip_occ[v], rgb_strip_fns[(p->bpp == 4) * 4 + v], kBlock, 0) != hipSuccess || p->strip_occ[v] < 1) p->strip_occ[v] = 1;
             p->no_xp = std::getenv("TTS_NO_XP") && std::atoi(std::getenv("TTS_NO_XP"));
         }
+        if (!rc && !p->strip_ok && !p->packed12 && !full) p->walk = rgb_walk_create(g, p->lh, p->lv, p->ch, p->cv, p->bpp, p->swap, p->coef, n_cus);
     }
     if (rc) { rgb_plan_destroy(p); return rc; }
     *out = p;
@@ -1811,10 +1807,17 @@ void rgb_plan_destroy(RgbPlan *p)
     if (!p) return;
     for (int i = 0; i < 4; ++i) { (void)hipFree(p->d_pos[i]); (void)hipFree(p->d_taps[i]); }
     (void)hipFree(p->d_tab);
+    rgb_walk_destroy(p->walk);
     delete p;
 }
 
-const char *rgb_plan_kernel_name(const RgbPlan *p) { return p ? p->name : ""; }
+const char *rgb_plan_kernel_name(const RgbPlan *p) { return !p ? "" : p->walk ? rgb_walk_name(p->walk) : p->name; }
+bool rgb_plan_walks(const RgbPlan *p, int n, uint64_t src_span, uint32_t src_pitch, uint32_t dst_pitch)
+{
+    FrameAddr addr{};
+    addr.src_pitch = src_pitch; addr.dst_pitch = dst_pitch;
+    return p && p->walk && rgb_walk_takes(p->walk, n, src_span, addr);
+}
 bool rgb_plan_is_strip(const RgbPlan *p) { return p && p->strip_ok; }
 bool rgb_plan_general_only(const RgbPlan *p) { return p && (p->packed12 || p->full); }
 
@@ -1862,6 +1865,8 @@ int rgb_launch(const RgbPlan *p, const uint8_t *src, uint8_t *dst, int n, const 
             return launch_rgb("rgb_strip_kernel", fn, dim3(uint32_t(sblocks) * uint32_t(a.nseg)), dim3(kBlock), 0, st, src, dst, p->d_tab, a);
         }
     }
+    if (p->walk && rgb_walk_takes(p->walk, n, src_span, addr))
+        return rgb_walk_launch(p->walk, src, dst, n, src_stride, dst_stride, src_span, dst_span, addr, st);
     RgbFrameArgs f{};
     f.src = src; f.dst = dst;
     f.canvas_w = p->g.out_w; f.canvas_h = p->g.out_h;
