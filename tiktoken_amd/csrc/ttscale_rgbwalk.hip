@@ -146,15 +146,17 @@ __device__ __forceinline__ void walk_plan_run(uint32_t first, uint32_t last, uin
 }
 
 // BPP: 3 / 4 bytes a pixel; NL: 1 KiB LDS-DMAs per luma source row (a wave's luma runs hold <= 64 NL chunks);
-// D: luma source rows in flight per wave, one LDS slot each; XP: whole-sector stores through the LDS exchange
-template <int BPP, int NL, int D, bool XP>
-__global__ __launch_bounds__(kBlock, 2) void rgb_walk_kernel(const uint8_t *__restrict__ src, uint8_t *__restrict__ dst,
+// TP: tap pairs per column and ring row pairs (3: every filter but the vertical chroma one has <= 6 taps -- shrinks up
+// to 1.5x: the web box -- 4: <= 8 taps); XP: whole-sector stores through the LDS exchange.  D = 2 luma source rows are in
+// flight per wave, one LDS slot each (one: 7 % slower; four: 2 % faster at 8 more registers).
+template <int BPP, int NL, int TP, bool XP>
+__global__ __launch_bounds__(kBlock, TP == 3 ? 3 : 2) void rgb_walk_kernel(const uint8_t *__restrict__ src, uint8_t *__restrict__ dst,
                                                              const uint32_t *__restrict__ tab, const RgbWalkArgs a)
 {
     static_assert(BPP == 3 || BPP == 4, "rgb24 / bgr24 or rgba / bgra");
-    static_assert((NL == 1 || NL == 2) && (D == 1 || D == 2 || D == 4), "slots rotate with the ring of 8 rows");
+    static_assert((NL == 1 || NL == 2) && (TP == 3 || TP == 4), "slots rotate with the ring of 2 TP rows");
 #if defined(__HIP_DEVICE_COMPILE__)   // the LDS-DMA builtin exists in the device pass only
-    constexpr int RL = 8;
+    constexpr int RL = 2 * TP, D = 2;
     constexpr int kLSlot = NL * 1024 + 16;
     __shared__ __attribute__((aligned(16))) uint8_t ldsl[kBlock / 64][D][kLSlot];
     __shared__ __attribute__((aligned(16))) uint8_t ldsc[kBlock / 64][2][kWalkCSlot];
@@ -208,7 +210,7 @@ __global__ __launch_bounds__(kBlock, 2) void rgb_walk_kernel(const uint8_t *__re
     }
 
     // per-lane horizontal tables stay in registers for the whole walk
-    uint32_t offl[4], offu[2], offv[2], sell[8], coefl[8][4], selc[4], coefc[4][4];
+    uint32_t offl[4], offu[2], offv[2], sell[8], coefl[8][TP], selc[4], coefc[4][TP];
     {
 #pragma unroll
         for (int j = 0; j < 4; ++j) offl[j] = tab[a.hoffl + strip * 4 + j] + so[0];
@@ -218,13 +220,13 @@ __global__ __launch_bounds__(kBlock, 2) void rgb_walk_kernel(const uint8_t *__re
         for (int i = 0; i < 8; ++i) {
             sell[i] = tab[a.sell + strip * 8 + i];
 #pragma unroll
-            for (int k = 0; k < 4; ++k) coefl[i][k] = tab[a.coefl + (strip * 8 + i) * 4 + k];
+            for (int k = 0; k < TP; ++k) coefl[i][k] = tab[a.coefl + (strip * 8 + i) * 4 + k];
         }
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
             selc[i] = tab[a.selc + strip * 4 + i];
 #pragma unroll
-            for (int k = 0; k < 4; ++k) coefc[i][k] = tab[a.coefc + (strip * 4 + i) * 4 + k];
+            for (int k = 0; k < TP; ++k) coefc[i][k] = tab[a.coefc + (strip * 4 + i) * 4 + k];
         }
     }
 
@@ -338,7 +340,7 @@ __global__ __launch_bounds__(kBlock, 2) void rgb_walk_kernel(const uint8_t *__re
                 int acc = dot2(__builtin_amdgcn_perm(w[1], w[0], s0), coefl[i][0], 0);
                 acc = dot2(__builtin_amdgcn_perm(w[1], w[0], s1), coefl[i][1], acc);
                 acc = dot2(__builtin_amdgcn_perm(w[2], w[1], s0), coefl[i][2], acc);      // taps 4..7 sit four bytes on: the same selectors, one dword further
-                acc = dot2(__builtin_amdgcn_perm(w[2], w[1], s1), coefl[i][3], acc);
+                if constexpr (TP == 4) acc = dot2(__builtin_amdgcn_perm(w[2], w[1], s1), coefl[i][3], acc);
                 const uint32_t t = hfinish(acc);
                 ringl[i][s / 2] = (s & 1) ? __builtin_amdgcn_perm(t, ringl[i][s / 2], 0x05040100)
                                           : __builtin_amdgcn_perm(ringl[i][s / 2], t, 0x07060100);
@@ -346,7 +348,8 @@ __global__ __launch_bounds__(kBlock, 2) void rgb_walk_kernel(const uint8_t *__re
             // ---- output rows whose last luma source row this was
             while (next_last == r) {                             // wave-uniform
                 const int nc = y == y0 ? 4 : int(cur[1]);
-                const uint32_t vl0 = cur[2], vl1 = cur[3], vl2 = cur[4], vl3 = cur[5], vc0 = cur[6], vc1 = cur[7];
+                const uint32_t vl0 = cur[2], vl1 = cur[3], vl2 = cur[4], vc0 = cur[6], vc1 = cur[7];
+                [[maybe_unused]] const uint32_t vl3 = cur[5];
                 vr = (ctab_t)(tab + a.vrow) + 8 * size_t(min(y + 1, last_y));
 #pragma unroll
                 for (int k = 0; k < 8; ++k) cur[k] = vr[k];
@@ -371,11 +374,11 @@ __global__ __launch_bounds__(kBlock, 2) void rgb_walk_kernel(const uint8_t *__re
                         int au = dot2(__builtin_amdgcn_perm(wu[1], wu[0], s0), coefc[i][0], 0);
                         au = dot2(__builtin_amdgcn_perm(wu[1], wu[0], s1), coefc[i][1], au);
                         au = dot2(__builtin_amdgcn_perm(wu[2], wu[1], s0), coefc[i][2], au);
-                        au = dot2(__builtin_amdgcn_perm(wu[2], wu[1], s1), coefc[i][3], au);
+                        if constexpr (TP == 4) au = dot2(__builtin_amdgcn_perm(wu[2], wu[1], s1), coefc[i][3], au);
                         int av = dot2(__builtin_amdgcn_perm(wv[1], wv[0], s0), coefc[i][0], 0);
                         av = dot2(__builtin_amdgcn_perm(wv[1], wv[0], s1), coefc[i][1], av);
                         av = dot2(__builtin_amdgcn_perm(wv[2], wv[1], s0), coefc[i][2], av);
-                        av = dot2(__builtin_amdgcn_perm(wv[2], wv[1], s1), coefc[i][3], av);
+                        if constexpr (TP == 4) av = dot2(__builtin_amdgcn_perm(wv[2], wv[1], s1), coefc[i][3], av);
                         const uint32_t tu = hfinish(au), tv = hfinish(av);
                         ru[i][0] = __builtin_amdgcn_alignbit(ru[i][1], ru[i][0], 16);
                         ru[i][1] = __builtin_amdgcn_alignbit(tu, ru[i][1], 16);
@@ -387,8 +390,11 @@ __global__ __launch_bounds__(kBlock, 2) void rgb_walk_kernel(const uint8_t *__re
                 // vertical pass: yuv2rgb_X_c_template's 1 << 18 rounding, >> 19, no clip
                 int P[8], CR[4], CG[4], CB[4];
 #pragma unroll
-                for (int i = 0; i < 8; ++i)
-                    P[i] = __mul24(dot2(ringl[i][3], vl3, dot2(ringl[i][2], vl2, dot2(ringl[i][1], vl1, dot2(ringl[i][0], vl0, 1 << 18)))) >> 19, cy);
+                for (int i = 0; i < 8; ++i) {
+                    int t = dot2(ringl[i][2], vl2, dot2(ringl[i][1], vl1, dot2(ringl[i][0], vl0, 1 << 18)));
+                    if constexpr (TP == 4) t = dot2(ringl[i][3], vl3, t);
+                    P[i] = __mul24(t >> 19, cy);
+                }
 #pragma unroll
                 for (int j = 0; j < 4; ++j) {
                     const int U = walk_clip255(dot2(ru[j][1], vc1, dot2(ru[j][0], vc0, 1 << 18)) >> 19);
@@ -462,14 +468,14 @@ int launch_walk(const char *what, void (*fn)(P...), dim3 grid, dim3 block, hipSt
 
 typedef void (*rgb_walk_fn)(const uint8_t *, uint8_t *, const uint32_t *, const RgbWalkArgs);
 
-template <int BPP, int NL, int D>
-rgb_walk_fn walk_pick_xp(bool xp) { return xp ? rgb_walk_kernel<BPP, NL, D, true> : rgb_walk_kernel<BPP, NL, D, false>; }
+template <int BPP, int NL, int TP>
+rgb_walk_fn walk_pick_xp(bool xp) { return xp ? rgb_walk_kernel<BPP, NL, TP, true> : rgb_walk_kernel<BPP, NL, TP, false>; }
 template <int BPP, int NL>
-rgb_walk_fn walk_pick_d(int d, bool xp) { return d == 4 ? walk_pick_xp<BPP, NL, 4>(xp) : d == 2 ? walk_pick_xp<BPP, NL, 2>(xp) : walk_pick_xp<BPP, NL, 1>(xp); }
-rgb_walk_fn walk_pick(int bpp, int nl, int d, bool xp)
+rgb_walk_fn walk_pick_tp(int tp, bool xp) { return tp == 3 ? walk_pick_xp<BPP, NL, 3>(xp) : walk_pick_xp<BPP, NL, 4>(xp); }
+rgb_walk_fn walk_pick(int bpp, int nl, int tp, bool xp)
 {
-    if (bpp == 3) return nl == 2 ? walk_pick_d<3, 2>(d, xp) : walk_pick_d<3, 1>(d, xp);
-    return nl == 2 ? walk_pick_d<4, 2>(d, xp) : walk_pick_d<4, 1>(d, xp);
+    if (bpp == 3) return nl == 2 ? walk_pick_tp<3, 2>(tp, xp) : walk_pick_tp<3, 1>(tp, xp);
+    return nl == 2 ? walk_pick_tp<4, 2>(tp, xp) : walk_pick_tp<4, 1>(tp, xp);
 }
 
 }  // namespace
@@ -479,7 +485,7 @@ namespace tts {
 struct RgbWalkPlan {
     tts_geom g{};
     int n_cus = 256, bpp = 3;
-    int nl = 1, depth = 2;             // luma DMAs a row, luma rows in flight
+    int nl = 1, tp = 4;                // luma DMAs a row; tap pairs per column = ring row pairs (3: every filter <= 6 taps)
     bool no_xp = false;
     uint32_t *d_tab = nullptr;
     RgbWalkArgs args{};                // table offsets and constants; per-launch fields are filled in by rgb_walk_launch
@@ -565,8 +571,10 @@ RgbWalkPlan *rgb_walk_create(const tts_geom &g, const AxisFilter &lh, const Axis
         p->nl = cl <= 64u ? 1 : 2;
     }
     if (!ok) { delete p; return nullptr; }
+    p->tp = lh.size <= 6 && ch.size <= 6 && lv.size <= 6 && !env("TTS_RGB_WALK_TP4") ? 3 : 4;
+    const int rl = 2 * p->tp;
     // per output row and segment length: the luma source row that completes it, the chroma rows that enter first, the
-    // luma taps by ring slot (source row - the segment's first row) mod 8, the chroma taps right-aligned in 4 rows
+    // luma taps by ring slot (source row - the segment's first row) mod 2 tp, the chroma taps right-aligned in 4 rows
     for (int sr : {16, 24, 32, 48, 64, 96, 128, 192, 256}) {
         RgbWalkPlan::Seg sg;
         sg.seg_rows = sr; sg.nseg = (ph + sr - 1) / sr;
@@ -584,7 +592,7 @@ RgbWalkPlan *rgb_walk_create(const tts_geom &g, const AxisFilter &lh, const Axis
             r[0] = uint32_t(lv.pos[vy] + lv.size - 1);
             r[1] = y ? uint32_t(cv.pos[vy] - cv.pos[vy - 1]) : 0u;
             int16_t tl[8] = {0, 0, 0, 0, 0, 0, 0, 0}, tc[4] = {0, 0, 0, 0};
-            for (int k = 0; k < lv.size; ++k) tl[(lv.pos[vy] + k - rstart) & 7] = lv.taps[size_t(vy) * lv.size + k];
+            for (int k = 0; k < lv.size; ++k) tl[(lv.pos[vy] + k - rstart) % rl] = lv.taps[size_t(vy) * lv.size + k];
             for (int k = 0; k < cv.size; ++k) tc[4 - cv.size + k] = cv.taps[size_t(vy) * cv.size + k];
             for (int k = 0; k < 4; ++k) r[2 + k] = pack16(tl[2 * k], tl[2 * k + 1]);
             r[6] = pack16(tc[0], tc[1]); r[7] = pack16(tc[2], tc[3]);
@@ -597,16 +605,14 @@ RgbWalkPlan *rgb_walk_create(const tts_geom &g, const AxisFilter &lh, const Axis
     a.src_h_l = lv.src; a.src_h_c = cv.src;
     a.row_rel[0] = uint32_t(lh.src); a.row_rel[1] = uint32_t(ch.src);            // (the context's source rows: what chunks_needed counted)
     a.swap = swap; a.coef = coef;
-    p->depth = env("TTS_RGB_WALK_D") ? env("TTS_RGB_WALK_D") : 2;
-    if (p->depth != 1 && p->depth != 2 && p->depth != 4) p->depth = 2;
     p->no_xp = env("TTS_NO_XP") != 0;
     if (ok) {
         const size_t bytes = std::max<size_t>(tab.size(), 1) * sizeof(uint32_t);
         ok = hipMalloc(reinterpret_cast<void **>(&p->d_tab), bytes) == hipSuccess && hipMemcpy(p->d_tab, tab.data(), tab.size() * sizeof(uint32_t), hipMemcpyHostToDevice) == hipSuccess;
     }
     if (!ok) { rgb_walk_destroy(p); return nullptr; }
-    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&p->occ, walk_pick(bpp, p->nl, p->depth, true), kBlock, 0) != hipSuccess || p->occ < 1) p->occ = 2;
-    std::snprintf(p->name, sizeof p->name, "rgb_walk<%d,%d,%d,%d,%d,dma%d,d%d>", bpp, lh.size, lv.size, ch.size, cv.size, p->nl, p->depth);
+    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&p->occ, walk_pick(bpp, p->nl, p->tp, true), kBlock, 0) != hipSuccess || p->occ < 1) p->occ = 2;
+    std::snprintf(p->name, sizeof p->name, "rgb_walk<%d,%d,%d,%d,%d,dma%d,tp%d>", bpp, lh.size, lv.size, ch.size, cv.size, p->nl, p->tp);
     return p;
 }
 
@@ -651,7 +657,7 @@ int rgb_walk_launch(const RgbWalkPlan *p, const uint8_t *src, uint8_t *dst, int 
         const int pw_ = (g.in_w + k) >> k, ph_ = (g.in_h + k) >> k, px_ = g.pre_x >> k, py_ = g.pre_y >> k;
         a.end_rel[k] = uint32_t(ph_ - py_ - 1) * uint32_t(src_stride[k]) + uint32_t(pw_ - px_);
     }
-    return launch_walk("rgb_walk_kernel", walk_pick(p->bpp, p->nl, p->depth, xp), dim3(uint32_t(sblocks) * uint32_t(a.nseg)), dim3(kBlock), st,
+    return launch_walk("rgb_walk_kernel", walk_pick(p->bpp, p->nl, p->tp, xp), dim3(uint32_t(sblocks) * uint32_t(a.nseg)), dim3(kBlock), st,
                        src, dst, static_cast<const uint32_t *>(p->d_tab), a);
 }
 

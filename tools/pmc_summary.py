@@ -11,7 +11,7 @@ acc = defaultdict(lambda: defaultdict(list))
 for f in glob.glob(os.path.join(out, "p*", "**", "*counter_collection.csv"), recursive=True):
     for r in csv.DictReader(open(f)):
         k = r["Kernel_Name"]
-        names = [n for n in ("rgb_strip", "rgb_generic", "rgb_unscaled", "rgbin_", "strip_", "column_lds", "generic_kernel") if n in k]
+        names = [n for n in ("rgb_walk", "rgb_strip", "rgb_generic", "rgb_unscaled", "rgbin_", "strip_", "column_lds", "generic_kernel") if n in k]
         if not names:
             continue
         k = k[k.index(names[0]):][:44]
