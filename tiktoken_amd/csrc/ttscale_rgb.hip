@@ -1614,6 +1614,7 @@ static bool build_rgb_strip(RgbPlan *p)
     const tts_geom &g = p->g;
     const AxisFilter &lh = p->lh, &lv = p->lv, &ch = p->ch, &cv = p->cv;
     if (std::getenv("TTS_FORCE_GENERIC") && std::atoi(std::getenv("TTS_FORCE_GENERIC"))) return false;
+    if (std::getenv("TTS_NO_RGB_STRIP") && std::atoi(std::getenv("TTS_NO_RGB_STRIP"))) return false;     // (A/B: the 5-8 tap walk takes the enlargements too)
     if (g.rgb_stage != TTS_RGB_AT_SCALE || g.do_pad || p->two_stage) return false;
     if (lh.size > 4 || lv.size > 4 || ch.size > 4 || cv.size > 4) return false;
     if ((g.crop_x & 1) || (g.crop_w & 1) || g.crop_w < 8) return false;           // pixel pairs must not straddle a strip

@@ -51,6 +51,9 @@ CASES = {
     "cvt_rgba": ("format=rgba", 1920, 1080, 3110400 + 8294400),
     "cvt_rgbin": ("format=yuv420p", 1920, 1080, 6220800 + 3110400),                                  # rgb24 -> yuv420p, no scale
     "web_rgb24": ("scale=720:1280,format=rgb24", 1080, 1920, 3110400 + 2764800),      # 1.5x shrink written as RGB
+    "web_rgba": ("scale=720:1280,format=rgba", 1080, 1920, 3110400 + 3686400),
+    "4k_rgb24": ("scale=1080:1920:force_original_aspect_ratio=increase,crop=1080:1920,format=rgb24", 3840, 2160, 3939840 + 6220800),   # 1.125x shrink, 5 taps
+    "half_rgb24": ("scale=1920:1080,format=rgb24", 3840, 2160, 12441600 + 6220800),      # 2x shrink, 8 taps
     "thumbref_rgb24": ("scale=320x180:force_original_aspect_ratio=decrease,pad=320x180:-1:-1:color=black,format=rgb24", 1920, 1080, 3110400 + 172800),
 }
 
