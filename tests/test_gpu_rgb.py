@@ -430,6 +430,46 @@ def test_rgb24_input_enlargements_strip_walk(tts, oracle, monkeypatch, vf, iw, i
         assert np.array_equal(got, tiled.run_batch(d).cpu().numpy())
 
 
+RGBIN_SHRINK_CASES = [
+    ("scale=960:540", 1920, 1080),                     # 2x exactly: 8 taps across, 16 down the chroma planes
+    ("scale=720:1280", 1080, 1920),                    # the web compress box (portrait.test.js:70-97) from an RGB source: 1.5x
+    ("scale=1280:720", 1920, 1080),
+    ("scale=640:360", 1280, 720),
+    ("scale=320:568:flags=area", 1080, 1920),          # BASELINE's thumbnails from an RGB source: 3.4x, 5 taps across (area)
+    ("scale=1080:1920:force_original_aspect_ratio=increase,crop=1080:1920", 3840, 2160),   # 4K -> portrait: 1.125x, a crop behind the scale
+    ("scale=960:540,crop=800:400:80:70", 1920, 1080),  # crop at an odd row
+    ("scale=48:26", 64, 36),                           # a partial wave; 13 chroma rows out
+    ("scale=1280:300", 1920, 1080),                    # 1.5x across, 3.6x down: 14 luma and 29 chroma taps down the picture
+    ("scale=1718:1000", 1920, 1080),                   # 1.12x: 4-pixel lanes, a width of 4 k + 2
+    ("scale=640:360:flags=bilinear", 1280, 720),
+]
+
+
+@pytest.mark.parametrize("vf,iw,ih", RGBIN_SHRINK_CASES)
+def test_rgb24_input_shrinks_source_row_walk(tts, oracle, monkeypatch, vf, iw, ih):
+    """rgb24 in, shrunk (at most 8 taps across): rgbin_shrink_kernel (lanes are (frame, strip) pairs; the wave converts
+    its runs of pixels once per source row into LDS -- chroma per pixel pair: rgb24ToUV_half_c -- lanes filter 4 luma +
+    2 + 2 chroma columns from there and add the row into the sums of the output rows that hold it); the tiled kernel
+    (TTS_NO_RGBIN_SHRINK=1) and the oracle give the same bytes; one frame and batches whose waves straddle frames."""
+    import torch
+    fast = tts.Plan.from_vf(vf, iw, ih, in_fmt="rgb24")
+    assert fast.kernel_name(0).startswith("rgbin_shrink"), fast.kernel_name(0)
+    monkeypatch.setenv("TTS_NO_RGBIN_SHRINK", "1")
+    tiled = tts.Plan.from_vf(vf, iw, ih, in_fmt="rgb24")
+    assert not tiled.kernel_name(0).startswith("rgbin_shrink"), tiled.kernel_name(0)
+    big = iw * ih > 500 * 1000
+    for pat, n in (("random", 1), ("impulse", 2), ("zone", 2 if big else 24)):
+        src = rgb_frames(pat, iw, ih, n)
+        d = torch.from_numpy(src).cuda()
+        got = fast.run_batch(d).cpu().numpy()
+        m = min(n, 2)
+        want = oracle.run_chain(fast.geom, src[:m])
+        bad = np.flatnonzero(got[:m].ravel() != want.ravel())
+        assert bad.size == 0, "%s %dx%d %s n=%d [%s]: %d bytes differ, first at %d (got %d want %d)" % (
+            vf, iw, ih, pat, n, fast.kernel_name(0), bad.size, bad[0], got[:m].ravel()[bad[0]], want.ravel()[bad[0]])
+        assert np.array_equal(got, tiled.run_batch(d).cpu().numpy())
+
+
 def rgb_frames(pattern, w, h, n):
     """Packed rgb24 test frames: the three planes of the yuv generator at full size, interleaved."""
     y = synth.frames(pattern, 2 * w, 2 * h, n)         # gives planes of w x h as its chroma
@@ -462,6 +502,7 @@ def test_rgb24_input_tiled_and_generic_kernels_agree(tts, oracle, monkeypatch, v
     import torch
     src = rgb_frames("random", iw, ih, 4)
     monkeypatch.setenv("TTS_NO_RGBIN_STRIP", "1")        # (enlargements take the strip walk by default: its own test below)
+    monkeypatch.setenv("TTS_NO_RGBIN_SHRINK", "1")       # (shrinks the source-row walk)
     tiled = tts.Plan.from_vf(vf, iw, ih, in_fmt="rgb24")
     assert tiled.kernel_name(0).startswith("rgbin_tile"), tiled.kernel_name(0)
     monkeypatch.setenv("TTS_FORCE_GENERIC", "1")

@@ -71,4 +71,23 @@ const char *rgbin_plan_kernel_name(const RgbInPlan *p);
 int rgbin_launch(const RgbInPlan *p, const uint8_t *src, uint8_t *dst, int n, int src_stride, const int dst_stride[2],
                  const FrameAddr &addr, hipStream_t st, int only_plane = -1);
 
+// ---- packed rgb24 in, shrunk (at most 8 taps across): one walk over the source rows (ttscale_rgbin_shrink.hip) ----
+struct RgbInShrinkPlan;
+// nullptr: the geometry does not fit (an enlargement across, more than 8 taps across, a pad, odd widths, ...)
+RgbInShrinkPlan *rgbin_shrink_create(const tts_geom &g, const AxisFilter &lh, const AxisFilter &lv, const AxisFilter &ch, const AxisFilter &cv, const int coef[9]);
+void rgbin_shrink_destroy(RgbInShrinkPlan *p);
+const char *rgbin_shrink_name(const RgbInShrinkPlan *p);
+int rgbin_shrink_launch(const RgbInShrinkPlan *p, const uint8_t *src, uint8_t *dst, int n, int src_stride, const int dst_stride[2],
+                        const FrameAddr &addr, hipStream_t st);
+
+// utils.c fill_rgb2yuv_table(): the default matrix's table (BT.601 limited range), 15 fractional bits: ry gy by, ru gu bu, rv gv bv
+inline void rgbin_coefficients(int coef[9])
+{
+    const double S = 32768.0;
+    const int c[9] = {int(0.299 * 219 / 255 * S + 0.5), int(0.587 * 219 / 255 * S + 0.5), int(0.114 * 219 / 255 * S + 0.5),
+                      -int(0.169 * 224 / 255 * S + 0.5), -int(0.331 * 224 / 255 * S + 0.5), int(0.500 * 224 / 255 * S + 0.5),
+                      int(0.500 * 224 / 255 * S + 0.5), -int(0.419 * 224 / 255 * S + 0.5), -int(0.081 * 224 / 255 * S + 0.5)};
+    for (int i = 0; i < 9; ++i) coef[i] = c[i];
+}
+
 }  // namespace tts

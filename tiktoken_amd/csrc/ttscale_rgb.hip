@@ -1986,6 +1986,7 @@ struct RgbInPlan {
     uint32_t so_strip = 0, so_wave = 0, so_lastl = 0, so_vcol = 0, so_lastc = 0, so_vcoc = 0;
     int strips = 0, pxl = 8, chd = 2;
     int seg_knob = 0;                  // TTS_RGBIN_SEG at plan creation: row segments a launch (0: the launch decides)
+    RgbInShrinkPlan *shrink = nullptr; // shrinks with at most 8 taps across: the source-row walk of ttscale_rgbin_shrink.hip
     char name[96] = "";
 };
 
@@ -2182,7 +2183,13 @@ int rgbin_plan_create(const tts_geom &g, RgbInPlan **out)
             }
         }
     }
-    if (p->walk) std::snprintf(p->name, sizeof p->name, "rgbin_walk<%d>", p->cv.size);
+    if (!rc && !p->walk && !p->strip) {
+        int coef[9];
+        rgbin_coefficients(coef);
+        p->shrink = rgbin_shrink_create(g, p->lh, p->lv, p->ch, p->cv, coef);
+    }
+    if (p->shrink) std::snprintf(p->name, sizeof p->name, "%s", rgbin_shrink_name(p->shrink));
+    else if (p->walk) std::snprintf(p->name, sizeof p->name, "rgbin_walk<%d>", p->cv.size);
     else if (p->strip) std::snprintf(p->name, sizeof p->name, "rgbin_strip<%d,%d,%d,%d,%dpx>", p->lh.size, p->lv.size, p->ch.size, p->cv.size, p->pxl);   // luma taps across / down, chroma taps across / down
     else if (p->tiled) std::snprintf(p->name, sizeof p->name, "rgbin_tile<%d,%d>", p->th[0], p->th[1]);
     else std::snprintf(p->name, sizeof p->name, "rgbin_generic<%d,%d,%d,%d>", p->lh.size, p->lv.size, p->ch.size, p->cv.size);
@@ -2196,6 +2203,7 @@ void rgbin_plan_destroy(RgbInPlan *p)
     if (!p) return;
     for (int i = 0; i < 4; ++i) { (void)hipFree(p->d_pos[i]); (void)hipFree(p->d_taps[i]); }
     (void)hipFree(p->d_walk); (void)hipFree(p->d_strip);
+    rgbin_shrink_destroy(p->shrink);
     delete p;
 }
 
@@ -2222,11 +2230,8 @@ int rgbin_launch(const RgbInPlan *p, const uint8_t *src, uint8_t *dst, int n, in
     a.src_origin = uint32_t(g.pre_y) * uint32_t(src_stride) + uint32_t(g.pre_x) * 3u;
     a.src_extent = uint32_t(size_t(g.in_h - 1) * size_t(src_stride) + size_t(g.in_w) * 3);
     a.fill[0] = g.fill_y; a.fill[1] = g.fill_u; a.fill[2] = g.fill_v;
-    // utils.c fill_rgb2yuv_table(): the default matrix's table, 15 fractional bits
-    const double S = 32768.0;
-    const int coef[9] = {int(0.299 * 219 / 255 * S + 0.5), int(0.587 * 219 / 255 * S + 0.5), int(0.114 * 219 / 255 * S + 0.5),
-                         -int(0.169 * 224 / 255 * S + 0.5), -int(0.331 * 224 / 255 * S + 0.5), int(0.500 * 224 / 255 * S + 0.5),
-                         int(0.500 * 224 / 255 * S + 0.5), -int(0.419 * 224 / 255 * S + 0.5), -int(0.081 * 224 / 255 * S + 0.5)};
+    int coef[9];
+    rgbin_coefficients(coef);
     for (int i = 0; i < 9; ++i) a.coef[i] = coef[i];
     a.addr = addr;
     int rc = TTS_OK;
@@ -2293,6 +2298,13 @@ int rgbin_launch(const RgbInPlan *p, const uint8_t *src, uint8_t *dst, int n, in
                               : (p->chd == 2 ? rgbin_strip_kernel<8, 2> : p->chd == 3 ? rgbin_strip_kernel<8, 3> : rgbin_strip_kernel<8, 4>);
         return launch_rgb("rgbin_strip_kernel", fn, dim3(unsigned((waves + kBlock / 64 - 1) / (kBlock / 64)), unsigned(w.nseg), 1), dim3(kBlock), 0, st, src, dst, static_cast<const int32_t *>(p->d_strip), w);
     }
+    // shrinks: the source-row walk, where the output planes lie on the halfword grid its stores need
+    bool shrink = p->shrink && only_plane < 0 && reinterpret_cast<uintptr_t>(dst) % 2 == 0 && dst_stride[0] % 2 == 0 && int64_t(n) * ((g.out_w + 3) / 4) < (int64_t(1) << 30);
+    if (shrink && addr.use_table) {
+        for (int i = 0; i < n && shrink; ++i) shrink = addr.dst_tab[0][i] % 2 == 0;
+    } else if (shrink)
+        shrink = addr.dst_pitch % 2 == 0 && addr.dst_plane[0] % 2 == 0;
+    if (shrink) return rgbin_shrink_launch(p->shrink, src, dst, n, src_stride, dst_stride, addr, st);
     for (int f0 = 0; f0 < n && !rc; f0 += 21845) {          // grid.z = frames x 3 planes
         const int nf = std::min(21845, n - f0);
         a.frame0 = f0;

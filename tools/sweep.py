@@ -43,6 +43,9 @@ CASES = {
     # packed rgb24 IN, yuv420p out (the reverse of the above): 3 bytes a pixel read once + the planes written once
     "portrait_rgbin": ("scale=1080:1920:force_original_aspect_ratio=increase,crop=1080:1920", 1920, 1080, 608 * 1080 * 3 + 3110400),
     "stretch_rgbin": ("scale=w=720:h=1280", 480, 854, 480 * 854 * 3 + 1382400),
+    "half_rgbin": ("scale=960:540", 1920, 1080, 6220800 + 777600),                       # 2x shrink from RGB: 8 taps across, 16 down the chroma planes
+    "web_rgbin": ("scale=720:1280", 1080, 1920, 6220800 + 1382400),                     # the web box from RGB: 1.5x
+    "thumb_rgbin": ("scale=320:568:flags=area", 1080, 1920, 6220800 + 272640),          # BASELINE's thumbnails from RGB
     "cvt_yuvj": ("format=yuvj420p", 1920, 1080, 3110400 * 2),                               # range step alone
     "pad_only": ("pad=1920:1280:-1:-1:color=black", 1920, 1080, 3110400 + 1920 * 1280 * 3 // 2),
     "crop_only": ("crop=1080:1080", 1920, 1080, 1080 * 1080 * 3),
@@ -58,7 +61,7 @@ CASES = {
 }
 
 
-IN_FMT = {"portrait_rgbin": "rgb24", "stretch_rgbin": "rgb24", "cvt_rgbin": "rgb24"}
+IN_FMT = {"portrait_rgbin": "rgb24", "stretch_rgbin": "rgb24", "cvt_rgbin": "rgb24", "half_rgbin": "rgb24", "web_rgbin": "rgb24", "thumb_rgbin": "rgb24"}
 
 
 def plan_for(case):
