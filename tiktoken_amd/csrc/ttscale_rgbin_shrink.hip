@@ -26,7 +26,7 @@
 
 namespace {
 
-constexpr int kPend = 8;               // output rows a source row may contribute to (host-checked)
+constexpr int kPend = 8;               // output rows a source row may contribute to, at most (host-checked; the kernel keeps KP <= kPend sums a column)
 constexpr int kRowEntry = 4 + 2 * kPend;   // dwords of a source row's table entry
 
 struct RgbInShrinkArgs {
@@ -44,9 +44,11 @@ struct RgbInShrinkArgs {
 typedef float f32x2_t __attribute__((ext_vector_type(2)));
 typedef const __attribute__((address_space(4))) int32_t *ctab_t;   // wave-uniform reads of it are scalar loads
 
-// PXL: pixels of the wave's runs a lane converts per row (4 or 8); TPH: tap pairs of a horizontal window (taps <= 6, 8)
-template <int PXL, int TPH>
-__global__ __launch_bounds__(kBlock, 3) void rgbin_shrink_kernel(const uint8_t *__restrict__ src, uint8_t *__restrict__ dst,
+// PXL: pixels of the wave's runs a lane converts per row (4 or 8); TPH: tap pairs of a horizontal window (taps <= 6, 8);
+// KP: sums kept per column = the most output rows any source row of this geometry contributes to (6: 16 registers fewer
+// than 8, which is the fourth wave a SIMD)
+template <int PXL, int TPH, int KP>
+__global__ __launch_bounds__(kBlock, KP == 6 ? 4 : 3) void rgbin_shrink_kernel(const uint8_t *__restrict__ src, uint8_t *__restrict__ dst,
                                                                  const int32_t *__restrict__ tab, const RgbInShrinkArgs a)
 {
     static_assert((PXL == 4 || PXL == 8) && (TPH == 3 || TPH == 4), "pixels a lane converts; tap pairs a window");
@@ -116,9 +118,9 @@ __global__ __launch_bounds__(kBlock, 3) void rgbin_shrink_kernel(const uint8_t *
     const f32x2_t yR = a.cy[0], yG = a.cy[1], yB = a.cy[2], y0 = a.cy[3];
     const f32x2_t cR = {a.cu[0], a.cv[0]}, cG = {a.cu[1], a.cv[1]}, cB = {a.cu[2], a.cv[2]}, c0 = {a.cu[3], a.cv[3]};
     constexpr int kBias = 64 << 12;
-    int accl[4][kPend], accu[2][kPend], accv[2][kPend];
+    int accl[4][KP], accu[2][KP], accv[2][KP];
 #pragma unroll
-    for (int k = 0; k < kPend; ++k) {
+    for (int k = 0; k < KP; ++k) {
 #pragma unroll
         for (int c = 0; c < 4; ++c) accl[c][k] = kBias;
 #pragma unroll
@@ -234,7 +236,7 @@ __global__ __launch_bounds__(kBlock, 3) void rgbin_shrink_kernel(const uint8_t *
         // ---- vertical pass, output-stationary: this row into the sums of the output rows that hold it
         const int npl = (e[2] >> 16) & 255, npc = (e[2] >> 24) & 255;
 #pragma unroll
-        for (int k = 0; k < kPend; ++k) {
+        for (int k = 0; k < KP; ++k) {
             if (k < 4 || k < npl) {                                  // wave-uniform (the first four always: zero taps where nothing is pending)
 #pragma unroll
                 for (int c = 0; c < 4; ++c) accl[c][k] = __mul24(hl[c], e[4 + k]) + accl[c][k];
@@ -256,8 +258,8 @@ __global__ __launch_bounds__(kBlock, 3) void rgbin_shrink_kernel(const uint8_t *
 #pragma unroll
             for (int c = 0; c < 4; ++c) {
 #pragma unroll
-                for (int k = 0; k < kPend - 1; ++k) accl[c][k] = accl[c][k + 1];
-                accl[c][kPend - 1] = kBias;
+                for (int k = 0; k < KP - 1; ++k) accl[c][k] = accl[c][k + 1];
+                accl[c][KP - 1] = kBias;
             }
         }
         for (int i = 0; i < ncc; ++i) {
@@ -271,8 +273,8 @@ __global__ __launch_bounds__(kBlock, 3) void rgbin_shrink_kernel(const uint8_t *
 #pragma unroll
             for (int j = 0; j < 2; ++j) {
 #pragma unroll
-                for (int k = 0; k < kPend - 1; ++k) { accu[j][k] = accu[j][k + 1]; accv[j][k] = accv[j][k + 1]; }
-                accu[j][kPend - 1] = accv[j][kPend - 1] = kBias;
+                for (int k = 0; k < KP - 1; ++k) { accu[j][k] = accu[j][k + 1]; accv[j][k] = accv[j][k + 1]; }
+                accu[j][KP - 1] = accv[j][KP - 1] = kBias;
             }
         }
     }
@@ -299,7 +301,7 @@ struct RgbInShrinkPlan {
     tts_geom g{};
     int32_t *d_tab = nullptr;
     RgbInShrinkArgs args{};            // table offsets and constants; per-launch fields are filled in by rgbin_shrink_launch
-    int pxl = 8, tph = 4;
+    int pxl = 8, tph = 4, kp = 8;
     int seg_knob = 0;                  // TTS_RGBIN_SEG at plan creation: row segments a launch (0: the launch decides)
     char name[96] = "";
 };
@@ -412,7 +414,7 @@ RgbInShrinkPlan *rgbin_shrink_create(const tts_geom &g, const AxisFilter &lh, co
     a.o_rows = uint32_t(t.size());
     t.resize(t.size() + size_t(kRowEntry) * (h1 - h0), 0);
     {
-        int yl = 0, yc = 0;
+        int yl = 0, yc = 0, most = 0;
         for (int r = h0; r < h1 && ok; ++r) {
             int32_t *E = t.data() + a.o_rows + size_t(kRowEntry) * (r - h0);
             while (yl < oh && ll[yl] < r) ++yl;
@@ -428,11 +430,13 @@ RgbInShrinkPlan *rgbin_shrink_create(const tts_geom &g, const AxisFilter &lh, co
                 E[4 + kPend + npc] = cv.taps[size_t(oyc + y) * cvt + (r - pc[y])];
                 ncc += lcv[y] == r;
             }
+            most = std::max(most, std::max(npl, npc));
             E[0] = yl; E[1] = yc;
             E[2] = ncl | ncc << 8 | npl << 16 | npc << 24;
             E[3] = std::max(h0, std::min(yl < oh ? pl[yl] : r, yc < och ? pc[yc] : r));
             if (ncl > 255 || ncc > 255) ok = false;
         }
+        p->kp = most <= 6 && !env("TTS_RGBIN_SHRINK_KP8") ? 6 : 8;
     }
     if (ok) {
         const size_t bytes = std::max<size_t>(t.size(), 1) * sizeof(int32_t);
@@ -447,7 +451,7 @@ RgbInShrinkPlan *rgbin_shrink_create(const tts_geom &g, const AxisFilter &lh, co
     a.cy[3] = float(2 * ((32 << 14) + (1 << 8)) + 1) / 1024.0f;
     a.cu[3] = a.cv[3] = 1.0f / 2048.0f;
     p->seg_knob = env("TTS_RGBIN_SEG");
-    std::snprintf(p->name, sizeof p->name, "rgbin_shrink<%d,%d,%d,%d,%dpx,%d strips a wave>", lht, lvt, cht, cvt, best_pxl, best_spw);
+    std::snprintf(p->name, sizeof p->name, "rgbin_shrink<%d,%d,%d,%d,%dpx,%d strips a wave,%d sums>", lht, lvt, cht, cvt, best_pxl, best_spw, p->kp);
     return p;
 }
 
@@ -477,7 +481,8 @@ int rgbin_shrink_launch(const RgbInShrinkPlan *p, const uint8_t *src, uint8_t *d
     if (p->seg_knob > 0) nseg = std::max(1, std::min(p->seg_knob, rows / 8));
     w.seg_rows = (rows + nseg - 1) / nseg;
     w.nseg = (rows + w.seg_rows - 1) / w.seg_rows;
-    auto fn = p->pxl == 4 ? (p->tph == 3 ? rgbin_shrink_kernel<4, 3> : rgbin_shrink_kernel<4, 4>) : (p->tph == 3 ? rgbin_shrink_kernel<8, 3> : rgbin_shrink_kernel<8, 4>);
+    auto fn = p->kp == 6 ? (p->pxl == 4 ? (p->tph == 3 ? rgbin_shrink_kernel<4, 3, 6> : rgbin_shrink_kernel<4, 4, 6>) : (p->tph == 3 ? rgbin_shrink_kernel<8, 3, 6> : rgbin_shrink_kernel<8, 4, 6>))
+                         : (p->pxl == 4 ? (p->tph == 3 ? rgbin_shrink_kernel<4, 3, 8> : rgbin_shrink_kernel<4, 4, 8>) : (p->tph == 3 ? rgbin_shrink_kernel<8, 3, 8> : rgbin_shrink_kernel<8, 4, 8>));
     return launch_shrink("rgbin_shrink_kernel", fn, dim3(unsigned((waves + kBlock / 64 - 1) / (kBlock / 64)), unsigned(w.nseg), 1), dim3(kBlock), st,
                          src, dst, static_cast<const int32_t *>(p->d_tab), w);
 }
