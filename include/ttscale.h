@@ -62,7 +62,7 @@ typedef struct tts_geom {
     int32_t out_fmt;                          /* TTS_FMT_*: what the chain hands out (0 = yuv420p) */
     int32_t rgb_stage;                        /* TTS_RGB_*: where the yuv -> RGB conversion sits (0 when out_fmt is yuv420p) */
     int32_t fill_rgb;                         /* pad colour as 0xRRGGBB, used when the pad stage works on RGB pixels */
-    int32_t in_fmt;                           /* TTS_FMT_YUV420P or TTS_FMT_RGB24: what the chain is fed (tts_parse_vf_fmt) */
+    int32_t in_fmt;                           /* TTS_FMT_*: what the chain is fed (tts_parse_vf_fmt); 0 = yuv420p */
 } tts_geom;
 
 /* One frame: Y, U, V plane pointers and byte strides (yuv420p), or plane[0] / stride[0] alone (packed RGB). */
@@ -95,7 +95,10 @@ int tts_parse_vf(const char *vf, int iw, int ih, tts_geom *out);
  * swscale's input side (libswscale/input.c rgb24ToY_c, rgb24ToUV_half_c: BT.601 limited range, two
  * neighbouring pixels averaged into one chroma sample, every source row its own chroma row) feeding the scaler's
  * 16-bit horizontal pass.  Without a scale the conversion is a pass of its own behind the crops.
- * Source frames are ONE plane of in_w * 3 bytes a row; in_w (after a crop: its width) must be even.
+ * Source frames are ONE plane of in_w * 3 bytes a row; in_w (after a crop: its width) must be even unless the chain
+ * widens the picture (chroma is then read per pixel: rgb24ToUV_c).
+ * in_fmt = TTS_FMT_BGR24, TTS_FMT_RGBA, TTS_FMT_BGRA: the same arithmetic on the other byte orders (input.c bgr24ToY_c
+ * & co., and the 32-bit readers, whose extra fractional bits are all zero; alpha is ignored); 4 bytes a pixel for the last two.
  */
 int tts_parse_vf_fmt(const char *vf, int iw, int ih, int in_fmt, tts_geom *out);
 

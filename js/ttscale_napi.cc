@@ -55,6 +55,9 @@ bool get_in_fmt(napi_env env, napi_callback_info info, size_t index, int &in_fmt
     std::string f;
     if (!get_string(env, argv[index], f)) return false;
     if (f == "rgb24") in_fmt = TTS_FMT_RGB24;
+    else if (f == "bgr24") in_fmt = TTS_FMT_BGR24;
+    else if (f == "rgba") in_fmt = TTS_FMT_RGBA;
+    else if (f == "bgra") in_fmt = TTS_FMT_BGRA;
     else if (f != "yuv420p") return false;
     return true;
 }

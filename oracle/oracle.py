@@ -107,7 +107,7 @@ def out_frame_bytes(c):
 
 
 def in_frame_bytes(c):
-    return c.in_w * c.in_h * 3 if c.in_fmt else frame_bytes(c.in_w, c.in_h)
+    return c.in_w * c.in_h * (4 if c.in_fmt >= 3 else 3) if c.in_fmt else frame_bytes(c.in_w, c.in_h)
 
 
 def run_chain(geom, frames):
@@ -121,7 +121,7 @@ def run_chain(geom, frames):
         ocw, och = (ow + 1) // 2, (oh + 1) // 2
         for i in range(frames.shape[0]):
             d = out[i].ctypes.data
-            rc = lib().tto_run_chain_rgbin(ctypes.byref(c), frames[i].ctypes.data, c.in_w * 3, d, d + ow * oh, d + ow * oh + ocw * och, ow, ocw, ocw)
+            rc = lib().tto_run_chain_rgbin(ctypes.byref(c), frames[i].ctypes.data, c.in_w * (4 if c.in_fmt >= 3 else 3), d, d + ow * oh, d + ow * oh + ocw * och, ow, ocw, ocw)
             assert rc == 0, rc
         return out
     out = np.empty((frames.shape[0], out_frame_bytes(c)), np.uint8)

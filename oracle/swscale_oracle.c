@@ -693,6 +693,18 @@ static void tto_vscale_plane(const int16_t *tmp, int dw, const tto_filter *vf, u
 int tto_sws_rgb24_to_yuv420(const uint8_t *src, int sstride, int sw, int sh,
                             uint8_t *dy, uint8_t *du, uint8_t *dv, int dys, int dus, int dvs, int dw, int dh, int alg)
 {
+    return tto_sws_packed_to_yuv420(TTO_FMT_RGB24, src, sstride, sw, sh, dy, du, dv, dys, dus, dvs, dw, dh, alg);
+}
+
+/* The same for the four packed layouts: input.c bgr24ToY_c & co. are rgb24's with the channels read from the other
+ * end; the 32-bit readers (rgb16_32ToY_c_template for rgba / bgra) carry 8 more fractional bits through the same
+ * sum -- (coef << 8) * channel + (rnd << 8) >> (S - 6 + 8) -- all of them zero, so the 14-bit samples are the
+ * same; alpha is not read.  RECALLED, UNVERIFIED like the rest of this block. */
+int tto_sws_packed_to_yuv420(int fmt, const uint8_t *src, int sstride, int sw, int sh,
+                             uint8_t *dy, uint8_t *du, uint8_t *dv, int dys, int dus, int dvs, int dw, int dh, int alg)
+{
+    const int pb = (fmt == TTO_FMT_RGBA || fmt == TTO_FMT_BGRA) ? 4 : 3;    /* bytes a pixel */
+    const int ro = (fmt == TTO_FMT_BGR24 || fmt == TTO_FMT_BGRA) ? 2 : 0, bo = 2 - ro;   /* where red and blue sit */
     const int S = 15;                                                      /* RGB2YUV_SHIFT */
     const int ry = (int)(0.299 * 219 / 255 * (1 << S) + 0.5), gy = (int)(0.587 * 219 / 255 * (1 << S) + 0.5), by = (int)(0.114 * 219 / 255 * (1 << S) + 0.5);
     const int ru = -(int)(0.169 * 224 / 255 * (1 << S) + 0.5), gu = -(int)(0.331 * 224 / 255 * (1 << S) + 0.5), bu = (int)(0.500 * 224 / 255 * (1 << S) + 0.5);
@@ -701,7 +713,7 @@ int tto_sws_rgb24_to_yuv420(const uint8_t *src, int sstride, int sw, int sh,
     const int csw = half ? (sw + 1) >> 1 : sw, cdw = (dw + 1) >> 1, cdh = (dh + 1) >> 1;
     tto_filter lh, lv, ch, cv;
     int16_t *y14, *u14, *v14, *ty, *tu, *tv;
-    if (sw < 1 || sh < 1 || dw < 1 || dh < 1) return -1;
+    if (fmt < TTO_FMT_RGB24 || fmt > TTO_FMT_BGRA || sw < 1 || sh < 1 || dw < 1 || dh < 1) return -1;
     if (half && (sw < 2 || (sw & 1))) return -1;                           /* (the pair reader would run past an odd row's end) */
     if (tto_filter_init(&lh, sw, dw, 1 << 14, alg) || tto_filter_init(&lv, sh, dh, 1 << 12, alg) ||
         tto_filter_init(&ch, csw, cdw, 1 << 14, alg) || tto_filter_init(&cv, sh, cdh, 1 << 12, alg)) return -1;
@@ -711,16 +723,17 @@ int tto_sws_rgb24_to_yuv420(const uint8_t *src, int sstride, int sw, int sh,
     for (int y = 0; y < sh; y++) {
         const uint8_t *s = src + (size_t)y * sstride;
         for (int i = 0; i < sw; i++) {
-            const int r = s[3 * i], g = s[3 * i + 1], b = s[3 * i + 2];
+            const int r = s[pb * i + ro], g = s[pb * i + 1], b = s[pb * i + bo];
             y14[(size_t)y * sw + i] = (int16_t)((ry * r + gy * g + by * b + (32 << (S - 1)) + (1 << (S - 7))) >> (S - 6));
         }
         for (int i = 0; i < csw; i++) {
             if (half) {                                                    /* rgb24ToUV_half_c */
-                const int r = s[6 * i] + s[6 * i + 3], g = s[6 * i + 1] + s[6 * i + 4], b = s[6 * i + 2] + s[6 * i + 5];
+                const uint8_t *q = s + 2 * pb * i;
+                const int r = q[ro] + q[pb + ro], g = q[1] + q[pb + 1], b = q[bo] + q[pb + bo];
                 u14[(size_t)y * csw + i] = (int16_t)((ru * r + gu * g + bu * b + (256 << S) + (1 << (S - 6))) >> (S - 5));
                 v14[(size_t)y * csw + i] = (int16_t)((rv * r + gv * g + bv * b + (256 << S) + (1 << (S - 6))) >> (S - 5));
             } else {                                                       /* rgb24ToUV_c */
-                const int r = s[3 * i], g = s[3 * i + 1], b = s[3 * i + 2];
+                const int r = s[pb * i + ro], g = s[pb * i + 1], b = s[pb * i + bo];
                 u14[(size_t)y * csw + i] = (int16_t)((ru * r + gu * g + bu * b + (256 << (S - 1)) + (1 << (S - 7))) >> (S - 6));
                 v14[(size_t)y * csw + i] = (int16_t)((rv * r + gv * g + bv * b + (256 << (S - 1)) + (1 << (S - 7))) >> (S - 6));
             }
@@ -749,8 +762,9 @@ int tto_run_chain_rgbin(const tto_chain *c, const uint8_t *src, int sstride,
     uint8_t *buf = (uint8_t *)malloc((size_t)vw * vh + 2 * (size_t)cw * chh);
     uint8_t *py = buf, *pu = buf + (size_t)vw * vh, *pv = pu + (size_t)cw * chh;
     tto_chain rest = *c;
-    int rc = tto_sws_rgb24_to_yuv420(src + (size_t)c->pre_y * sstride + (size_t)c->pre_x * 3, sstride, c->pre_w, c->pre_h,
-                                     py, pu, pv, vw, cw, cw, vw, vh, c->alg);
+    const int pb = (c->in_fmt == TTO_FMT_RGBA || c->in_fmt == TTO_FMT_BGRA) ? 4 : 3;
+    int rc = tto_sws_packed_to_yuv420(c->in_fmt, src + (size_t)c->pre_y * sstride + (size_t)c->pre_x * pb, sstride, c->pre_w, c->pre_h,
+                                      py, pu, pv, vw, cw, cw, vw, vh, c->alg);
     if (!rc) {
         /* what is left of the chain sees a yuv420p frame of the scaled size */
         rest.in_fmt = 0; rest.in_w = vw; rest.in_h = vh; rest.pre_x = rest.pre_y = 0; rest.pre_w = vw; rest.pre_h = vh; rest.do_scale = 0;

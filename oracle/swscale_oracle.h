@@ -48,7 +48,7 @@ typedef struct tto_chain {
     int out_fmt;                      /* TTO_FMT_*: packed RGB written by the chain's swscale pass */
     int rgb_stage;                    /* 0 none, 1 inside the chain's scale (crop / pad then work on RGB), 2 a pass of its own at the end */
     int fill_rgb;                     /* pad colour 0xRRGGBB for pads that work on RGB */
-    int in_fmt;                       /* TTO_FMT_YUV420P, or TTO_FMT_RGB24: the chain's swscale pass reads packed rgb24 */
+    int in_fmt;                       /* TTO_FMT_YUV420P, or a packed layout (rgb24, bgr24, rgba, bgra): the chain's swscale pass reads packed RGB */
 } tto_chain;
 
 enum { TTO_FMT_YUV420P = 0, TTO_FMT_RGB24 = 1, TTO_FMT_BGR24 = 2, TTO_FMT_RGBA = 3, TTO_FMT_BGRA = 4 };
@@ -92,6 +92,8 @@ int tto_rgb_in_half_chroma(int sw, int dw);
  * libswscale/input.c rgb24ToY_c / rgb24ToUV_half_c or rgb24ToUV_c (14-bit samples), swscale.c hScale16To15_c,
  * output.c yuv2planeX_8_c.  Chroma: ceil(sw / 2) x sh samples (sw even) when the width does not grow, else
  * sw x sh, scaled to ceil(dw / 2) x ceil(dh / 2). */
+int tto_sws_packed_to_yuv420(int fmt, const uint8_t *src, int sstride, int sw, int sh,
+                             uint8_t *dy, uint8_t *du, uint8_t *dv, int dys, int dus, int dvs, int dw, int dh, int alg);
 int tto_sws_rgb24_to_yuv420(const uint8_t *src, int sstride, int sw, int sh,
                             uint8_t *dy, uint8_t *du, uint8_t *dv, int dys, int dus, int dvs, int dw, int dh, int alg);
 

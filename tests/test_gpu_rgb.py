@@ -480,6 +480,51 @@ def rgb_frames(pattern, w, h, n):
     return out.reshape(n, -1)
 
 
+def repack(rgb, w, h, fmt):
+    """rgb24 frames [n, h * w * 3] in another packed layout (alpha: a byte pattern nothing may depend on)."""
+    n = rgb.shape[0]
+    px = rgb.reshape(n, h, w, 3)
+    if fmt == "rgb24":
+        return rgb
+    if fmt == "bgr24":
+        return np.ascontiguousarray(px[..., ::-1]).reshape(n, -1)
+    out = np.empty((n, h, w, 4), np.uint8)
+    out[..., :3] = px if fmt == "rgba" else px[..., ::-1]
+    out[..., 3] = (np.arange(w, dtype=np.uint32) * 37 + 11).astype(np.uint8)
+    return out.reshape(n, -1)
+
+
+PACKED_IN_CASES = [
+    ("format=yuv420p", 640, 360),                      # conversion alone: the streaming walk for the 3-byte layouts
+    (PORTRAIT, 1280, 720),                             # an enlargement: the strip walk (bgr24), the tiled kernel (4-byte pixels)
+    ("scale=640:360", 1280, 720),                      # a shrink: the source-row walk (bgr24)
+    (THUMB + ",format=yuv420p", 720, 1280),            # the reference's thumbnail chain, pad on yuv420p behind the scale
+    ("crop=64:33:11:7,scale=128:96", 100, 60),         # a crop on the packed pixels at odd offsets
+    ("scale=96:54", 63, 36),                           # an odd source width, widened
+]
+
+
+@pytest.mark.parametrize("fmt", ["bgr24", "rgba", "bgra"])
+@pytest.mark.parametrize("vf,iw,ih", PACKED_IN_CASES)
+def test_packed_rgb_input_other_layouts(tts, oracle, vf, iw, ih, fmt):
+    """`-pix_fmt bgr24 | rgba | bgra` in front of `-i`: the oracle's bytes, and the bytes the rgb24 plan gives for the
+    same pixels repacked (alpha is not read)."""
+    import torch
+    plan = tts.Plan.from_vf(vf, iw, ih, in_fmt=fmt)
+    ref = tts.Plan.from_vf(vf, iw, ih, in_fmt="rgb24")
+    assert plan.in_bytes == iw * ih * (4 if fmt.endswith("a") else 3) and plan.kernel_name(0).startswith("rgbin")
+    if fmt == "bgr24":
+        assert plan.kernel_name(0) == ref.kernel_name(0), (plan.kernel_name(0), ref.kernel_name(0))   # (every walk takes the swapped layout)
+    for pat in ("random", "impulse"):
+        rgb = rgb_frames(pat, iw, ih, 3)
+        src = repack(rgb, iw, ih, fmt)
+        got = plan.run_batch(torch.from_numpy(src).cuda()).cpu().numpy()
+        want = oracle.run_chain(plan.geom, src)
+        bad = np.flatnonzero(got != want)
+        assert bad.size == 0, "%s %s %dx%d %s [%s]: %d bytes differ, first at %d" % (fmt, vf, iw, ih, pat, plan.kernel_name(0), bad.size, bad[0])
+        assert np.array_equal(got, ref.run_batch(torch.from_numpy(rgb).cuda()).cpu().numpy())
+
+
 @pytest.mark.parametrize("vf,iw,ih", RGBIN_CASES)
 def test_rgb24_input_matches_oracle(tts, oracle, vf, iw, ih):
     import torch

@@ -127,3 +127,22 @@ def test_range_step_known_answers(oracle):
     out = oracle.run_chain(g, frame[None])[0]
     y, u, v = out[:256], out[512:640], out[640:768]
     assert (y[0], y[255]) == (16, 235) and (u[0], v[-1]) == (16, 240)
+
+
+def test_oracle_packed_input_layouts_agree():
+    """bgr24 / rgba / bgra sources: the rgb24 bytes for the same pixels repacked (CPU only)."""
+    from oracle import oracle
+    iw, ih = 64, 36
+    rng = np.random.default_rng(5)
+    px = rng.integers(0, 256, (2, ih, iw, 3), dtype=np.uint8)
+
+    def geom(fmt):                # the fields oracle.chain_from reads, for `scale=48:26` on a 64x36 source
+        g = dict(in_w=iw, in_h=ih, pre_x=0, pre_y=0, pre_w=iw, pre_h=ih, do_scale=1, sc_w=48, sc_h=26, alg=0, crop_x=0, crop_y=0, crop_w=48, crop_h=26,
+                 do_pad=0, pad_x=0, pad_y=0, out_w=48, out_h=26, fill_y=16, fill_u=128, fill_v=128, out_range=0, out_fmt=0, rgb_stage=0, fill_rgb=0, in_fmt=fmt)
+        return g
+    want = oracle.run_chain(geom(1), px.reshape(2, -1))
+    assert np.array_equal(oracle.run_chain(geom(2), np.ascontiguousarray(px[..., ::-1]).reshape(2, -1)), want)
+    for fmt, order in ((3, slice(None)), (4, slice(None, None, -1))):
+        q = np.empty((2, ih, iw, 4), np.uint8)
+        q[..., :3] = px[..., order]; q[..., 3] = 99
+        assert np.array_equal(oracle.run_chain(geom(fmt), q.reshape(2, -1)), want)

@@ -54,6 +54,16 @@ CHAINS = [
     ("scale=w=720:h=1280", 480, 854, "yuv420p", "rgb24"),
     ("scale=320:568:flags=area", 1080, 1920, "yuv420p", "rgb24"),
     ("scale=96:54", 63, 36, "yuv420p", "rgb24"),
+    # the other packed layouts in (input.c bgr24ToY_c & co., the 32-bit readers), round 3
+    ("scale=w=720:h=1280", 480, 854, "yuv420p", "bgr24"),
+    ("scale=640:360", 1280, 720, "yuv420p", "rgba"),
+    ("format=yuv420p", 64, 48, "yuv420p", "bgra"),
+    # shrinks out of RGB (rgbin_shrink_kernel) and the 5-8 tap scales written as RGB (rgb_walk_kernel), round 3
+    ("scale=960:540", 1920, 1080, "yuv420p", "rgb24"),
+    ("scale=720:1280,format=rgb24", 1080, 1920, "rgb24"),
+    # RGB from a full-range link and through swscale's 1- / 2-line packed writers, round 3
+    (THUMB_REF + ",format=yuvj420p,format=rgb24", 720, 1280, "rgb24"),
+    ("scale=128:96:flags=bilinear,format=rgb24", 64, 48, "rgb24"),
 ]
 CHAINS = [c if len(c) == 5 else c + ("yuv420p",) for c in CHAINS]
 
@@ -68,7 +78,13 @@ def source_frames(pattern, iw, ih, n, in_fmt):
     for i in range(n):
         a, b, c = synth.split(y[i], 2 * iw, 2 * ih)
         out[i, :, :, 0] = a[::2, ::2]; out[i, :, :, 1] = b; out[i, :, :, 2] = c
-    return out.reshape(n, -1)
+    if in_fmt == "rgb24":
+        return out.reshape(n, -1)
+    if in_fmt == "bgr24":
+        return np.ascontiguousarray(out[..., ::-1]).reshape(n, -1)
+    four = np.full((n, ih, iw, 4), 255, np.uint8)              # rgba / bgra
+    four[..., :3] = out if in_fmt == "rgba" else out[..., ::-1]
+    return four.reshape(n, -1)
 
 
 def with_flags(chain, flags):
@@ -109,7 +125,7 @@ def diff_report(name, got, want):
 @needs_ffmpeg
 @pytest.mark.parametrize("chain,iw,ih,pix_fmt,in_fmt", CHAINS)
 def test_oracle_vs_ffmpeg(oracle, tts, tmp_path, chain, iw, ih, pix_fmt, in_fmt):
-    rgb = pix_fmt == "rgb24" or in_fmt == "rgb24"
+    rgb = pix_fmt == "rgb24" or in_fmt != "yuv420p"
     geom = tts.parse_vf(chain, iw, ih, in_fmt=in_fmt)
     for pattern in ("random", "limited", "zone", "impulse"):
         frames = source_frames(pattern, iw, ih, 2, in_fmt)
@@ -125,7 +141,7 @@ def test_oracle_vs_ffmpeg(oracle, tts, tmp_path, chain, iw, ih, pix_fmt, in_fmt)
 @pytest.mark.parametrize("chain,iw,ih,pix_fmt,in_fmt", CHAINS)
 def test_hip_vs_ffmpeg(tts, tmp_path, chain, iw, ih, pix_fmt, in_fmt):
     import torch
-    rgb = pix_fmt == "rgb24" or in_fmt == "rgb24"
+    rgb = pix_fmt == "rgb24" or in_fmt != "yuv420p"
     plan = tts.Plan.from_vf(chain, iw, ih, in_fmt=in_fmt)
     frames = source_frames("random", iw, ih, 2, in_fmt)
     ours = plan.run_batch(torch.from_numpy(frames).cuda()).cpu().numpy().ravel()

@@ -223,8 +223,8 @@ int check_geom(const tts_geom &g)
     if (g.pre_w < 1 || g.pre_h < 1 || g.pre_x < 0 || g.pre_y < 0 ||
         g.pre_x + g.pre_w > g.in_w || g.pre_y + g.pre_h > g.in_h) return TTS_ERR_INVALID_INPUT;
     const bool has_pre = g.pre_x || g.pre_y || g.pre_w != g.in_w || g.pre_h != g.in_h;
-    if (g.in_fmt != TTS_FMT_YUV420P && g.in_fmt != TTS_FMT_RGB24) return TTS_ERR_INVALID_INPUT;
-    if (g.in_fmt == TTS_FMT_RGB24) {
+    if (g.in_fmt < TTS_FMT_YUV420P || g.in_fmt > TTS_FMT_BGRA) return TTS_ERR_INVALID_INPUT;
+    if (g.in_fmt != TTS_FMT_YUV420P) {
         // a crop in front of the conversion works on RGB pixels (any offset); rgb24ToUV_half_c reads pixel pairs
         if (g.out_fmt != TTS_FMT_YUV420P || g.out_range != TTS_RANGE_KEEP || ((g.pre_w & 1) && rgb_in_half_chroma(g.pre_w, g.sc_w))) return TTS_ERR_UNSUPPORTED;
     } else if (has_pre && !(even(g.pre_x) && even(g.pre_y) && even(g.pre_w) && even(g.pre_h))) return TTS_ERR_INVALID_INPUT;

@@ -110,7 +110,7 @@ int tts_plan_create(const tts_geom *g, tts_plan **out)
     // tts_run_host_static's scratch: its device address is looked up here, at set-up, so that the entry point itself does no
     // first-call runtime work (a failure is kept for that call to report)
     { unsigned char *scratch_base = nullptr; (void)scratch_for_device(dev, &scratch_base); }
-    if (g->in_fmt == TTS_FMT_RGB24) {
+    if (g->in_fmt != TTS_FMT_YUV420P) {
         rc = tts::rgbin_plan_create(*g, &p->rgbin);            // (sets the error text itself)
         if (rc) { tts_plan_destroy(p); return rc; }
         *out = p;
@@ -181,7 +181,7 @@ int tts_plan_device(const tts_plan *p) { return p ? p->device : TTS_ERR_INVALID_
 size_t tts_plan_frame_bytes(const tts_plan *p, int which)
 {
     if (!p) return 0;
-    if (which == 0) return p->g.in_fmt == TTS_FMT_RGB24 ? size_t(p->g.in_w) * p->g.in_h * 3 : tts_frame_bytes(p->g.in_w, p->g.in_h);
+    if (which == 0) return p->g.in_fmt != TTS_FMT_YUV420P ? size_t(p->g.in_w) * p->g.in_h * tts::packed_pixel_bytes(p->g.in_fmt) : tts_frame_bytes(p->g.in_w, p->g.in_h);
     if (p->g.out_fmt == TTS_FMT_YUV420P) return tts_frame_bytes(p->g.out_w, p->g.out_h);
     return size_t(p->g.out_w) * p->g.out_h * (p->g.out_fmt >= TTS_FMT_RGBA ? 4 : 3);
 }
@@ -283,7 +283,7 @@ int run_batch_impl(const tts_plan *p, const void *src, size_t src_pitch, const i
     const tts_geom &g = p->g;
     if (p->rgbin) {
         // packed rgb24 in (one plane, rows sstride[0] bytes apart), packed or strided I420 out; the kernel covers the canvas
-        if (sstride[0] < g.in_w * 3 || dstride[0] < g.out_w || dstride[1] < ceil_shift(g.out_w, 1)) return TTS_ERR_INVALID_INPUT;
+        if (sstride[0] < g.in_w * tts::packed_pixel_bytes(g.in_fmt) || dstride[0] < g.out_w || dstride[1] < ceil_shift(g.out_w, 1)) return TTS_ERR_INVALID_INPUT;
         const size_t sbytes = size_t(sstride[0]) * g.in_h;
         const size_t dbytes = size_t(dstride[0]) * g.out_h + 2 * size_t(dstride[1]) * ceil_shift(g.out_h, 1);
         if (src_pitch < sbytes || dst_pitch < dbytes) return TTS_ERR_INVALID_INPUT;
@@ -384,7 +384,7 @@ int run_rgbin_frames(const tts_plan *p, const tts_frame *src, const tts_frame *d
     for (int i = 0; i < n_frames; ++i) {
         if (src[i].mem != TTS_MEM_DEVICE || dst[i].mem != TTS_MEM_DEVICE) { g_last_error = "rgb24 in: device frames only (host buffers: tts_run_host)"; return TTS_ERR_UNSUPPORTED; }
         if (src[i].width != g.in_w || src[i].height != g.in_h || dst[i].width != g.out_w || dst[i].height != g.out_h) return TTS_ERR_INVALID_INPUT;
-        if (!src[i].plane[0] || src[i].stride[0] < g.in_w * 3) return TTS_ERR_INVALID_INPUT;
+        if (!src[i].plane[0] || src[i].stride[0] < g.in_w * tts::packed_pixel_bytes(g.in_fmt)) return TTS_ERR_INVALID_INPUT;
         for (int k = 0; k < 3; ++k)
             if (!dst[i].plane[k] || dst[i].stride[k] < ceil_shift(g.out_w, k ? 1 : 0)) return TTS_ERR_INVALID_INPUT;
         if (dst[i].stride[1] != dst[i].stride[2]) return TTS_ERR_UNSUPPORTED;
@@ -402,7 +402,7 @@ int run_rgbin_frames(const tts_plan *p, const tts_frame *src, const tts_frame *d
                 const tts_frame &sf = src[f0 + n], &df = dst[f0 + n];
                 if (n && (sf.stride[0] != src[f0].stride[0] || df.stride[0] != dst[f0].stride[0] || df.stride[1] != dst[f0].stride[1])) break;
                 const uintptr_t a = std::min(smin, uintptr_t(sf.plane[0]));
-                const uintptr_t b = std::max(smax, uintptr_t(sf.plane[0]) + size_t(g.in_h - 1) * size_t(sf.stride[0]) + size_t(g.in_w) * 3);
+                const uintptr_t b = std::max(smax, uintptr_t(sf.plane[0]) + size_t(g.in_h - 1) * size_t(sf.stride[0]) + size_t(g.in_w) * tts::packed_pixel_bytes(g.in_fmt));
                 uintptr_t c2 = dmin, e = dmax;
                 for (int k = k0; k < k1; ++k) {
                     const int ci = k ? 1 : 0;
@@ -444,7 +444,7 @@ int tts_run_batch(const tts_plan *p, const void *src, size_t src_pitch, void *ds
 {
     if (!p) return TTS_ERR_INVALID_INPUT;
     const int bpp = p->g.out_fmt == TTS_FMT_YUV420P ? 1 : p->g.out_fmt >= TTS_FMT_RGBA ? 4 : 3;
-    const int sstride[2] = {p->g.in_fmt == TTS_FMT_RGB24 ? p->g.in_w * 3 : p->g.in_w, ceil_shift(p->g.in_w, 1)}, dstride[2] = {p->g.out_w * bpp, ceil_shift(p->g.out_w, 1)};
+    const int sstride[2] = {p->g.in_fmt != TTS_FMT_YUV420P ? p->g.in_w * tts::packed_pixel_bytes(p->g.in_fmt) : p->g.in_w, ceil_shift(p->g.in_w, 1)}, dstride[2] = {p->g.out_w * bpp, ceil_shift(p->g.out_w, 1)};
     return run_batch_impl(p, src, src_pitch, sstride, dst, dst_pitch, dstride, n_frames, hip_stream);
 }
 

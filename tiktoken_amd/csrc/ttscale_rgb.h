@@ -80,14 +80,19 @@ const char *rgbin_shrink_name(const RgbInShrinkPlan *p);
 int rgbin_shrink_launch(const RgbInShrinkPlan *p, const uint8_t *src, uint8_t *dst, int n, int src_stride, const int dst_stride[2],
                         const FrameAddr &addr, hipStream_t st);
 
+inline int  packed_pixel_bytes(int fmt) { return fmt >= TTS_FMT_RGBA ? 4 : 3; }
+inline bool packed_blue_first(int fmt) { return fmt == TTS_FMT_BGR24 || fmt == TTS_FMT_BGRA; }
+
 // utils.c fill_rgb2yuv_table(): the default matrix's table (BT.601 limited range), 15 fractional bits: ry gy by, ru gu bu, rv gv bv
-inline void rgbin_coefficients(int coef[9])
+// -- by BYTE of a pixel: blue_first (bgr24, bgra) swaps the first and the third of each row, and every kernel reads
+// bytes 0, 1, 2 of a pixel as it does for rgb24
+inline void rgbin_coefficients(int coef[9], bool blue_first = false)
 {
     const double S = 32768.0;
     const int c[9] = {int(0.299 * 219 / 255 * S + 0.5), int(0.587 * 219 / 255 * S + 0.5), int(0.114 * 219 / 255 * S + 0.5),
                       -int(0.169 * 224 / 255 * S + 0.5), -int(0.331 * 224 / 255 * S + 0.5), int(0.500 * 224 / 255 * S + 0.5),
                       int(0.500 * 224 / 255 * S + 0.5), -int(0.419 * 224 / 255 * S + 0.5), -int(0.081 * 224 / 255 * S + 0.5)};
-    for (int i = 0; i < 9; ++i) coef[i] = c[i];
+    for (int i = 0; i < 9; ++i) coef[i] = c[blue_first ? 3 * (i / 3) + 2 - i % 3 : i];
 }
 
 }  // namespace tts

@@ -969,6 +969,7 @@ struct RgbInArgs {
     int32_t coef[9];                   // ry gy by, ru gu bu, rv gv bv
     int32_t  only_plane;               // >= 0: the launch produces this destination plane alone
     int32_t  chr_half;                 // 1: chroma samples are pixel-pair sums (rgb24ToUV_half_c), 0: one per pixel (rgb24ToUV_c); filter.h rgb_in_half_chroma()
+    int32_t  pb;                       // bytes a source pixel: 3 (rgb24, bgr24) or 4 (rgba, bgra: the fourth is ignored); coef is by byte of a pixel
     uint32_t src_origin, src_extent;   // bytes from a frame's first byte to the pre-cropped origin / to one past its last byte
     FrameAddr addr;
 };
@@ -1013,13 +1014,13 @@ __global__ __launch_bounds__(kBlock) void rgbin_generic_kernel(const RgbInArgs a
             for (int k = 0; k < ht; ++k) {
                 int s14;
                 if (ci == 0) {
-                    const uint8_t *q = row + 3 * (hp + k);
+                    const uint8_t *q = row + a.pb * (hp + k);
                     s14 = (cr * q[0] + cg * q[1] + cb * q[2] + (32 << 14) + (1 << 8)) >> 9;
                 } else if (a.chr_half) {
-                    const uint8_t *q = row + 6 * (hp + k);
-                    s14 = (cr * (q[0] + q[3]) + cg * (q[1] + q[4]) + cb * (q[2] + q[5]) + (256 << 15) + (1 << 9)) >> 10;
+                    const uint8_t *q = row + 2 * a.pb * (hp + k), *q2 = q + a.pb;
+                    s14 = (cr * (q[0] + q2[0]) + cg * (q[1] + q2[1]) + cb * (q[2] + q2[2]) + (256 << 15) + (1 << 9)) >> 10;
                 } else {
-                    const uint8_t *q = row + 3 * (hp + k);
+                    const uint8_t *q = row + a.pb * (hp + k);
                     s14 = (cr * q[0] + cg * q[1] + cb * q[2] + (256 << 14) + (1 << 8)) >> 9;
                 }
                 acc += s14 * int(hc[k]);
@@ -1080,7 +1081,7 @@ __global__ __launch_bounds__(kBlock) void rgbin_tile_kernel(const RgbInTileArgs 
     uint8_t *raw = reinterpret_cast<uint8_t *>(rgbin_lds) + ((size_t(sym) * (sxm + 64) + size_t(t.th[ci]) * (vt + 1)) * 2 + 3 & ~size_t(3));   // [sy_max][raw_w] source bytes
     const int wave = __builtin_amdgcn_readfirstlane(int(threadIdx.x >> 6)), lane = int(threadIdx.x & 63);
     const int waves = int(blockDim.x >> 6);
-    const int nb = ci && a.chr_half ? 6 : 3;                        // bytes per source sample: a pixel, a pixel pair
+    const int nb = ci && a.chr_half ? 2 * a.pb : a.pb;              // bytes per source sample: a pixel, a pixel pair
     const int bias = ci ? (256 << 14) + (1 << 8) : (32 << 14) + (1 << 8);   // rgb24ToUV_c / rgb24ToY_c
     int sxlo = 0, nsx = 0, sylo = 0, nsy = 0;
     if (any) {
@@ -1121,8 +1122,8 @@ __global__ __launch_bounds__(kBlock) void rgbin_tile_kernel(const RgbInTileArgs 
             const uint8_t *q0 = raw + r * raww + int(reinterpret_cast<uintptr_t>(g0) & 3u);
             for (int c = lane; c < nsx; c += 64) {
                 const uint8_t *q = q0 + nb * c;
-                const int v = nb == 3 ? (cr * q[0] + cg * q[1] + cb * q[2] + bias) >> 9
-                                      : (cr * (q[0] + q[3]) + cg * (q[1] + q[4]) + cb * (q[2] + q[5]) + (256 << 15) + (1 << 9)) >> 10;
+                const int v = nb == a.pb ? (cr * q[0] + cg * q[1] + cb * q[2] + bias) >> 9
+                                         : (cr * (q[0] + q[a.pb]) + cg * (q[1] + q[a.pb + 1]) + cb * (q[2] + q[a.pb + 2]) + (256 << 15) + (1 << 9)) >> 10;
                 s14[r * sxm + c] = int16_t(v);
             }
         }
@@ -1969,6 +1970,8 @@ namespace tts {
 struct RgbInPlan {
     tts_geom g{};
     bool half = true;                  // chroma read as pixel-pair sums (no horizontal enlargement), else one sample per pixel
+    int pb = 3;                        // bytes a source pixel (rgba, bgra: 4 -- the general kernels only)
+    bool blue_first = false;           // bgr24, bgra: the coefficient table is swapped, the kernels read bytes 0, 1, 2 as ever
     AxisFilter lh, lv, ch, cv;
     int32_t *d_pos[4] = {nullptr, nullptr, nullptr, nullptr};
     int16_t *d_taps[4] = {nullptr, nullptr, nullptr, nullptr};
@@ -2030,14 +2033,17 @@ int rgbin_plan_create(const tts_geom &g, RgbInPlan **out)
 {
     *out = nullptr;
     const bool half = rgb_in_half_chroma(g.pre_w, g.sc_w);           // sws_init_context()'s chrSrcHSubSample for this context
-    if (g.in_fmt != TTS_FMT_RGB24 || g.out_fmt != TTS_FMT_YUV420P || g.out_range != TTS_RANGE_KEEP || (half && (g.pre_w & 1))) {
-        set_last_error("rgb24 in: the chain must hand out yuv420p (no range step) and, unless it widens the picture, read an even width");
+    if (g.in_fmt == TTS_FMT_YUV420P || g.out_fmt != TTS_FMT_YUV420P || g.out_range != TTS_RANGE_KEEP || (half && (g.pre_w & 1))) {
+        set_last_error("packed RGB in: the chain must hand out yuv420p (no range step) and, unless it widens the picture, read an even width");
         return TTS_ERR_UNSUPPORTED;
     }
     RgbInPlan *p = new (std::nothrow) RgbInPlan();
     if (!p) return TTS_ERR_INITIALIZATION_FAILED;
     p->g = g;
     p->half = half;
+    p->pb = packed_pixel_bytes(g.in_fmt);
+    p->blue_first = packed_blue_first(g.in_fmt);
+    const bool three = p->pb == 3;         // the walks read 3-byte pixels; 4-byte sources run the tiled / general kernels
     int rc = TTS_OK;
     if (!build_axis_filter(g.pre_w, g.sc_w, 1 << 14, g.alg, p->lh) || !build_axis_filter(g.pre_h, g.sc_h, 1 << 12, g.alg, p->lv) ||
         !build_axis_filter(half ? g.pre_w / 2 : g.pre_w, (g.sc_w + 1) >> 1, 1 << 14, g.alg, p->ch) || !build_axis_filter(g.pre_h, (g.sc_h + 1) >> 1, 1 << 12, g.alg, p->cv)) {
@@ -2051,17 +2057,17 @@ int rgbin_plan_create(const tts_geom &g, RgbInPlan **out)
         const RgbInRect r0 = rgbin_rect(g, 0), r1 = rgbin_rect(g, 1);
         for (size_t budget : {size_t(32768), size_t(65536)})        // (64 KiB: the most a workgroup gets without opting in)
             if (!p->tiled)
-                p->tiled = rgbin_tile_shape(r0, p->lh, p->lv, 3, budget, p->th[0], p->sx_max[0], p->sy_max[0]) &&
-                           rgbin_tile_shape(r1, p->ch, p->cv, half ? 6 : 3, budget, p->th[1], p->sx_max[1], p->sy_max[1]);
+                p->tiled = rgbin_tile_shape(r0, p->lh, p->lv, p->pb, budget, p->th[0], p->sx_max[0], p->sy_max[0]) &&
+                           rgbin_tile_shape(r1, p->ch, p->cv, half ? 2 * p->pb : p->pb, budget, p->th[1], p->sx_max[1], p->sy_max[1]);
         if (p->tiled) {
             p->tiles_y[0] = (r0.canvas_h + p->th[0] - 1) / p->th[0]; p->tiles_y[1] = (r1.canvas_h + p->th[1] - 1) / p->th[1];
             const AxisFilter *vf[2] = {&p->lv, &p->cv};
-            for (int k = 0; k < 2; ++k) p->lds_bytes = std::max(p->lds_bytes, rgbin_tile_lds(p->sy_max[k], p->sx_max[k], p->th[k], vf[k]->size, k && half ? 6 : 3));
+            for (int k = 0; k < 2; ++k) p->lds_bytes = std::max(p->lds_bytes, rgbin_tile_lds(p->sy_max[k], p->sx_max[k], p->th[k], vf[k]->size, k && half ? 2 * p->pb : p->pb));
         }
     }
     // The conversion alone (nothing in the chain resizes, crops or pads): the streaming walk.  Its arithmetic has the
     // one-tap filters folded in, so they are checked to be exactly that: position i, the full weight.
-    if (!rc && !std::getenv("TTS_FORCE_GENERIC") && !(std::getenv("TTS_NO_RGBIN_WALK") && std::atoi(std::getenv("TTS_NO_RGBIN_WALK")))) {
+    if (!rc && three && !std::getenv("TTS_FORCE_GENERIC") && !(std::getenv("TTS_NO_RGBIN_WALK") && std::atoi(std::getenv("TTS_NO_RGBIN_WALK")))) {
         auto identity = [](const AxisFilter &f, int one) {
             if (f.size != 1) return false;
             for (size_t i = 0; i < f.pos.size(); ++i) if (f.pos[i] != int(i) || f.taps[i] != one) return false;
@@ -2086,7 +2092,7 @@ int rgbin_plan_create(const tts_geom &g, RgbInPlan **out)
     }
     // Horizontal enlargements (full-width chroma; <= 4 luma taps per axis, <= 8 chroma taps per axis): the strip walk on
     // 16-bit samples, if every wave's runs of source pixels fit what its 64 lanes convert per row
-    if (!rc && !p->walk && !std::getenv("TTS_FORCE_GENERIC") && !(std::getenv("TTS_NO_RGBIN_STRIP") && std::atoi(std::getenv("TTS_NO_RGBIN_STRIP")))) {
+    if (!rc && three && !p->walk && !std::getenv("TTS_FORCE_GENERIC") && !(std::getenv("TTS_NO_RGBIN_STRIP") && std::atoi(std::getenv("TTS_NO_RGBIN_STRIP")))) {
         auto monotone = [](const std::vector<int32_t> &v) { for (size_t i = 1; i < v.size(); ++i) if (v[i] < v[i - 1]) return false; return true; };
         const int lht = p->lh.size, cht = p->ch.size, lvt = p->lv.size, cvt = p->cv.size;
         bool ok = !half && !(g.pre_w & 1) && !g.do_pad && g.out_w == g.crop_w && g.out_h == g.crop_h && g.out_w % 8 == 0 && g.out_w >= 64 && lht <= 4 && cht <= 8 && lvt <= 4 && cvt <= 8 &&
@@ -2183,9 +2189,9 @@ int rgbin_plan_create(const tts_geom &g, RgbInPlan **out)
             }
         }
     }
-    if (!rc && !p->walk && !p->strip) {
+    if (!rc && three && !p->walk && !p->strip) {
         int coef[9];
-        rgbin_coefficients(coef);
+        rgbin_coefficients(coef, p->blue_first);
         p->shrink = rgbin_shrink_create(g, p->lh, p->lv, p->ch, p->cv, coef);
     }
     if (p->shrink) std::snprintf(p->name, sizeof p->name, "%s", rgbin_shrink_name(p->shrink));
@@ -2227,11 +2233,12 @@ int rgbin_launch(const RgbInPlan *p, const uint8_t *src, uint8_t *dst, int n, in
     a.src_stride = src_stride;
     a.only_plane = only_plane;
     a.chr_half = p->half ? 1 : 0;
-    a.src_origin = uint32_t(g.pre_y) * uint32_t(src_stride) + uint32_t(g.pre_x) * 3u;
-    a.src_extent = uint32_t(size_t(g.in_h - 1) * size_t(src_stride) + size_t(g.in_w) * 3);
+    a.pb = p->pb;
+    a.src_origin = uint32_t(g.pre_y) * uint32_t(src_stride) + uint32_t(g.pre_x) * uint32_t(p->pb);
+    a.src_extent = uint32_t(size_t(g.in_h - 1) * size_t(src_stride) + size_t(g.in_w) * size_t(p->pb));
     a.fill[0] = g.fill_y; a.fill[1] = g.fill_u; a.fill[2] = g.fill_v;
     int coef[9];
-    rgbin_coefficients(coef);
+    rgbin_coefficients(coef, p->blue_first);
     for (int i = 0; i < 9; ++i) a.coef[i] = coef[i];
     a.addr = addr;
     int rc = TTS_OK;
@@ -2312,7 +2319,7 @@ int rgbin_launch(const RgbInPlan *p, const uint8_t *src, uint8_t *dst, int n, in
             RgbInTileArgs t{};
             t.g = a;
             for (int k = 0; k < 2; ++k) { t.th[k] = p->th[k]; t.sx_max[k] = p->sx_max[k]; t.sy_max[k] = p->sy_max[k]; t.tiles_y[k] = p->tiles_y[k]; }
-            for (int k = 0; k < 2; ++k) t.raw_w[k] = rgbin_raw_w(p->sx_max[k], k && p->half ? 6 : 3);
+            for (int k = 0; k < 2; ++k) t.raw_w[k] = rgbin_raw_w(p->sx_max[k], k && p->half ? 2 * p->pb : p->pb);
             const bool t8 = std::max(std::max(a.lht, a.lvt), std::max(a.cht, a.cvt)) <= 8;
             rc = launch_rgb("rgbin_tile_kernel", t8 ? rgbin_tile_kernel<8> : rgbin_tile_kernel<0>,
                             dim3((g.out_w + 63) / 64, std::max(p->tiles_y[0], p->tiles_y[1]), nf * 3), dim3(kBlock), p->lds_bytes, st, t);

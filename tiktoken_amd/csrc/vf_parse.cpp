@@ -261,7 +261,7 @@ int parse_alg(const std::string &flags, int &alg)
 int parse_vf(const char *vf, int iw, int ih, tts_geom &g, std::string &err, int in_fmt)
 {
     if (!vf || iw < 1 || ih < 1) { err = "bad arguments"; return TTS_ERR_INVALID_INPUT; }
-    if (in_fmt != TTS_FMT_YUV420P && in_fmt != TTS_FMT_RGB24) { err = "input format: yuv420p or rgb24"; return TTS_ERR_UNSUPPORTED; }
+    if (in_fmt < TTS_FMT_YUV420P || in_fmt > TTS_FMT_BGRA) { err = "input format: yuv420p, rgb24, bgr24, rgba or bgra"; return TTS_ERR_UNSUPPORTED; }
     std::memset(&g, 0, sizeof(g));
     g.in_fmt = in_fmt;
     g.in_w = iw; g.in_h = ih;
@@ -304,10 +304,10 @@ int parse_vf(const char *vf, int iw, int ih, tts_geom &g, std::string &err, int 
     // chroma subsampling of the link a filter sits on: 2 on yuv420p, 1 once the pixels are RGB
     // (rgb24 in: everything in front of the scale -- or, without one, the whole chain -- works on RGB pixels)
     auto grid = [&]() {
-        if (g.in_fmt == TTS_FMT_RGB24) return stage == kBeforeScale ? 1 : 2;
+        if (g.in_fmt != TTS_FMT_YUV420P) return stage == kBeforeScale ? 1 : 2;
         return g.rgb_stage == TTS_RGB_AT_SCALE && stage != kBeforeScale ? 1 : 2;
     };
-    if (g.in_fmt == TTS_FMT_RGB24 && g.out_fmt != TTS_FMT_YUV420P) { err = "rgb24 in and packed RGB out is not supported"; return TTS_ERR_UNSUPPORTED; }
+    if (g.in_fmt != TTS_FMT_YUV420P && g.out_fmt != TTS_FMT_YUV420P) { err = "packed RGB in and packed RGB out is not supported"; return TTS_ERR_UNSUPPORTED; }
 
     try {
         for (const std::string &raw : split(vf, ',')) {
@@ -431,9 +431,9 @@ int parse_vf(const char *vf, int iw, int ih, tts_geom &g, std::string &err, int 
                 if (y < 0 || y + ch > h) y = (h - ch) / 2;
                 if (grid() == 2) { w &= ~1; h &= ~1; x &= ~1; y &= ~1; }   // round down to the chroma grid (none on RGB)
                 if (!parse_color(o.get("color", "black"), g)) { err = "pad: unsupported colour"; return TTS_ERR_INVALID_FORMAT; }
-                if (stage == kBeforeScale && g.in_fmt == TTS_FMT_RGB24) {
+                if (stage == kBeforeScale && g.in_fmt != TTS_FMT_YUV420P) {
                     // the pad would run on RGB pixels and the conversion pass behind it would resample its border
-                    err = "rgb24 in: pad needs a scale in front of it"; return TTS_ERR_UNSUPPORTED;
+                    err = "packed RGB in: pad needs a scale in front of it"; return TTS_ERR_UNSUPPORTED;
                 }
                 if (stage == kBeforeScale) { g.pre_x = cx; g.pre_y = cy; g.pre_w = cw; g.pre_h = ch; g.sc_w = cw; g.sc_h = ch; cx = cy = 0; }
                 g.crop_x = cx; g.crop_y = cy; g.crop_w = cw; g.crop_h = ch;

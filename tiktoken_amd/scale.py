@@ -22,8 +22,8 @@ FMT = {"yuv420p": 0, "rgb24": 1, "bgr24": 2, "rgba": 3, "bgra": 4}
 
 
 def parse_vf(vf, iw, ih, in_fmt="yuv420p"):
-    """Resolve a filter chain for an iw x ih input -> Geom (raises TtsError).  in_fmt: "yuv420p", or "rgb24"
-    for a chain fed with packed RGB (`-pix_fmt rgb24 -i ...`)."""
+    """Resolve a filter chain for an iw x ih input -> Geom (raises TtsError).  in_fmt: "yuv420p", or "rgb24" /
+    "bgr24" / "rgba" / "bgra" for a chain fed with packed RGB (`-pix_fmt rgb24 -i ...`)."""
     g = Geom()
     rc = _lib.lib().tts_parse_vf_fmt(vf.encode(), iw, ih, FMT[in_fmt], ctypes.byref(g))
     check(rc, _lib.lib().tts_last_error().decode() if rc else "")
