@@ -393,7 +393,7 @@ __global__ __launch_bounds__(kBlock, TP == 3 ? 3 : 2) void rgb_walk_kernel(const
                 for (int i = 0; i < 8; ++i) {
                     int t = dot2(ringl[i][2], vl2, dot2(ringl[i][1], vl1, dot2(ringl[i][0], vl0, 1 << 18)));
                     if constexpr (TP == 4) t = dot2(ringl[i][3], vl3, t);
-                    P[i] = __mul24(t >> 19, cy);
+                    P[i] = t >> 19;
                 }
 #pragma unroll
                 for (int j = 0; j < 4; ++j) {
@@ -410,7 +410,7 @@ __global__ __launch_bounds__(kBlock, TP == 3 ? 3 : 2) void rgb_walk_kernel(const
                 if constexpr (BPP == 3) {
                     int v[24];
 #pragma unroll
-                    for (int i = 0; i < 8; ++i) { v[3 * i] = P[i] + CR[i / 2]; v[3 * i + 1] = P[i] + CG[i / 2]; v[3 * i + 2] = P[i] + CB[i / 2]; }
+                    for (int i = 0; i < 8; ++i) { v[3 * i] = __mul24(P[i], cy) + CR[i / 2]; v[3 * i + 1] = __mul24(P[i], cy) + CG[i / 2]; v[3 * i + 2] = __mul24(P[i], cy) + CB[i / 2]; }   // (v_mad_i32_i24: the product rides in the add)
                     uint32_t o[6];
 #pragma unroll
                     for (int q = 0; q < 6; ++q) o[q] = pack4<16>(v[4 * q], v[4 * q + 1], v[4 * q + 2], v[4 * q + 3]);      // (>> 16, clip, pack: two instructions)
@@ -433,7 +433,7 @@ __global__ __launch_bounds__(kBlock, TP == 3 ? 3 : 2) void rgb_walk_kernel(const
                     uint32_t o[8];
 #pragma unroll
                     for (int i = 0; i < 8; ++i)
-                        o[i] = pack4<16>(P[i] + CR[i / 2], P[i] + CG[i / 2], P[i] + CB[i / 2], 0x7fff0000);   // alpha 255
+                        o[i] = pack4<16>(__mul24(P[i], cy) + CR[i / 2], __mul24(P[i], cy) + CG[i / 2], __mul24(P[i], cy) + CB[i / 2], 0x7fff0000);   // alpha 255
                     if constexpr (XP) {
                         u32x4_t v1, v2;
                         walk_exchange4(xw, o, xr1, xr2, v1, v2);
