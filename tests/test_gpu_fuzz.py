@@ -226,6 +226,58 @@ def test_random_enlargements_packed_rgb_in(tts, oracle, seed):
     assert ran, "no case ran"
 
 
+def _repack(rgb, w, h, fmt):
+    n = rgb.shape[0]
+    px = rgb.reshape(n, h, w, 3)
+    if fmt == "rgb24":
+        return rgb
+    if fmt == "bgr24":
+        return np.ascontiguousarray(px[..., ::-1]).reshape(n, -1)
+    out = np.empty((n, h, w, 4), np.uint8)
+    out[..., :3] = px if fmt == "rgba" else px[..., ::-1]
+    out[..., 3] = 0x5A
+    return out.reshape(n, -1)
+
+
+@pytest.mark.parametrize("seed", range(int(__import__("os").environ.get("TTS_FUZZ_RGB_SEEDS", "12"))))
+def test_random_shrinks_packed_rgb_in(tts, oracle, seed):
+    """Packed RGB in (all four layouts), shrunk by 1x .. 2.3x across and 1x .. 6x down (independently): the source-row walk
+    where the geometry fits it (widths on and off its grid of 4 source pixels, output widths of 4 k and 4 k + 2, crops
+    behind the scale at odd rows), the tiled kernel elsewhere; batches whose waves straddle frames."""
+    import torch
+    rng = np.random.default_rng(21000 + seed)
+    ran = walk = 0
+    for _ in range(6):
+        iw = int(rng.choice([4, 4, 2])) * int(rng.integers(8, 360))
+        ih = int(rng.integers(12, 420))
+        ow = max(8, int(iw / rng.uniform(1.0, 2.3)))
+        if rng.random() < 0.85:
+            ow &= ~1
+        oh = max(4, int(ih / rng.uniform(1.0, 6.0)))
+        parts = ["scale=%d:%d%s" % (ow, oh, rng.choice(["", "", ":flags=bilinear", ":flags=area"]))]
+        if rng.random() < 0.3 and ow > 40 and oh > 16:
+            cw, chh = 2 * int(rng.integers(8, ow // 2 + 1)), int(rng.integers(8, oh + 1))
+            parts.append("crop=%d:%d:%d:%d" % (cw, chh, 2 * int(rng.integers(0, (ow - cw) // 2 + 1)), int(rng.integers(0, oh - chh + 1))))
+        fmt = str(rng.choice(["rgb24", "rgb24", "bgr24", "rgba", "bgra"]))
+        vf, n = ",".join(parts), int(rng.choice([1, 2, 5, 19]))
+        try:
+            plan = tts.Plan.from_vf(vf, iw, ih, in_fmt=fmt)
+        except tts.TtsError:
+            continue
+        walk += plan.kernel_name(0).startswith("rgbin_shrink")
+        src = _repack(rng.integers(0, 256, (n, iw * ih * 3), dtype=np.uint8), iw, ih, fmt)
+        m = min(n, 3)
+        want = oracle.run_chain(plan.geom, src[:m])
+        got = plan.run_batch(torch.from_numpy(src).cuda()).cpu().numpy()
+        bad = np.flatnonzero(got[:m].ravel() != want.ravel())
+        assert bad.size == 0, "%s %dx%d %s n=%d [%s]: %d bytes differ, first at %d" % (vf, iw, ih, fmt, n, plan.kernel_name(0), bad.size, bad[0])
+        if n > m:                                              # the rest of a batch: frame k against frame k alone
+            k = int(rng.integers(m, n))
+            assert np.array_equal(got[k], plan.run_batch(torch.from_numpy(src[k: k + 1]).cuda()).cpu().numpy()[0])
+        ran += 1
+    assert ran, "no case ran"
+
+
 @pytest.mark.parametrize("seed", range(int(__import__("os").environ.get("TTS_FUZZ_RGB_SEEDS", "12"))))
 def test_random_conversion_alone_both_directions(tts, oracle, seed):
     """No scale in the chain: yuv420p -> packed RGB and rgb24 -> yuv420p at random sizes -- widths on and off the grids
