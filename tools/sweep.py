@@ -17,6 +17,7 @@ CASES = {
     "720p": ("scale=1080:1920:force_original_aspect_ratio=increase,crop=1080:1920", 1280, 720, 3548880),
     "w1088": ("scale=1080:1920:force_original_aspect_ratio=increase,crop=1088:1920", 1920, 1080, 613 * 1080 * 3 // 2 + 1088 * 1920 * 3 // 2),
     "w1152": ("scale=1080:1920:force_original_aspect_ratio=increase,crop=1152:1920", 1920, 1080, 649 * 1080 * 3 // 2 + 1152 * 1920 * 3 // 2),
+    "w512": ("scale=1080:1920:force_original_aspect_ratio=increase,crop=512:1920", 1920, 1080, 291 * 1080 * 3 // 2 + 512 * 1920 * 3 // 2),     # 64 strips a row: a luma wave is one whole row, row after row
     "aligned": ("scale=1080:1920:force_original_aspect_ratio=increase,crop=1024:1920", 1920, 1080, 3882240),
     # the reference's own thumbnail chain (src/services/video.js:329-332) on a 1080p / portrait 1080p / 4K source
     "thumbref": ("scale=320x180:force_original_aspect_ratio=decrease,pad=320x180:-1:-1:color=black,format=yuv420p", 1920, 1080, 3110400 + 86400),
