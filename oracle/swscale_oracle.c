@@ -660,6 +660,8 @@ int tto_run_chain_rgb(const tto_chain *c, const uint8_t *sy, const uint8_t *su, 
  *   vertical pass of the planar path (yuv2planeX_8_c / yuv2plane1_8_c).
  * ------------------------------------------------------------------------------------------------ */
 int tto_rgb_in_half_chroma(int sw, int dw) { return (dw >> 1) <= (sw >> 1); }
+/* bgr24 -> yuv420p at the same size takes swscale's special converter (see tto_sws_packed_to_yuv420) */
+int tto_bgr24_special_converter(int fmt, int sw, int sh, int dw, int dh) { return fmt == TTO_FMT_BGR24 && sw == dw && sh == dh; }
 
 static void tto_hscale16_plane(const int16_t *src, int sw, int sh, const tto_filter *hf, int16_t *tmp)
 {
@@ -714,6 +716,30 @@ int tto_sws_packed_to_yuv420(int fmt, const uint8_t *src, int sstride, int sw, i
     tto_filter lh, lv, ch, cv;
     int16_t *y14, *u14, *v14, *ty, *tu, *tv;
     if (fmt < TTO_FMT_RGB24 || fmt > TTO_FMT_BGRA || sw < 1 || sh < 1 || dw < 1 || dh < 1) return -1;
+    if (tto_bgr24_special_converter(fmt, sw, sh, dw, dh)) {
+        /* swscale_unscaled.c ff_get_unscaled_swscale(), "bgr24toYV12": srcFormat == BGR24 && dstFormat == YUV420P &&
+         * !(flags & SWS_ACCURATE_RND) -> bgr24ToYv12Wrapper -> rgb2rgb_template.c ff_rgb24toyv12_c() (FFmpeg 4.3: "Chrominance
+         * data is only taken from every second line, others are ignored in the C version"): no 14-bit intermediates, no
+         * rounding term -- luma ((ry r + gy g + by b) >> 15) + 16 per pixel; chroma ((ru r + gu g + bu b) >> 15) + 128 from
+         * the LEFT pixel of each pair of an EVEN row (rows 0, 2, ...; the last row of an odd height is such a row), stored
+         * as bytes (the sums are unsigned there: the shift floors, the store keeps the low 8 bits).  chromWidth = width >> 1
+         * pairs a row: the last column of an odd width is never written, so an odd width is refused here (later FFmpeg
+         * sends odd widths down the general path instead).  Later FFmpeg (the 2x2 average in this function) differs:
+         * RECALLED for 4.3, UNVERIFIED like the rest of this block. */
+        if (sw & 1) return -1;
+        for (int y = 0; y < sh; y++) {
+            const uint8_t *s = src + (size_t)y * sstride;
+            for (int i = 0; i < sw; i++) {
+                const unsigned b = s[3 * i], g = s[3 * i + 1], r = s[3 * i + 2];
+                dy[(size_t)y * dys + i] = (uint8_t)((((unsigned)ry * r + (unsigned)gy * g + (unsigned)by * b) >> S) + 16);
+                if (!(y & 1) && !(i & 1)) {
+                    du[(size_t)(y >> 1) * dus + (i >> 1)] = (uint8_t)((((unsigned)ru * r + (unsigned)gu * g + (unsigned)bu * b) >> S) + 128);
+                    dv[(size_t)(y >> 1) * dvs + (i >> 1)] = (uint8_t)((((unsigned)rv * r + (unsigned)gv * g + (unsigned)bv * b) >> S) + 128);
+                }
+            }
+        }
+        return 0;
+    }
     if (half && (sw < 2 || (sw & 1))) return -1;                           /* (the pair reader would run past an odd row's end) */
     if (tto_filter_init(&lh, sw, dw, 1 << 14, alg) || tto_filter_init(&lv, sh, dh, 1 << 12, alg) ||
         tto_filter_init(&ch, csw, cdw, 1 << 14, alg) || tto_filter_init(&cv, sh, cdh, 1 << 12, alg)) return -1;

@@ -88,6 +88,11 @@ int tto_run_chain_rgb(const tto_chain *c, const uint8_t *sy, const uint8_t *su, 
  * 1 (chroma read at half width, rgb24ToUV_half_c) iff (dw >> 1) <= (sw >> 1), else 0 (rgb24ToUV_c per pixel) */
 int tto_rgb_in_half_chroma(int sw, int dw);
 
+/* 1 when the context takes swscale_unscaled.c's "bgr24toYV12" converter instead (bgr24 in, same size out, no
+ * accurate_rnd: rgb2rgb_template.c ff_rgb24toyv12_c -- truncating sums, chroma from the left pixel of every pair of
+ * the even rows); tto_sws_packed_to_yuv420 then refuses an odd width (-1: its last column is never written) */
+int tto_bgr24_special_converter(int fmt, int sw, int sh, int dw, int dh);
+
 /* One swscale context packed rgb24 (sw x sh) -> yuv420p (dw x dh), C path, default flags:
  * libswscale/input.c rgb24ToY_c / rgb24ToUV_half_c or rgb24ToUV_c (14-bit samples), swscale.c hScale16To15_c,
  * output.c yuv2planeX_8_c.  Chroma: ceil(sw / 2) x sh samples (sw even) when the width does not grow, else

@@ -512,8 +512,11 @@ def test_packed_rgb_input_other_layouts(tts, oracle, vf, iw, ih, fmt):
     import torch
     plan = tts.Plan.from_vf(vf, iw, ih, in_fmt=fmt)
     ref = tts.Plan.from_vf(vf, iw, ih, in_fmt="rgb24")
-    assert plan.in_bytes == iw * ih * (4 if fmt.endswith("a") else 3) and plan.kernel_name(0).startswith("rgbin")
-    if fmt == "bgr24":
+    special = fmt == "bgr24" and vf == "format=yuv420p"    # the same size: swscale's bgr24toYV12 converter, other bytes than the scaler's
+    assert plan.in_bytes == iw * ih * (4 if fmt.endswith("a") else 3) and plan.kernel_name(0).startswith("bgr24" if special else "rgbin")
+    if special:
+        assert plan.kernel_name(0) == "bgr24_yv12"
+    elif fmt == "bgr24":
         assert plan.kernel_name(0) == ref.kernel_name(0), (plan.kernel_name(0), ref.kernel_name(0))   # (every walk takes the swapped layout)
     for pat in ("random", "impulse"):
         rgb = rgb_frames(pat, iw, ih, 3)
@@ -522,7 +525,53 @@ def test_packed_rgb_input_other_layouts(tts, oracle, vf, iw, ih, fmt):
         want = oracle.run_chain(plan.geom, src)
         bad = np.flatnonzero(got != want)
         assert bad.size == 0, "%s %s %dx%d %s [%s]: %d bytes differ, first at %d" % (fmt, vf, iw, ih, pat, plan.kernel_name(0), bad.size, bad[0])
-        assert np.array_equal(got, ref.run_batch(torch.from_numpy(rgb).cuda()).cpu().numpy())
+        assert np.array_equal(got, ref.run_batch(torch.from_numpy(rgb).cuda()).cpu().numpy()) != special
+
+
+BGR24_SAME_SIZE_CASES = [
+    ("format=yuv420p", 1920, 1080),
+    ("format=yuv420p", 66, 37),                         # an odd height: the last row is an even row and has chroma
+    ("crop=64:33:11:7", 100, 60),                       # a crop on the packed pixels, odd offsets, odd height
+    ("scale=100:60,crop=64:32:12:8", 100, 60),          # a scale to the same size is still that converter; the crop behind it is planar
+    ("scale=100:60,pad=128:96:-1:-1:color=red", 100, 60),
+    ("crop=80:40:3:5,scale=80:40,crop=64:32,pad=96:64:-1:-1", 100, 60),
+]
+
+
+@pytest.mark.parametrize("vf,iw,ih", BGR24_SAME_SIZE_CASES)
+def test_bgr24_same_size_special_converter(tts, oracle, vf, iw, ih):
+    """bgr24 in, nothing resized: ff_rgb24toyv12_c's bytes (oracle: tto_sws_packed_to_yuv420's first branch), through
+    batches and through per-frame pointers; an odd width is refused with the reason."""
+    import torch
+    plan = tts.Plan.from_vf(vf, iw, ih, in_fmt="bgr24")
+    assert plan.kernel_name(0) == "bgr24_yv12", plan.kernel_name(0)
+    for pat in ("random", "impulse", "hramp"):
+        src = repack(rgb_frames(pat, iw, ih, 3), iw, ih, "bgr24")
+        want = oracle.run_chain(plan.geom, src)
+        d = torch.from_numpy(src).cuda()
+        got = plan.run_batch(d).cpu().numpy()
+        bad = np.flatnonzero(got != want)
+        assert bad.size == 0, "%s %dx%d %s: %d bytes differ, first at %d" % (vf, iw, ih, pat, bad.size, bad[0])
+    # per-frame pointers, padded strides
+    n, ow, oh = 3, plan.out_size[0], plan.out_size[1]
+    keep, sp, ss, dp, ds = [], [], [], [], []
+    for i in range(n):
+        t = torch.zeros((ih, iw * 3 + 5), dtype=torch.uint8, device="cuda")
+        t[:, : iw * 3] = torch.from_numpy(src[i].reshape(ih, iw * 3)).cuda()
+        outs = [torch.full(((oh + 1) // 2 if k else oh, ((ow + 1) // 2 if k else ow) + 3), 9, dtype=torch.uint8, device="cuda") for k in (0, 1, 1)]
+        keep += [t] + outs
+        sp.append([t.data_ptr(), 0, 0]); ss.append([t.shape[1], 0, 0])
+        dp.append(outs); ds.append([o.shape[1] for o in outs])
+    plan.run_frames(sp, [[o.data_ptr() for o in f] for f in dp], ss, ds)
+    torch.cuda.synchronize()
+    for i in range(n):
+        for k, w in enumerate(synth.split(want[i], ow, oh)):
+            g = dp[i][k].cpu().numpy()
+            assert np.array_equal(g[:, : w.shape[1]], w), ("per-frame pointers", i, k)
+            assert (g[:, w.shape[1]:] == 9).all(), "wrote into the stride padding"
+    with pytest.raises(Exception) as e:
+        tts.Plan.from_vf("format=yuv420p", iw - 1, ih, in_fmt="bgr24")
+    assert "UNSUPPORTED" in str(e.value) or "odd width" in str(e.value), str(e.value)
 
 
 @pytest.mark.parametrize("vf,iw,ih", RGBIN_CASES)

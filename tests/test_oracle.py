@@ -146,3 +146,54 @@ def test_oracle_packed_input_layouts_agree():
         q = np.empty((2, ih, iw, 4), np.uint8)
         q[..., :3] = px[..., order]; q[..., 3] = 99
         assert np.array_equal(oracle.run_chain(geom(fmt), q.reshape(2, -1)), want)
+
+
+def _bgr_geom(iw, ih, **kw):
+    g = dict(in_w=iw, in_h=ih, pre_x=0, pre_y=0, pre_w=iw, pre_h=ih, do_scale=0, sc_w=iw, sc_h=ih, alg=0, crop_x=0, crop_y=0, crop_w=iw, crop_h=ih,
+             do_pad=0, pad_x=0, pad_y=0, out_w=iw, out_h=ih, fill_y=16, fill_u=128, fill_v=128, out_range=0, out_fmt=0, rgb_stage=0, fill_rgb=0, in_fmt=2)
+    g.update(kw)
+    return g
+
+
+def test_bgr24_same_size_takes_the_special_converter():
+    """bgr24 -> yuv420p at the same size, default flags: swscale_unscaled.c hands the frame to ff_rgb24toyv12_c, not to the
+    scaler -- sums TRUNCATED (white is Y 234, not 235; grey chroma 127: the coefficient rows sum to -1), chroma from the
+    left pixel of each pair of the EVEN rows only.  Known answers worked by hand from the BT.601 table (ry gy by = 8414
+    16519 3208, ru gu bu = -4865 -9528 14392, rv gv bv = 14392 -12061 -2332, 15 fractional bits)."""
+    from oracle import oracle
+    iw, ih = 8, 5                                                      # an odd height: the last row is an even row
+    px = np.zeros((1, ih, iw, 3), np.uint8)                            # b, g, r
+    px[0, :, :, :] = 255
+    out = oracle.run_chain(_bgr_geom(iw, ih), px.reshape(1, -1))[0]
+    y, u, v = out[:iw * ih], out[iw * ih:iw * ih + 4 * 3], out[iw * ih + 12:]
+    assert (y == 234).all() and (u == 127).all() and (v == 127).all() and v.size == 12
+    # the same pixels as rgb24 run the scaler's one-tap path: rounded, 235 / 128
+    ref = oracle.run_chain(_bgr_geom(iw, ih, in_fmt=1), px.reshape(1, -1))[0]
+    assert (ref[:iw * ih] == 235).all() and (ref[iw * ih:] == 128).all()
+    # primaries: pure red, green, blue pixels (bytes b, g, r)
+    for bgr, want in (((0, 0, 255), (81, 90, 239)), ((0, 255, 0), (144, 53, 34)), ((255, 0, 0), (40, 239, 109)), ((0, 0, 0), (16, 128, 128))):
+        px[0, :, :] = bgr
+        out = oracle.run_chain(_bgr_geom(iw, ih), px.reshape(1, -1))[0]
+        assert (out[0], out[iw * ih], out[iw * ih + 12]) == want, (bgr, out[0], out[iw * ih], out[iw * ih + 12])
+    # chroma reads pixel (2 i, 2 j) alone: colouring the other three pixels of every 2 x 2 block changes luma only
+    px[0] = 0
+    base = oracle.run_chain(_bgr_geom(iw, ih), px.reshape(1, -1))[0]
+    px[0, 1::2, :, :] = (10, 200, 90); px[0, :, 1::2, :] = (250, 3, 77)
+    out = oracle.run_chain(_bgr_geom(iw, ih), px.reshape(1, -1))[0]
+    assert np.array_equal(out[iw * ih:], base[iw * ih:]) and not np.array_equal(out[:iw * ih], base[:iw * ih])
+    # ... and an independent restatement in numpy on random pixels, with a crop in front (any offset: RGB pixels)
+    rng = np.random.default_rng(11)
+    iw, ih = 22, 13
+    px = rng.integers(0, 256, (2, ih, iw, 3), dtype=np.uint8)
+    g = _bgr_geom(iw, ih, pre_x=3, pre_y=2, pre_w=16, pre_h=9, sc_w=16, sc_h=9, crop_w=16, crop_h=9, out_w=16, out_h=9)
+    out = oracle.run_chain(g, px.reshape(2, -1))
+    q = px[:, 2:11, 3:19].astype(np.int64)
+    M = np.array([[3208, 16519, 8414], [14392, -9528, -4865], [-2332, -12061, 14392]], np.int64)   # rows Y U V, columns b g r
+    yy = ((q @ M[0]) >> 15) + 16
+    uu = (((q[:, ::2, ::2] @ M[1]) >> 15) + 128) & 255
+    vv = (((q[:, ::2, ::2] @ M[2]) >> 15) + 128) & 255
+    want = np.concatenate([yy.reshape(2, -1), uu.reshape(2, -1), vv.reshape(2, -1)], axis=1).astype(np.uint8)
+    assert np.array_equal(out, want)
+    # a scale in the chain, even to nearly the same size, is the scaler again (the layouts agree there: the test above)
+    assert oracle.lib().tto_bgr24_special_converter(2, 16, 9, 16, 9) == 1 and oracle.lib().tto_bgr24_special_converter(2, 16, 9, 16, 10) == 0
+    assert oracle.lib().tto_bgr24_special_converter(1, 16, 9, 16, 9) == 0 and oracle.lib().tto_bgr24_special_converter(4, 16, 9, 16, 9) == 0

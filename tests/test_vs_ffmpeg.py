@@ -64,8 +64,21 @@ CHAINS = [
     # RGB from a full-range link and through swscale's 1- / 2-line packed writers, round 3
     (THUMB_REF + ",format=yuvj420p,format=rgb24", 720, 1280, "rgb24"),
     ("scale=128:96:flags=bilinear,format=rgb24", 64, 48, "rgb24"),
+    # bgr24 in at the same size: swscale_unscaled.c's bgr24toYV12 converter (ff_rgb24toyv12_c), which accurate_rnd would
+    # switch off -- run with `bitexact` alone.  x86 builds replace that function with SIMD that averages 2 x 2 chroma:
+    # the default-flags run of this chain is reported, not bounded.
+    ("format=yuv420p", 64, 48, "yuv420p", "bgr24"),
+    ("crop=64:33:11:7", 100, 60, "yuv420p", "bgr24"),
 ]
 CHAINS = [c if len(c) == 5 else c + ("yuv420p",) for c in CHAINS]
+
+
+def special_bgr24(chain, in_fmt):
+    return in_fmt == "bgr24" and "scale=" not in chain
+
+
+def exact_flags(chain, pix_fmt, in_fmt):
+    return "bicubic+bitexact" if pix_fmt == "rgb24" or special_bgr24(chain, in_fmt) else "bicubic+accurate_rnd+bitexact"
 
 
 def source_frames(pattern, iw, ih, n, in_fmt):
@@ -130,10 +143,10 @@ def test_oracle_vs_ffmpeg(oracle, tts, tmp_path, chain, iw, ih, pix_fmt, in_fmt)
     for pattern in ("random", "limited", "zone", "impulse"):
         frames = source_frames(pattern, iw, ih, 2, in_fmt)
         ours = oracle.run_chain(geom, frames).ravel()
-        exact = run_ffmpeg(tmp_path, chain, iw, ih, pix_fmt, frames, "bicubic+bitexact" if pix_fmt == "rgb24" else "bicubic+accurate_rnd+bitexact", in_fmt)
+        exact = run_ffmpeg(tmp_path, chain, iw, ih, pix_fmt, frames, exact_flags(chain, pix_fmt, in_fmt), in_fmt)
         assert diff_report("oracle vs ffmpeg C path [%s, %s in, %s]" % (chain, in_fmt, pattern), ours, exact) == 0
         default = run_ffmpeg(tmp_path, chain, iw, ih, pix_fmt, frames, "bicubic", in_fmt)
-        assert diff_report("oracle vs ffmpeg default flags [%s, %s in, %s]" % (chain, in_fmt, pattern), ours, default) <= (2 if rgb else 1)
+        assert diff_report("oracle vs ffmpeg default flags [%s, %s in, %s]" % (chain, in_fmt, pattern), ours, default) <= (255 if special_bgr24(chain, in_fmt) else 2 if rgb else 1)
 
 
 @needs_ffmpeg
@@ -145,10 +158,10 @@ def test_hip_vs_ffmpeg(tts, tmp_path, chain, iw, ih, pix_fmt, in_fmt):
     plan = tts.Plan.from_vf(chain, iw, ih, in_fmt=in_fmt)
     frames = source_frames("random", iw, ih, 2, in_fmt)
     ours = plan.run_batch(torch.from_numpy(frames).cuda()).cpu().numpy().ravel()
-    exact = run_ffmpeg(tmp_path, chain, iw, ih, pix_fmt, frames, "bicubic+bitexact" if pix_fmt == "rgb24" else "bicubic+accurate_rnd+bitexact", in_fmt)
+    exact = run_ffmpeg(tmp_path, chain, iw, ih, pix_fmt, frames, exact_flags(chain, pix_fmt, in_fmt), in_fmt)
     assert diff_report("libttscale vs ffmpeg C path [%s]" % chain, ours, exact) == 0
     default = run_ffmpeg(tmp_path, chain, iw, ih, pix_fmt, frames, "bicubic", in_fmt)
-    assert diff_report("libttscale vs ffmpeg default flags [%s]" % chain, ours, default) <= (2 if rgb else 1)
+    assert diff_report("libttscale vs ffmpeg default flags [%s]" % chain, ours, default) <= (255 if special_bgr24(chain, in_fmt) else 2 if rgb else 1)
 
 
 def test_skip_reason_is_visible():

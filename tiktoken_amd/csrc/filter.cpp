@@ -227,6 +227,7 @@ int check_geom(const tts_geom &g)
     if (g.in_fmt != TTS_FMT_YUV420P) {
         // a crop in front of the conversion works on RGB pixels (any offset); rgb24ToUV_half_c reads pixel pairs
         if (g.out_fmt != TTS_FMT_YUV420P || g.out_range != TTS_RANGE_KEEP || ((g.pre_w & 1) && rgb_in_half_chroma(g.pre_w, g.sc_w))) return TTS_ERR_UNSUPPORTED;
+        if (bgr24_special_converter(g) && (g.pre_w & 1)) return TTS_ERR_UNSUPPORTED;   // (already covered: the same size is never an enlargement)
     } else if (has_pre && !(even(g.pre_x) && even(g.pre_y) && even(g.pre_w) && even(g.pre_h))) return TTS_ERR_INVALID_INPUT;
     if (g.sc_w < 1 || g.sc_h < 1 || g.sc_w > 16384 || g.sc_h > 16384) return TTS_ERR_INVALID_INPUT;
     if (!g.do_scale && (g.sc_w != g.pre_w || g.sc_h != g.pre_h)) return TTS_ERR_INVALID_INPUT;

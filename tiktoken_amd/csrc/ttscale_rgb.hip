@@ -1035,6 +1035,32 @@ __global__ __launch_bounds__(kBlock) void rgbin_generic_kernel(const RgbInArgs a
     dp[size_t(y) * size_t(a.dst_stride[ci]) + x] = uint8_t(out);
 }
 
+// ---- bgr24 in at the same size: swscale's special converter -------------------------------------------------
+// swscale_unscaled.c "bgr24toYV12" -> rgb2rgb_template.c ff_rgb24toyv12_c() (filter.h bgr24_special_converter()): no
+// 14-bit samples, no filters -- luma ((ry r + gy g + by b) >> 15) + 16 per pixel, chroma ((ru r + gu g + bu b) >> 15)
+// + 128 from the left pixel of each pair of the even source rows, sums unsigned, the byte store keeps the low 8 bits.
+// One lane per output sample, crop / pad behind it as in the generic kernel.
+__global__ __launch_bounds__(kBlock) void bgr24_yv12_kernel(const RgbInArgs a)
+{
+    const int plane = int(blockIdx.z) % 3, frame = a.frame0 + int(blockIdx.z) / 3;
+    if (a.only_plane >= 0 && plane != a.only_plane) return;
+    const int ci = plane ? 1 : 0;
+    const int x = int(blockIdx.x) * 64 + int(threadIdx.x & 63);
+    const int y = int(blockIdx.y) * 4 + int(threadIdx.x >> 6);
+    if (x >= a.canvas_w[ci] || y >= a.canvas_h[ci]) return;
+    const uint8_t *fb;
+    uint8_t *dp;
+    rgbin_frame(a, frame, plane, fb, dp);
+    uint32_t out = uint32_t(a.fill[plane]);
+    if (y >= a.py[ci] && y < a.py[ci] + a.ph[ci] && x >= a.px[ci] && x < a.px[ci] + a.pw[ci]) {
+        const int vx = (a.ox[ci] + x - a.px[ci]) << ci, vy = (a.oy[ci] + y - a.py[ci]) << ci;   // chroma: pixel (2 x, 2 y)
+        const uint8_t *q = fb + a.src_origin + size_t(vy) * size_t(a.src_stride) + 3 * size_t(vx);
+        const uint32_t s = uint32_t(a.coef[3 * plane]) * q[0] + uint32_t(a.coef[3 * plane + 1]) * q[1] + uint32_t(a.coef[3 * plane + 2]) * q[2];   // (coef: by byte of a pixel)
+        out = ((s >> 15) + (plane ? 128u : 16u)) & 255u;
+    }
+    dp[size_t(y) * size_t(a.dst_stride[ci]) + x] = uint8_t(out);
+}
+
 // ---- packed rgb24 in, tiled: a workgroup owns 64 x TH output samples of one plane ---------------------------
 // The kernel above converts every source pixel once per TAP PAIR that touches it (taps_h x taps_v times per
 // output sample).  Here a workgroup converts the source samples its tile needs ONCE into LDS (rgb24ToY_c /
@@ -1990,6 +2016,7 @@ struct RgbInPlan {
     int strips = 0, pxl = 8, chd = 2;
     int seg_knob = 0;                  // TTS_RGBIN_SEG at plan creation: row segments a launch (0: the launch decides)
     RgbInShrinkPlan *shrink = nullptr; // shrinks with at most 8 taps across: the source-row walk of ttscale_rgbin_shrink.hip
+    bool yv12 = false;                 // bgr24 at the same size: swscale's special converter (bgr24_yv12_kernel), none of the above
     char name[96] = "";
 };
 
@@ -2043,7 +2070,13 @@ int rgbin_plan_create(const tts_geom &g, RgbInPlan **out)
     p->half = half;
     p->pb = packed_pixel_bytes(g.in_fmt);
     p->blue_first = packed_blue_first(g.in_fmt);
-    const bool three = p->pb == 3;         // the walks read 3-byte pixels; 4-byte sources run the tiled / general kernels
+    p->yv12 = bgr24_special_converter(g);
+    if (p->yv12 && (g.pre_w & 1)) {
+        set_last_error("swscale's bgr24 -> yuv420p converter for pictures of the same size never writes the last column of an odd width: not supported");
+        delete p;
+        return TTS_ERR_UNSUPPORTED;
+    }
+    const bool three = p->pb == 3 && !p->yv12;   // the walks read 3-byte pixels; 4-byte sources run the tiled / general kernels
     int rc = TTS_OK;
     if (!build_axis_filter(g.pre_w, g.sc_w, 1 << 14, g.alg, p->lh) || !build_axis_filter(g.pre_h, g.sc_h, 1 << 12, g.alg, p->lv) ||
         !build_axis_filter(half ? g.pre_w / 2 : g.pre_w, (g.sc_w + 1) >> 1, 1 << 14, g.alg, p->ch) || !build_axis_filter(g.pre_h, (g.sc_h + 1) >> 1, 1 << 12, g.alg, p->cv)) {
@@ -2052,7 +2085,7 @@ int rgbin_plan_create(const tts_geom &g, RgbInPlan **out)
     const AxisFilter *f[4] = {&p->lh, &p->lv, &p->ch, &p->cv};
     for (int i = 0; i < 4 && !rc; ++i)
         if (!upload_vec(p->d_pos[i], f[i]->pos) || !upload_vec(p->d_taps[i], f[i]->taps)) { set_last_error("table upload failed (hipMalloc / hipMemcpy)"); rc = TTS_ERR_INITIALIZATION_FAILED; }
-    if (!rc && !std::getenv("TTS_FORCE_GENERIC")) {
+    if (!rc && !p->yv12 && !std::getenv("TTS_FORCE_GENERIC")) {
         // 32 KiB a workgroup if some tile height fits that (five workgroups on a CU's 160 KiB), else 64 KiB
         const RgbInRect r0 = rgbin_rect(g, 0), r1 = rgbin_rect(g, 1);
         for (size_t budget : {size_t(32768), size_t(65536)})        // (64 KiB: the most a workgroup gets without opting in)
@@ -2194,7 +2227,8 @@ int rgbin_plan_create(const tts_geom &g, RgbInPlan **out)
         rgbin_coefficients(coef, p->blue_first);
         p->shrink = rgbin_shrink_create(g, p->lh, p->lv, p->ch, p->cv, coef);
     }
-    if (p->shrink) std::snprintf(p->name, sizeof p->name, "%s", rgbin_shrink_name(p->shrink));
+    if (p->yv12) std::snprintf(p->name, sizeof p->name, "bgr24_yv12");
+    else if (p->shrink) std::snprintf(p->name, sizeof p->name, "%s", rgbin_shrink_name(p->shrink));
     else if (p->walk) std::snprintf(p->name, sizeof p->name, "rgbin_walk<%d>", p->cv.size);
     else if (p->strip) std::snprintf(p->name, sizeof p->name, "rgbin_strip<%d,%d,%d,%d,%dpx>", p->lh.size, p->lv.size, p->ch.size, p->cv.size, p->pxl);   // luma taps across / down, chroma taps across / down
     else if (p->tiled) std::snprintf(p->name, sizeof p->name, "rgbin_tile<%d,%d>", p->th[0], p->th[1]);
@@ -2242,6 +2276,13 @@ int rgbin_launch(const RgbInPlan *p, const uint8_t *src, uint8_t *dst, int n, in
     for (int i = 0; i < 9; ++i) a.coef[i] = coef[i];
     a.addr = addr;
     int rc = TTS_OK;
+    if (p->yv12) {
+        for (int f0 = 0; f0 < n && !rc; f0 += 21845) {      // grid.z = frames x 3 planes
+            a.frame0 = f0;
+            rc = launch_rgb("bgr24_yv12_kernel", bgr24_yv12_kernel, dim3((g.out_w + 63) / 64, (g.out_h + 3) / 4, std::min(21845, n - f0) * 3), dim3(kBlock), 0, st, a);
+        }
+        return rc;
+    }
     // the conversion alone, frames at a fixed pitch, rows where 8-byte loads and stores may go: the streaming walk
     bool walk = p->walk && only_plane < 0 && reinterpret_cast<uintptr_t>(src) % 8 == 0 && src_stride % 8 == 0 && a.src_origin % 8 == 0 &&
                 reinterpret_cast<uintptr_t>(dst) % 8 == 0 && dst_stride[0] % 8 == 0 && dst_stride[1] % 4 == 0;
