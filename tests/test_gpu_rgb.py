@@ -515,7 +515,7 @@ def test_packed_rgb_input_other_layouts(tts, oracle, vf, iw, ih, fmt):
     special = fmt == "bgr24" and vf == "format=yuv420p"    # the same size: swscale's bgr24toYV12 converter, other bytes than the scaler's
     assert plan.in_bytes == iw * ih * (4 if fmt.endswith("a") else 3) and plan.kernel_name(0).startswith("bgr24" if special else "rgbin")
     if special:
-        assert plan.kernel_name(0) == "bgr24_yv12"
+        assert plan.kernel_name(0) == "bgr24_yv12_rows"
     elif fmt == "bgr24":
         assert plan.kernel_name(0) == ref.kernel_name(0), (plan.kernel_name(0), ref.kernel_name(0))   # (every walk takes the swapped layout)
     for pat in ("random", "impulse"):
@@ -531,6 +531,9 @@ def test_packed_rgb_input_other_layouts(tts, oracle, vf, iw, ih, fmt):
 BGR24_SAME_SIZE_CASES = [
     ("format=yuv420p", 1920, 1080),
     ("format=yuv420p", 66, 37),                         # an odd height: the last row is an even row and has chroma
+    ("format=yuv420p", 8, 2),
+    ("format=yuv420p", 6, 3),                           # narrower than a lane's eight pixels: a lane per sample
+    ("format=yuv420p", 1034, 11),                       # 129 and a quarter lanes a row: the last is slid left
     ("crop=64:33:11:7", 100, 60),                       # a crop on the packed pixels, odd offsets, odd height
     ("scale=100:60,crop=64:32:12:8", 100, 60),          # a scale to the same size is still that converter; the crop behind it is planar
     ("scale=100:60,pad=128:96:-1:-1:color=red", 100, 60),
@@ -539,12 +542,17 @@ BGR24_SAME_SIZE_CASES = [
 
 
 @pytest.mark.parametrize("vf,iw,ih", BGR24_SAME_SIZE_CASES)
-def test_bgr24_same_size_special_converter(tts, oracle, vf, iw, ih):
+def test_bgr24_same_size_special_converter(tts, oracle, monkeypatch, vf, iw, ih):
     """bgr24 in, nothing resized: ff_rgb24toyv12_c's bytes (oracle: tto_sws_packed_to_yuv420's first branch), through
     batches and through per-frame pointers; an odd width is refused with the reason."""
     import torch
     plan = tts.Plan.from_vf(vf, iw, ih, in_fmt="bgr24")
-    assert plan.kernel_name(0) == "bgr24_yv12", plan.kernel_name(0)
+    # nothing behind the converter: eight pixels of two rows a lane; a crop or pad behind it: a lane per output sample
+    assert plan.kernel_name(0) == ("bgr24_yv12" if "," in vf or iw < 8 else "bgr24_yv12_rows"), plan.kernel_name(0)
+    monkeypatch.setenv("TTS_FORCE_GENERIC", "1")
+    slow = tts.Plan.from_vf(vf, iw, ih, in_fmt="bgr24")
+    monkeypatch.delenv("TTS_FORCE_GENERIC")
+    assert slow.kernel_name(0) == "bgr24_yv12"
     for pat in ("random", "impulse", "hramp"):
         src = repack(rgb_frames(pat, iw, ih, 3), iw, ih, "bgr24")
         want = oracle.run_chain(plan.geom, src)
@@ -552,6 +560,7 @@ def test_bgr24_same_size_special_converter(tts, oracle, vf, iw, ih):
         got = plan.run_batch(d).cpu().numpy()
         bad = np.flatnonzero(got != want)
         assert bad.size == 0, "%s %dx%d %s: %d bytes differ, first at %d" % (vf, iw, ih, pat, bad.size, bad[0])
+        assert np.array_equal(slow.run_batch(d).cpu().numpy(), want)
     # per-frame pointers, padded strides
     n, ow, oh = 3, plan.out_size[0], plan.out_size[1]
     keep, sp, ss, dp, ds = [], [], [], [], []

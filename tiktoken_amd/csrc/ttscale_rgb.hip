@@ -1061,6 +1061,52 @@ __global__ __launch_bounds__(kBlock) void bgr24_yv12_kernel(const RgbInArgs a)
     dp[size_t(y) * size_t(a.dst_stride[ci]) + x] = uint8_t(out);
 }
 
+// The same converter where nothing follows it (no crop or pad behind, width >= 8): a lane owns 8 pixels of two rows --
+// 24 source bytes a row as six dwords at any byte address, 8 luma bytes a row, 4 + 4 chroma bytes from the upper row.  The
+// last lane of a row is slid left to end with the row (the width is even: so is its first pixel; same values, written twice).
+__global__ __launch_bounds__(kBlock) void bgr24_yv12_rows_kernel(const RgbInArgs a)
+{
+    typedef uint32_t u32_any __attribute__((aligned(1)));
+    const int frame = a.frame0 + int(blockIdx.z);
+    const int w = a.canvas_w[0], h = a.canvas_h[0];
+    const int gx = int(blockIdx.x) * 64 + int(threadIdx.x & 63), yp = int(blockIdx.y) * 4 + int(threadIdx.x >> 6);
+    if (gx * 8 >= w || 2 * yp >= h) return;
+    const int x0 = min(gx * 8, w - 8);
+    const uint8_t *fb;
+    uint8_t *dy, *du, *dv;
+    rgbin_frame(a, frame, 0, fb, dy);
+    rgbin_frame(a, frame, 1, fb, du);
+    rgbin_frame(a, frame, 2, fb, dv);
+    for (int rr = 0; rr < 2; ++rr) {
+        const int y = 2 * yp + rr;
+        if (y >= h) break;                                       // (an odd height: the last row is an upper row)
+        const u32_any *q = reinterpret_cast<const u32_any *>(fb + a.src_origin + size_t(y) * size_t(a.src_stride) + 3 * size_t(x0));
+        uint32_t d[6];
+#pragma unroll
+        for (int k = 0; k < 6; ++k) d[k] = q[k];
+        auto byte = [&](int i) { return (d[i >> 2] >> (8 * (i & 3))) & 255u; };
+        uint32_t o[2] = {0, 0};
+#pragma unroll
+        for (int i = 0; i < 8; ++i) {
+            const uint32_t s = uint32_t(a.coef[0]) * byte(3 * i) + uint32_t(a.coef[1]) * byte(3 * i + 1) + uint32_t(a.coef[2]) * byte(3 * i + 2);
+            o[i >> 2] |= ((s >> 15) + 16u) << (8 * (i & 3));     // (luma: at most 235)
+        }
+        u32_any *py = reinterpret_cast<u32_any *>(dy + size_t(y) * size_t(a.dst_stride[0]) + x0);
+        py[0] = o[0]; py[1] = o[1];
+        if (rr == 0) {
+            uint32_t cu = 0, cv = 0;
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                const uint32_t b = byte(6 * i), g = byte(6 * i + 1), r = byte(6 * i + 2);
+                cu |= ((((uint32_t(a.coef[3]) * b + uint32_t(a.coef[4]) * g + uint32_t(a.coef[5]) * r) >> 15) + 128u) & 255u) << (8 * i);
+                cv |= ((((uint32_t(a.coef[6]) * b + uint32_t(a.coef[7]) * g + uint32_t(a.coef[8]) * r) >> 15) + 128u) & 255u) << (8 * i);
+            }
+            *reinterpret_cast<u32_any *>(du + size_t(yp) * size_t(a.dst_stride[1]) + (x0 >> 1)) = cu;
+            *reinterpret_cast<u32_any *>(dv + size_t(yp) * size_t(a.dst_stride[1]) + (x0 >> 1)) = cv;
+        }
+    }
+}
+
 // ---- packed rgb24 in, tiled: a workgroup owns 64 x TH output samples of one plane ---------------------------
 // The kernel above converts every source pixel once per TAP PAIR that touches it (taps_h x taps_v times per
 // output sample).  Here a workgroup converts the source samples its tile needs ONCE into LDS (rgb24ToY_c /
@@ -2017,6 +2063,7 @@ struct RgbInPlan {
     int seg_knob = 0;                  // TTS_RGBIN_SEG at plan creation: row segments a launch (0: the launch decides)
     RgbInShrinkPlan *shrink = nullptr; // shrinks with at most 8 taps across: the source-row walk of ttscale_rgbin_shrink.hip
     bool yv12 = false;                 // bgr24 at the same size: swscale's special converter (bgr24_yv12_kernel), none of the above
+    bool yv12_rows = false;            // ... with nothing behind it: bgr24_yv12_rows_kernel
     char name[96] = "";
 };
 
@@ -2227,7 +2274,9 @@ int rgbin_plan_create(const tts_geom &g, RgbInPlan **out)
         rgbin_coefficients(coef, p->blue_first);
         p->shrink = rgbin_shrink_create(g, p->lh, p->lv, p->ch, p->cv, coef);
     }
-    if (p->yv12) std::snprintf(p->name, sizeof p->name, "bgr24_yv12");
+    p->yv12_rows = p->yv12 && !g.do_pad && g.crop_x == 0 && g.crop_y == 0 && g.crop_w == g.sc_w && g.crop_h == g.sc_h && g.out_w == g.sc_w && g.out_h == g.sc_h &&
+                   g.pre_w >= 8 && !std::getenv("TTS_FORCE_GENERIC");
+    if (p->yv12) std::snprintf(p->name, sizeof p->name, p->yv12_rows ? "bgr24_yv12_rows" : "bgr24_yv12");
     else if (p->shrink) std::snprintf(p->name, sizeof p->name, "%s", rgbin_shrink_name(p->shrink));
     else if (p->walk) std::snprintf(p->name, sizeof p->name, "rgbin_walk<%d>", p->cv.size);
     else if (p->strip) std::snprintf(p->name, sizeof p->name, "rgbin_strip<%d,%d,%d,%d,%dpx>", p->lh.size, p->lv.size, p->ch.size, p->cv.size, p->pxl);   // luma taps across / down, chroma taps across / down
@@ -2276,10 +2325,18 @@ int rgbin_launch(const RgbInPlan *p, const uint8_t *src, uint8_t *dst, int n, in
     for (int i = 0; i < 9; ++i) a.coef[i] = coef[i];
     a.addr = addr;
     int rc = TTS_OK;
-    if (p->yv12) {
+    if (p->yv12 && !(p->yv12_rows && only_plane < 0)) {
         for (int f0 = 0; f0 < n && !rc; f0 += 21845) {      // grid.z = frames x 3 planes
             a.frame0 = f0;
             rc = launch_rgb("bgr24_yv12_kernel", bgr24_yv12_kernel, dim3((g.out_w + 63) / 64, (g.out_h + 3) / 4, std::min(21845, n - f0) * 3), dim3(kBlock), 0, st, a);
+        }
+        return rc;
+    }
+    if (p->yv12_rows && only_plane < 0) {
+        const int groups = (g.out_w + 7) / 8, pairs = (g.out_h + 1) / 2;
+        for (int f0 = 0; f0 < n && !rc; f0 += 65535) {
+            a.frame0 = f0;
+            rc = launch_rgb("bgr24_yv12_rows_kernel", bgr24_yv12_rows_kernel, dim3((groups + 63) / 64, (pairs + 3) / 4, std::min(65535, n - f0)), dim3(kBlock), 0, st, a);
         }
         return rc;
     }

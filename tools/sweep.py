@@ -54,6 +54,7 @@ CASES = {
     "cvt_rgb24_portrait": ("format=rgb24", 1080, 1920, 3110400 + 6220800),
     "cvt_rgba": ("format=rgba", 1920, 1080, 3110400 + 8294400),
     "cvt_rgbin": ("format=yuv420p", 1920, 1080, 6220800 + 3110400),                                  # rgb24 -> yuv420p, no scale
+    "cvt_bgrin": ("format=yuv420p", 1920, 1080, 6220800 + 3110400),                                  # bgr24 -> yuv420p, no scale: swscale's special converter
     "web_rgb24": ("scale=720:1280,format=rgb24", 1080, 1920, 3110400 + 2764800),      # 1.5x shrink written as RGB
     "web_rgba": ("scale=720:1280,format=rgba", 1080, 1920, 3110400 + 3686400),
     "4k_rgb24": ("scale=1080:1920:force_original_aspect_ratio=increase,crop=1080:1920,format=rgb24", 3840, 2160, 3939840 + 6220800),   # 1.125x shrink, 5 taps
@@ -62,7 +63,7 @@ CASES = {
 }
 
 
-IN_FMT = {"portrait_rgbin": "rgb24", "stretch_rgbin": "rgb24", "cvt_rgbin": "rgb24", "half_rgbin": "rgb24", "web_rgbin": "rgb24", "thumb_rgbin": "rgb24"}
+IN_FMT = {"portrait_rgbin": "rgb24", "stretch_rgbin": "rgb24", "cvt_rgbin": "rgb24", "half_rgbin": "rgb24", "web_rgbin": "rgb24", "thumb_rgbin": "rgb24", "cvt_bgrin": "bgr24"}
 
 
 def plan_for(case):
