@@ -140,5 +140,11 @@ __device__ __forceinline__ void store_b8(uint32_t v, u32x4_t rs, uint32_t off, i
     asm volatile("buffer_store_dword %0, %1, %2, %3 offen" :: "v"(v), "v"(off), "s"(rs), "s"(soff));
 }
 
+// The same through a 64-bit address (the kernels that walk SOURCE rows with the next rows' loads in flight: with these
+// stores hidden and the loads two rows ahead, the compiler's wait for a row is vmcnt(<loads of the row behind it>), which
+// leaves the stores just issued in flight; with one row ahead, or with stores it sees inside the variable-trip emission
+// loops, every row waited out the acknowledgement of the stores in front of it)
+[[maybe_unused]] __device__ __forceinline__ void gstore_b64(void *p, u32x2_t v) { asm volatile("global_store_dwordx2 %0, %1, off" :: "v"(p), "v"(v)); }
+[[maybe_unused]] __device__ __forceinline__ void gstore_b32(void *p, uint32_t v) { asm volatile("global_store_dword %0, %1, off" :: "v"(p), "v"(v)); }
 
 }  // namespace

@@ -1294,7 +1294,7 @@ __global__ __launch_bounds__(kBlock) void rgbin_walk_kernel(const uint8_t *__res
     const int u = min(wx * 64 + lane, units - 1);                  // dead lanes shadow the last unit and store nothing
     const bool live = wx * 64 + lane < units;
     const int frame = a.frame0 + int(blockIdx.z);
-    const uint8_t *sp;
+    const uint8_t *sp;                                             // (wave-uniform: the frame's pre-cropped origin; lanes add 32-bit offsets)
     uint8_t *dy, *du, *dv;
     if (a.addr.use_table) {                                        // tts_run: per-frame offsets (at most kMaxTableFrames a launch: frame0 is 0)
         sp = src + a.addr.src_tab[0][frame];
@@ -1304,7 +1304,12 @@ __global__ __launch_bounds__(kBlock) void rgbin_walk_kernel(const uint8_t *__res
         uint8_t *dpf = dst + size_t(frame) * a.addr.dst_pitch;
         dy = dpf + a.addr.dst_plane[0]; du = dpf + a.addr.dst_plane[1]; dv = dpf + a.addr.dst_plane[2];
     }
-    sp += a.src_origin + 24 * size_t(u);
+    sp += a.src_origin;
+    // a lane's 24 bytes of a row as three 8-byte loads the compiler cannot merge (it is not told that the offsets are 8
+    // apart): what counts for the waits below is the NUMBER of loads issued behind a row's own
+    uint32_t lo[3];
+#pragma unroll
+    for (int k = 0; k < 3; ++k) { lo[k] = 24u * uint32_t(u) + 8u * k; asm volatile("" : "+v"(lo[k])); }
     dy += 8 * size_t(u); du += 4 * size_t(u); dv += 4 * size_t(u);
     const int ra = seg * a.seg_rows, rb = min(ra + a.seg_rows, a.h);
     int y = rgbin_lower_bound(last, a.ny, ra);
@@ -1315,21 +1320,31 @@ __global__ __launch_bounds__(kBlock) void rgbin_walk_kernel(const uint8_t *__res
     uint32_t ring[2][4][4];                                        // plane, chroma column, row pair (slots 2k, 2k + 1)
 #pragma unroll
     for (int i = 0; i < 32; ++i) (&ring[0][0][0])[i] = 0;
-    u32x2_t nx[3];
-    {
-        const u32x2_t *q = reinterpret_cast<const u32x2_t *>(sp + size_t(rstart) * a.src_stride);
-        nx[0] = q[0]; nx[1] = q[1]; nx[2] = q[2];
-    }
+    // Two rows in flight and the output stores hidden from the compiler (ttscale_device.h gstore_b64): the wait in front of a
+    // row's bytes is then vmcnt(3) -- the loads of the row behind it by the compiler's count, in fact the youngest three of
+    // those and of the stores issued since.  (One row in flight, stores the compiler sees inside the variable-trip loop
+    // below: vmcnt(0) every row, i.e. the acknowledgement of the stores just issued.)  Every pass of the unrolled loop
+    // issues its loads, run or skipped, so that no path joins another with loads in flight on one side only.
+    u32x2_t nx[2][3];
+    auto fetch = [&](int r, u32x2_t (&raw)[3]) {
+        const uint8_t *row = sp + size_t(r) * a.src_stride;        // (wave-uniform)
+#pragma unroll
+        for (int k = 0; k < 3; ++k) raw[k] = *reinterpret_cast<const u32x2_t *>(row + lo[k]);
+    };
+    fetch(min(rstart + (rstart & 1), rb - 1), nx[0]);
+    fetch(min(rstart + 1 - (rstart & 1), rb - 1), nx[1]);
     for (int r0 = rstart & ~7; r0 < rb; r0 += 8) {
 #pragma unroll
         for (int s = 0; s < 8; ++s) {
             const int r = r0 + s;
-            if (r < rstart || r >= rb) continue;                   // wave-uniform
-            const uint32_t w[6] = {nx[0].x, nx[0].y, nx[1].x, nx[1].y, nx[2].x, nx[2].y};
-            {
-                const u32x2_t *q = reinterpret_cast<const u32x2_t *>(sp + size_t(min(r + 1, rb - 1)) * a.src_stride);
-                nx[0] = q[0]; nx[1] = q[1]; nx[2] = q[2];
+            const bool skip = r < rstart || r >= rb;               // wave-uniform
+            uint32_t w[6];
+            if (!skip) {
+#pragma unroll
+                for (int k = 0; k < 3; ++k) { w[2 * k] = nx[s & 1][k].x; w[2 * k + 1] = nx[s & 1][k].y; }
             }
+            fetch(min(max(r + 2, rstart + ((r - rstart) & 1)), rb - 1), nx[s & 1]);
+            if (skip) continue;
             int R[8], G[8], B[8];
 #pragma unroll
             for (int i = 0; i < 8; ++i) {
@@ -1347,7 +1362,7 @@ __global__ __launch_bounds__(kBlock) void rgbin_walk_kernel(const uint8_t *__res
                     v[i] = min(2 * s14, 32767) + 64;
                 }
                 const u32x2_t o = {pack4<7>(v[0], v[1], v[2], v[3]), pack4<7>(v[4], v[5], v[6], v[7])};
-                if (live) *reinterpret_cast<u32x2_t *>(dy + size_t(r) * a.dst_stride[0]) = o;
+                if (live) gstore_b64(dy + size_t(r) * a.dst_stride[0], o);
             }
             // rgb24ToUV_half_c on the four pixel pairs, hScale16To15_c (one tap), into ring slot r & 7 (= s)
 #pragma unroll
@@ -1375,8 +1390,8 @@ __global__ __launch_bounds__(kBlock) void rgbin_walk_kernel(const uint8_t *__res
                     }
                 const uint32_t ou = pack4<19>(acc[0][0], acc[0][1], acc[0][2], acc[0][3]), ov = pack4<19>(acc[1][0], acc[1][1], acc[1][2], acc[1][3]);
                 if (live) {
-                    *reinterpret_cast<uint32_t *>(du + size_t(y) * a.dst_stride[1]) = ou;
-                    *reinterpret_cast<uint32_t *>(dv + size_t(y) * a.dst_stride[1]) = ov;
+                    gstore_b32(du + size_t(y) * a.dst_stride[1], ou);
+                    gstore_b32(dv + size_t(y) * a.dst_stride[1], ov);
                 }
                 ++y;
                 next_last = y < yend ? int(last[y]) : -1;
@@ -1428,6 +1443,7 @@ __global__ __launch_bounds__(kBlock, 3) void rgbin_strip_kernel(const uint8_t *_
                                                                 const int32_t *__restrict__ tab, const RgbInStripArgs a)
 {
     static_assert(PXL == 4 || PXL == 6 || PXL == 8, "pixels a lane converts");
+    constexpr bool SPLIT = true;                                     // (false: merged loads, four rows in flight -- 1-3 % slower, and three of the nine instantiations spill)
     constexpr int NP = PXL / 2, NDW = (3 * PXL + 6) / 4;             // pixel pairs; aligned dwords that hold a lane's 3 PXL bytes at any phase
     constexpr int CB = 32 * PXL + 8;                                 // dwords of one copy of a row (64 PXL samples + slack: windows read whole tap pairs; the odd copy starts one dword in)
     constexpr int ST = 28 + 4 * CHD;                                 // words of a strip's table entry
@@ -1520,28 +1536,44 @@ __global__ __launch_bounds__(kBlock, 3) void rgbin_strip_kernel(const uint8_t *_
     // A lane's 3 PXL bytes of a source row as the aligned dwords that hold them.  Every dword read holds at least one byte
     // of the lane's pixels (the host keeps those inside the frame), so it lies in a mapped page: the last of the NDW is
     // needed only at the larger byte phases, elsewhere the one before it is read again.
+    // SPLIT: one load instruction per dword (the offsets are made opaque so that the compiler cannot merge them): what counts
+    // for the waits is the NUMBER of loads issued behind a row's own (see D below)
     auto fetch = [&](int r, uint32_t (&raw)[NDW]) {
         const uint32_t o = off0 + uint32_t(r) * uint32_t(a.src_stride), oa = o & ~3u;
-        const uint32_t *q = reinterpret_cast<const uint32_t *>(sbase4 + oa);
 #pragma unroll
-        for (int k = 0; k < NDW - 1; ++k) raw[k] = q[k];
+        for (int k = 0; k < NDW - 1; ++k) {
+            uint32_t ok = oa + 4u * k;
+            if (SPLIT) asm volatile("" : "+v"(ok));
+            raw[k] = *reinterpret_cast<const uint32_t *>(sbase4 + ok);
+        }
         const bool need_last = (o & 3u) + 3u * PXL > 4u * (NDW - 1);
         raw[NDW - 1] = *reinterpret_cast<const uint32_t *>(sbase4 + (oa + (need_last ? 4u * (NDW - 1) : 4u * (NDW - 2))));
     };
-    uint32_t nx[NDW];
-    fetch(rstart, nx);
+    // D rows ahead, and the output stores below hidden from the compiler (ttscale_device.h gstore_b64): the wait in
+    // front of a row's bytes then leaves the loads of the D - 1 rows behind it -- in fact the stores issued since and the
+    // youngest of those loads -- in flight
+    constexpr int D = SPLIT ? 2 : 4;                               // rows in flight (a power of two that divides the unrolling)
+    uint32_t nx[D][NDW];
+#pragma unroll
+    for (int k = 0; k < D; ++k) fetch(min(rstart + ((k - rstart) & (D - 1)), rlast), nx[k]);   // (slot k: the first row r >= rstart with r % D == k; static register indices)
     for (int r0 = rstart & ~7; r0 <= rlast; r0 += 8) {
 #pragma unroll
         for (int s = 0; s < 8; ++s) {
             const int r = r0 + s;
-            if (r < rstart || r > rlast) continue;                 // wave-uniform
+            const bool skip = r < rstart || r > rlast;             // wave-uniform
+            // the row's bytes out of their registers, then the loads of the row two on into the same registers: EVERY
+            // pass issues them (a skipped one whatever row its registers have to hold when the walk gets there), so that no
+            // path joins another with loads in flight on one side only -- the copies such a join needs wait for vmcnt(0)
+            uint32_t w[NDW - 1];
+            if (!skip) {
+                const uint32_t ph = (off0 + uint32_t(r) * uint32_t(a.src_stride)) & 3u;
+#pragma unroll
+                for (int k = 0; k < NDW - 1; ++k) w[k] = __builtin_amdgcn_alignbyte(nx[s & (D - 1)][k + 1], nx[s & (D - 1)][k], ph);
+            }
+            fetch(min(max(r + D, rstart + ((r - rstart) & (D - 1))), rlast), nx[s & (D - 1)]);
+            if (skip) continue;
             // ---- convert this lane's PXL pixels of the wave's runs
             {
-                const uint32_t ph = (off0 + uint32_t(r) * uint32_t(a.src_stride)) & 3u;
-                uint32_t w[NDW - 1];
-#pragma unroll
-                for (int k = 0; k < NDW - 1; ++k) w[k] = __builtin_amdgcn_alignbyte(nx[k + 1], nx[k], ph);
-                fetch(min(r + 1, rlast), nx);
                 auto ub = [&](int b) { return float((w[b >> 2] >> (8 * (b & 3))) & 255u); };   // v_cvt_f32_ubyteN
                 uint32_t pk[3][NP];
 #pragma unroll
@@ -1597,7 +1629,7 @@ __global__ __launch_bounds__(kBlock, 3) void rgbin_strip_kernel(const uint8_t *_
 #pragma unroll
                 for (int c = 0; c < 8; ++c) v[c] = dot2(ringl[c][1], kl[1], dot2(ringl[c][0], kl[0], 64 << 12));
                 const u32x2_t o = {pack4<19>(v[0], v[1], v[2], v[3]), pack4<19>(v[4], v[5], v[6], v[7])};
-                if (live) *reinterpret_cast<u32x2_t *>(dy + size_t(yl) * a.dst_stride[0]) = o;
+                if (live) gstore_b64(dy + size_t(yl) * a.dst_stride[0], o);
                 ++yl;
                 next_luma();
             }
@@ -1612,8 +1644,8 @@ __global__ __launch_bounds__(kBlock, 3) void rgbin_strip_kernel(const uint8_t *_
                 }
                 const uint32_t ou = pack4<19>(au[0], au[1], au[2], au[3]), ov = pack4<19>(av[0], av[1], av[2], av[3]);
                 if (live) {
-                    *reinterpret_cast<uint32_t *>(du + size_t(yc) * a.dst_stride[1]) = ou;
-                    *reinterpret_cast<uint32_t *>(dv + size_t(yc) * a.dst_stride[1]) = ov;
+                    gstore_b32(du + size_t(yc) * a.dst_stride[1], ou);
+                    gstore_b32(dv + size_t(yc) * a.dst_stride[1], ov);
                 }
                 ++yc;
                 next_chroma();

@@ -9,9 +9,9 @@ if len(sys.argv) > 4:      # child: time one library
     import tiktoken_amd._lib as L
     if sys.argv[4] != "-": L.LIB_PATH = sys.argv[4]
     import torch, tiktoken_amd as tts
-    from sweep import CASES
+    from sweep import CASES, IN_FMT
     vf, iw, ih, algo = CASES[case]
-    plan = tts.Plan.from_vf(vf, iw, ih)
+    plan = tts.Plan.from_vf(vf, iw, ih, in_fmt=IN_FMT.get(case, "yuv420p"))
     src = torch.randint(0, 256, (frames, plan.in_bytes), dtype=torch.uint8, device="cuda")
     dst = torch.empty((frames, plan.out_bytes), dtype=torch.uint8, device="cuda")
     for _ in range(30): plan.run_batch(src, dst)
