@@ -43,6 +43,9 @@ enum { TTS_FMT_YUV420P = 0, TTS_FMT_RGB24 = 1, TTS_FMT_BGR24 = 2, TTS_FMT_RGBA =
  * (everything after it -- crop, pad -- then works on RGB pixels: no chroma-grid rounding, pad colour in
  * RGB), or, in a chain without one, in a pass of its own at the very end (after pad, borders included). */
 enum { TTS_RGB_NONE = 0, TTS_RGB_AT_SCALE = 1, TTS_RGB_AT_END = 2 };
+/* A chain FED with packed RGB (in_fmt != 0) converts inside its `scale` too (rgb_stage 0).  Without a scale the
+ * conversion pass is inserted at the end, which only matters behind a `pad`: the pad then runs on RGB pixels (any
+ * offset, colour in RGB) and the conversion reads the padded canvas, border included -- rgb_stage TTS_RGB_AT_END. */
 
 /*
  * Resolved geometry of one filter chain, in luma pixels of a yuv420p frame:
@@ -60,7 +63,7 @@ typedef struct tts_geom {
     int32_t fill_y, fill_u, fill_v;           /* pad colour */
     int32_t out_range;                        /* TTS_RANGE_*: `format=yuvj420p` / `format=yuv420p` ending the chain */
     int32_t out_fmt;                          /* TTS_FMT_*: what the chain hands out (0 = yuv420p) */
-    int32_t rgb_stage;                        /* TTS_RGB_*: where the yuv -> RGB conversion sits (0 when out_fmt is yuv420p) */
+    int32_t rgb_stage;                        /* TTS_RGB_*: where the colour conversion sits (0 when the chain stays yuv420p, or is fed RGB and has a scale or no pad) */
     int32_t fill_rgb;                         /* pad colour as 0xRRGGBB, used when the pad stage works on RGB pixels */
     int32_t in_fmt;                           /* TTS_FMT_*: what the chain is fed (tts_parse_vf_fmt); 0 = yuv420p */
 } tts_geom;

@@ -789,6 +789,32 @@ int tto_run_chain_rgbin(const tto_chain *c, const uint8_t *src, int sstride,
     uint8_t *py = buf, *pu = buf + (size_t)vw * vh, *pv = pu + (size_t)cw * chh;
     tto_chain rest = *c;
     const int pb = (c->in_fmt == TTO_FMT_RGBA || c->in_fmt == TTO_FMT_BGRA) ? 4 : 3;
+    if (c->rgb_stage == 2) {
+        /* No scale in the chain and a pad: libavfilter's negotiation (avfiltergraph.c query_formats(): vf_pad keeps ONE
+         * format list for its input and output, the source pins it to the packed format, so the link that fails to merge
+         * is the one behind the pad) puts the conversion pass at the END: vf_pad fills its canvas with the colour as RGB
+         * and copies the (cropped) picture to any offset, then one swscale context converts the canvas, border included.
+         * RECALLED, UNVERIFIED. */
+        const int W = c->out_w, H = c->out_h, cw2 = (W + 1) >> 1;
+        const int fr = (c->fill_rgb >> 16) & 255, fg = (c->fill_rgb >> 8) & 255, fb = c->fill_rgb & 255;
+        const int ro = (c->in_fmt == TTO_FMT_BGR24 || c->in_fmt == TTO_FMT_BGRA) ? 2 : 0;
+        uint8_t *canvas;
+        int rcc;
+        if (!c->do_pad || c->do_scale || c->pad_x < 0 || c->pad_y < 0 || c->pad_x + c->pre_w > W || c->pad_y + c->pre_h > H) return -1;
+        canvas = (uint8_t *)malloc((size_t)W * H * pb);
+        for (size_t i = 0; i < (size_t)W * H; i++) {
+            uint8_t *q = canvas + i * pb;
+            q[ro] = (uint8_t)fr; q[1] = (uint8_t)fg; q[2 - ro] = (uint8_t)fb;
+            if (pb == 4) q[3] = 255;                                        /* (not read) */
+        }
+        for (int y = 0; y < c->pre_h; y++)
+            memcpy(canvas + ((size_t)(c->pad_y + y) * W + c->pad_x) * pb, src + (size_t)(c->pre_y + y) * sstride + (size_t)c->pre_x * pb, (size_t)c->pre_w * pb);
+        rcc = tto_sws_packed_to_yuv420(c->in_fmt, canvas, W * pb, W, H, dy, du, dv, dys, dus, dvs, W, H, c->alg);
+        (void)cw2;
+        free(canvas);
+        free(buf);
+        return rcc;
+    }
     int rc = tto_sws_packed_to_yuv420(c->in_fmt, src + (size_t)c->pre_y * sstride + (size_t)c->pre_x * pb, sstride, c->pre_w, c->pre_h,
                                       py, pu, pv, vw, cw, cw, vw, vh, c->alg);
     if (!rc) {

@@ -297,6 +297,8 @@ def test_random_conversion_alone_both_directions(tts, oracle, seed):
         for rgb_in in (False, True):
             vf = ",".join(parts + ["format=" + ("yuv420p" if rgb_in else str(rng.choice(["rgb24", "bgr24", "rgba", "bgra"])))])
             in_fmt = str(rng.choice(["rgb24", "bgr24"])) if rgb_in else "yuv420p"   # (bgr24 at the same size: swscale's own converter for that pair, bgr24_yv12*_kernel)
+            if rgb_in and rng.random() < 0.3:                 # a pad on the RGB pixels in front of the conversion pass (any offset, even canvas width)
+                vf = ",".join(parts + ["pad=iw+%d:ih+%d:%d:%d:color=%s" % (2 * int(rng.integers(1, 9)) + (cw & 1 if parts else 0), int(rng.integers(1, 17)), int(rng.integers(0, 3)), int(rng.integers(0, 2)), rng.choice(["black", "red", "0x336699"]))])
             try:
                 plan = tts.Plan.from_vf(vf, iw, ih, in_fmt=in_fmt)
             except tts.TtsError:

@@ -698,6 +698,35 @@ def test_rgb24_input_host_path_and_rejections(tts, oracle):
     plan = tts.Plan.from_vf("scale=96:54", 64, 36, in_fmt="rgb24")
     src = rgb_frames("zone", 64, 36, 5)
     assert np.array_equal(plan.run_host(src), oracle.run_chain(plan.geom, src))
-    for vf, iw in (("scale=96:54,format=rgb24", 64), ("scale=48:27", 63), ("format=yuv420p", 63), ("pad=80:60", 64), ("format=yuvj420p", 64)):
+    for vf, iw in (("scale=96:54,format=rgb24", 64), ("scale=48:27", 63), ("format=yuv420p", 63), ("pad=81:60", 64), ("format=yuvj420p", 64)):
         with pytest.raises(tts.TtsError, match="UNSUPPORTED"):
             tts.Plan.from_vf(vf, iw, 36, in_fmt="rgb24")
+
+
+RGBIN_PAD_CASES = [
+    ("pad=80:60:7:5:color=red", 64, 36),                # an odd offset: pixel pairs straddle the picture's edges
+    ("pad=320:180:-1:-1:color=black", 102, 180),        # the reference's letterbox (src/services/video.js:331) on RGB pixels
+    ("crop=31:20:3:1,pad=80:61:-1:-1:color=0x336699", 64, 36),   # an odd picture width and an odd canvas height
+    ("pad=iw+2:ih+2:1:1:color=white", 638, 358),
+]
+
+
+@pytest.mark.parametrize("fmt", ["rgb24", "bgr24", "rgba", "bgra"])
+@pytest.mark.parametrize("vf,iw,ih", RGBIN_PAD_CASES)
+def test_packed_rgb_input_pad_without_scale(tts, oracle, vf, iw, ih, fmt):
+    """No scale in the chain: the pad runs on RGB pixels and the conversion pass libavfilter puts behind it reads the canvas
+    (oracle: tto_run_chain_rgbin, rgb_stage 2).  The kernels never store that canvas: they read through its rectangle."""
+    import torch
+    plan = tts.Plan.from_vf(vf, iw, ih, in_fmt=fmt)
+    assert plan.geom.rgb_stage == 2 and plan.kernel_name(0).endswith("+rgb_pad"), plan.kernel_name(0)
+    assert plan.kernel_name(0).startswith("bgr24_yv12" if fmt == "bgr24" else "rgbin_generic")
+    for pat in ("random", "impulse"):
+        src = repack(rgb_frames(pat, iw, ih, 3), iw, ih, fmt)
+        want = oracle.run_chain(plan.geom, src)
+        got = plan.run_batch(torch.from_numpy(src).cuda()).cpu().numpy()
+        bad = np.flatnonzero(got != want)
+        assert bad.size == 0, "%s %s %dx%d %s: %d bytes differ, first at %d" % (fmt, vf, iw, ih, pat, bad.size, bad[0])
+    # the same picture behind a scale to its own size is converted first and padded on yuv420p: a different chain
+    if "crop" not in vf:
+        other = tts.Plan.from_vf("scale=%d:%d,%s" % (iw, ih, vf), iw, ih, in_fmt=fmt)
+        assert other.geom.rgb_stage == 0 and not other.kernel_name(0).endswith("+rgb_pad")

@@ -128,6 +128,12 @@ def test_parse_vf_rgb24_input(tts):
     g = tts.parse_vf("crop=64:33:11:7,scale=128:96,pad=140:100:-1:-1", 100, 60, in_fmt="rgb24").as_dict()
     assert (g["in_fmt"], g["pre_x"], g["pre_y"], g["pre_w"], g["pre_h"]) == (1, 11, 7, 64, 33)
     assert (g["pad_x"], g["pad_y"], g["out_w"], g["out_h"], g["out_fmt"]) == (6, 2, 140, 100, 0)
+    # no scale: the pad works on RGB pixels (any offset, odd picture sizes) in front of the conversion pass: rgb_stage 2
+    g = tts.parse_vf("crop=31:20:3:1,pad=80:61:-1:-1:color=red", 64, 36, in_fmt="bgr24").as_dict()
+    assert (g["rgb_stage"], g["pre_x"], g["pre_w"], g["pad_x"], g["pad_y"], g["out_w"], g["out_h"], g["fill_rgb"]) == (2, 3, 31, 24, 20, 80, 61, 0xff0000)
+    with pytest.raises(tts.TtsError, match="UNSUPPORTED"):
+        tts.parse_vf("pad=81:60", 64, 36, in_fmt="rgb24")               # an odd canvas into the pair-summing chroma reader
+    assert tts.parse_vf("scale=64:36,pad=80:60", 64, 36, in_fmt="rgb24").as_dict()["rgb_stage"] == 0
     with pytest.raises(tts.TtsError, match="UNSUPPORTED"):
         tts.parse_vf("scale=10:10,format=rgb24", 64, 36, in_fmt="rgb24")
     with pytest.raises(tts.TtsError, match="UNSUPPORTED"):

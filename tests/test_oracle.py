@@ -197,3 +197,37 @@ def test_bgr24_same_size_takes_the_special_converter():
     # a scale in the chain, even to nearly the same size, is the scaler again (the layouts agree there: the test above)
     assert oracle.lib().tto_bgr24_special_converter(2, 16, 9, 16, 9) == 1 and oracle.lib().tto_bgr24_special_converter(2, 16, 9, 16, 10) == 0
     assert oracle.lib().tto_bgr24_special_converter(1, 16, 9, 16, 9) == 0 and oracle.lib().tto_bgr24_special_converter(4, 16, 9, 16, 9) == 0
+
+
+def test_rgb_in_pad_without_scale_runs_on_rgb_pixels():
+    """`-pix_fmt rgb24 -i ... -vf pad=...` (no scale): the pad fills RGB pixels at any offset and the conversion pass behind it
+    reads the canvas -- a pixel pair that straddles the picture's edge gives ONE chroma sample from both colours.  Known
+    answers by hand from rgb24ToY_c / rgb24ToUV_half_c (one-tap filters: 15-bit value = 2 x the 14-bit sample; constant
+    rows through the 2 : 1 vertical chroma filter stay what they are)."""
+    from oracle import oracle
+    iw, ih, W, H, px, py = 20, 40, 32, 48, 5, 4                       # an odd x: the pair (4, 5) is border + picture
+    red, grey = (255, 0, 0), (100, 100, 100)
+    g = dict(in_w=iw, in_h=ih, pre_x=0, pre_y=0, pre_w=iw, pre_h=ih, do_scale=0, sc_w=iw, sc_h=ih, alg=0, crop_x=0, crop_y=0, crop_w=iw, crop_h=ih,
+             do_pad=1, pad_x=px, pad_y=py, out_w=W, out_h=H, fill_y=81, fill_u=90, fill_v=240, out_range=0, out_fmt=0, rgb_stage=2, fill_rgb=0xff0000, in_fmt=1)
+    src = np.empty((1, ih, iw, 3), np.uint8); src[...] = grey
+    out = oracle.run_chain(g, src.reshape(1, -1))[0]
+    Y, U, V = out[:W * H].reshape(H, W), out[W * H:W * H + W * H // 4].reshape(H // 2, W // 2), out[W * H + W * H // 4:].reshape(H // 2, W // 2)
+    ry, gy, by, ru, gu, bu, rv, gv, bv = 8414, 16519, 3208, -4865, -9528, 14392, 14392, -12061, -2332
+
+    def y8(c): return (2 * ((ry * c[0] + gy * c[1] + by * c[2] + (32 << 14) + (1 << 8)) >> 9) + 64) >> 7
+    def c8(k, a, b): return (2 * ((k[0] * (a[0] + b[0]) + k[1] * (a[1] + b[1]) + k[2] * (a[2] + b[2]) + (256 << 15) + (1 << 9)) >> 10) + 64) >> 7
+    assert Y[0, 0] == y8(red) and Y[py + 3, px - 1] == y8(red) and Y[py + 3, px] == y8(grey) and Y[py + ih - 1, px + iw - 1] == y8(grey) and Y[py + ih, px] == y8(red)
+    mid = (py + ih // 2) // 2                                          # a chroma row whose 8 source rows all cross the picture
+    assert U[mid, 0] == c8((ru, gu, bu), red, red) and V[mid, 0] == c8((rv, gv, bv), red, red)
+    assert U[mid, 4] == c8((ru, gu, bu), grey, grey) and V[mid, 4] == c8((rv, gv, bv), grey, grey)
+    assert U[mid, 2] == c8((ru, gu, bu), red, grey) and V[mid, 2] == c8((rv, gv, bv), red, grey)      # canvas pixels 4 | 5
+    assert c8((ru, gu, bu), red, grey) not in (c8((ru, gu, bu), red, red), c8((ru, gu, bu), grey, grey))
+    # the same picture behind `scale=iw:ih,pad=...` is converted first and padded on yuv420p at even offsets: other bytes
+    g2 = dict(g, rgb_stage=0, pad_x=4)
+    out2 = oracle.run_chain(g2, src.reshape(1, -1))[0]
+    assert not np.array_equal(out, out2)
+    # bgr24: the canvas goes through swscale's own converter for that pair (truncating; chroma from canvas pixel (2i, 2j))
+    g3 = dict(g, in_fmt=2)
+    out3 = oracle.run_chain(g3, src[..., ::-1].copy().reshape(1, -1))[0]
+    U3 = out3[W * H:W * H + W * H // 4].reshape(H // 2, W // 2)
+    assert out3[0] == ((ry * 255) >> 15) + 16 and U3[mid, 2] == (((ru * 255) >> 15) + 128) & 255 and U3[mid, 3] == (((ru + gu + bu) * 100 >> 15) + 128) & 255

@@ -69,6 +69,10 @@ CHAINS = [
     # the default-flags run of this chain is reported, not bounded.
     ("format=yuv420p", 64, 48, "yuv420p", "bgr24"),
     ("crop=64:33:11:7", 100, 60, "yuv420p", "bgr24"),
+    # packed RGB in and a pad with no scale in front: the pad runs on RGB pixels (odd offsets allowed), the conversion pass
+    # behind it reads the canvas -- settles where libavfilter's negotiation puts that pass
+    ("pad=80:60:7:5:color=red", 64, 36, "yuv420p", "rgb24"),
+    ("pad=320:180:-1:-1:color=black", 102, 180, "yuv420p", "rgba"),
 ]
 CHAINS = [c if len(c) == 5 else c + ("yuv420p",) for c in CHAINS]
 

@@ -226,20 +226,25 @@ int check_geom(const tts_geom &g)
     if (g.in_fmt < TTS_FMT_YUV420P || g.in_fmt > TTS_FMT_BGRA) return TTS_ERR_INVALID_INPUT;
     if (g.in_fmt != TTS_FMT_YUV420P) {
         // a crop in front of the conversion works on RGB pixels (any offset); rgb24ToUV_half_c reads pixel pairs
-        if (g.out_fmt != TTS_FMT_YUV420P || g.out_range != TTS_RANGE_KEEP || ((g.pre_w & 1) && rgb_in_half_chroma(g.pre_w, g.sc_w))) return TTS_ERR_UNSUPPORTED;
-        if (bgr24_special_converter(g) && (g.pre_w & 1)) return TTS_ERR_UNSUPPORTED;   // (already covered: the same size is never an enlargement)
+        const bool canvas = g.rgb_stage == TTS_RGB_AT_END;      // (the conversion reads a padded RGB canvas: its width is checked below)
+        if (g.out_fmt != TTS_FMT_YUV420P || g.out_range != TTS_RANGE_KEEP || (!canvas && (g.pre_w & 1) && rgb_in_half_chroma(g.pre_w, g.sc_w))) return TTS_ERR_UNSUPPORTED;
+        if (!canvas && bgr24_special_converter(g) && (g.pre_w & 1)) return TTS_ERR_UNSUPPORTED;   // (already covered: the same size is never an enlargement)
     } else if (has_pre && !(even(g.pre_x) && even(g.pre_y) && even(g.pre_w) && even(g.pre_h))) return TTS_ERR_INVALID_INPUT;
     if (g.sc_w < 1 || g.sc_h < 1 || g.sc_w > 16384 || g.sc_h > 16384) return TTS_ERR_INVALID_INPUT;
     if (!g.do_scale && (g.sc_w != g.pre_w || g.sc_h != g.pre_h)) return TTS_ERR_INVALID_INPUT;
     if (g.alg < TTS_ALG_BICUBIC || g.alg > TTS_ALG_BILINEAR) return TTS_ERR_INVALID_INPUT;
     if (g.out_range < TTS_RANGE_KEEP || g.out_range > TTS_RANGE_TO_LIMITED) return TTS_ERR_INVALID_INPUT;
     if (g.out_fmt < TTS_FMT_YUV420P || g.out_fmt > TTS_FMT_BGRA) return TTS_ERR_INVALID_INPUT;
-    if ((g.out_fmt == TTS_FMT_YUV420P) != (g.rgb_stage == TTS_RGB_NONE) || g.rgb_stage < 0 || g.rgb_stage > TTS_RGB_AT_END) return TTS_ERR_INVALID_INPUT;
+    // (fed with packed RGB: TTS_RGB_AT_END marks a pad on RGB pixels in front of the conversion pass: no scale, nothing else behind it)
+    const bool rgb_pad = g.in_fmt != TTS_FMT_YUV420P && g.rgb_stage == TTS_RGB_AT_END;
+    if (rgb_pad && (!g.do_pad || g.do_scale || g.sc_w != g.pre_w || g.sc_h != g.pre_h || g.crop_x || g.crop_y || g.crop_w != g.sc_w || g.crop_h != g.sc_h)) return TTS_ERR_INVALID_INPUT;
+    if (rgb_pad && (g.out_w & 1)) return TTS_ERR_UNSUPPORTED;      // (the pair-summing chroma reader / bgr24's own converter over an odd canvas)
+    if (!rgb_pad && ((g.out_fmt == TTS_FMT_YUV420P) != (g.rgb_stage == TTS_RGB_NONE) || g.rgb_stage < 0 || g.rgb_stage > TTS_RGB_AT_END)) return TTS_ERR_INVALID_INPUT;
     // packed RGB from a full-range link (`format=yuvj420p,format=rgb24`): the range pass, then a conversion pass of its own
     if (g.out_fmt != TTS_FMT_YUV420P && g.out_range != TTS_RANGE_KEEP && !(g.out_range == TTS_RANGE_TO_FULL && g.rgb_stage == TTS_RGB_AT_END)) return TTS_ERR_UNSUPPORTED;
     if (g.fill_rgb & ~0xffffff) return TTS_ERR_INVALID_INPUT;
     // crop and pad behind an RGB-writing scale work on RGB pixels: no chroma grid
-    if (g.rgb_stage == TTS_RGB_AT_SCALE) even = [](int) { return true; };
+    if (g.rgb_stage == TTS_RGB_AT_SCALE || rgb_pad) even = [](int) { return true; };
     if (g.crop_w < 1 || g.crop_h < 1 || g.crop_x < 0 || g.crop_y < 0 ||
         g.crop_x + g.crop_w > g.sc_w || g.crop_y + g.crop_h > g.sc_h) return TTS_ERR_INVALID_INPUT;
     const bool has_crop = g.crop_x || g.crop_y || g.crop_w != g.sc_w || g.crop_h != g.sc_h;

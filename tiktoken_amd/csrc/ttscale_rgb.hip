@@ -971,8 +971,21 @@ struct RgbInArgs {
     int32_t  chr_half;                 // 1: chroma samples are pixel-pair sums (rgb24ToUV_half_c), 0: one per pixel (rgb24ToUV_c); filter.h rgb_in_half_chroma()
     int32_t  pb;                       // bytes a source pixel: 3 (rgb24, bgr24) or 4 (rgba, bgra: the fourth is ignored); coef is by byte of a pixel
     uint32_t src_origin, src_extent;   // bytes from a frame's first byte to the pre-cropped origin / to one past its last byte
+    int32_t  vs_on, vs_x, vs_y, vs_w, vs_h, vs_fill[3];   // a pad on RGB pixels in front of the conversion: the picture's rectangle in the canvas the conversion reads, the colour by byte of a pixel
     FrameAddr addr;
 };
+
+// Pixel (x, y) of the picture the conversion reads: the pre-cropped source's or, behind a pad on RGB pixels, the canvas's
+// (the picture where it was put, the pad colour around it)
+__device__ __forceinline__ void rgbin_pixel(const RgbInArgs &a, const uint8_t *sp, int x, int y, int &c0, int &c1, int &c2)
+{
+    if (a.vs_on) {
+        x -= a.vs_x; y -= a.vs_y;
+        if (x < 0 || y < 0 || x >= a.vs_w || y >= a.vs_h) { c0 = a.vs_fill[0]; c1 = a.vs_fill[1]; c2 = a.vs_fill[2]; return; }
+    }
+    const uint8_t *q = sp + size_t(y) * size_t(a.src_stride) + a.pb * x;
+    c0 = q[0]; c1 = q[1]; c2 = q[2];
+}
 
 // Where frame `frame` lies: its first source byte (dword loads must stay inside [fb, fb + src_extent)) and plane
 // `plane` of its output -- at a fixed pitch from the bases, or through the launch's offset tables (tts_run).
@@ -1009,19 +1022,20 @@ __global__ __launch_bounds__(kBlock) void rgbin_generic_kernel(const RgbInArgs a
         const int cr = a.coef[3 * plane], cg = a.coef[3 * plane + 1], cb = a.coef[3 * plane + 2];
         int val = 64 << 12;
         for (int j = 0; j < vt; ++j) {
-            const uint8_t *row = sp + size_t(vp + j) * size_t(a.src_stride);
             int acc = 0;
             for (int k = 0; k < ht; ++k) {
-                int s14;
+                int s14, q0, q1, q2;
                 if (ci == 0) {
-                    const uint8_t *q = row + a.pb * (hp + k);
-                    s14 = (cr * q[0] + cg * q[1] + cb * q[2] + (32 << 14) + (1 << 8)) >> 9;
+                    rgbin_pixel(a, sp, hp + k, vp + j, q0, q1, q2);
+                    s14 = (cr * q0 + cg * q1 + cb * q2 + (32 << 14) + (1 << 8)) >> 9;
                 } else if (a.chr_half) {
-                    const uint8_t *q = row + 2 * a.pb * (hp + k), *q2 = q + a.pb;
-                    s14 = (cr * (q[0] + q2[0]) + cg * (q[1] + q2[1]) + cb * (q[2] + q2[2]) + (256 << 15) + (1 << 9)) >> 10;
+                    int r0, r1, r2;
+                    rgbin_pixel(a, sp, 2 * (hp + k), vp + j, q0, q1, q2);
+                    rgbin_pixel(a, sp, 2 * (hp + k) + 1, vp + j, r0, r1, r2);
+                    s14 = (cr * (q0 + r0) + cg * (q1 + r1) + cb * (q2 + r2) + (256 << 15) + (1 << 9)) >> 10;
                 } else {
-                    const uint8_t *q = row + a.pb * (hp + k);
-                    s14 = (cr * q[0] + cg * q[1] + cb * q[2] + (256 << 14) + (1 << 8)) >> 9;
+                    rgbin_pixel(a, sp, hp + k, vp + j, q0, q1, q2);
+                    s14 = (cr * q0 + cg * q1 + cb * q2 + (256 << 14) + (1 << 8)) >> 9;
                 }
                 acc += s14 * int(hc[k]);
             }
@@ -1054,8 +1068,9 @@ __global__ __launch_bounds__(kBlock) void bgr24_yv12_kernel(const RgbInArgs a)
     uint32_t out = uint32_t(a.fill[plane]);
     if (y >= a.py[ci] && y < a.py[ci] + a.ph[ci] && x >= a.px[ci] && x < a.px[ci] + a.pw[ci]) {
         const int vx = (a.ox[ci] + x - a.px[ci]) << ci, vy = (a.oy[ci] + y - a.py[ci]) << ci;   // chroma: pixel (2 x, 2 y)
-        const uint8_t *q = fb + a.src_origin + size_t(vy) * size_t(a.src_stride) + 3 * size_t(vx);
-        const uint32_t s = uint32_t(a.coef[3 * plane]) * q[0] + uint32_t(a.coef[3 * plane + 1]) * q[1] + uint32_t(a.coef[3 * plane + 2]) * q[2];   // (coef: by byte of a pixel)
+        int q0, q1, q2;
+        rgbin_pixel(a, fb + a.src_origin, vx, vy, q0, q1, q2);
+        const uint32_t s = uint32_t(a.coef[3 * plane]) * uint32_t(q0) + uint32_t(a.coef[3 * plane + 1]) * uint32_t(q1) + uint32_t(a.coef[3 * plane + 2]) * uint32_t(q2);   // (coef: by byte of a pixel)
         out = ((s >> 15) + (plane ? 128u : 16u)) & 255u;
     }
     dp[size_t(y) * size_t(a.dst_stride[ci]) + x] = uint8_t(out);
@@ -2096,6 +2111,7 @@ struct RgbInPlan {
     RgbInShrinkPlan *shrink = nullptr; // shrinks with at most 8 taps across: the source-row walk of ttscale_rgbin_shrink.hip
     bool yv12 = false;                 // bgr24 at the same size: swscale's special converter (bgr24_yv12_kernel), none of the above
     bool yv12_rows = false;            // ... with nothing behind it: bgr24_yv12_rows_kernel
+    bool canvas = false;               // a pad on RGB pixels in front of the conversion (TTS_RGB_AT_END): the general kernels read the canvas through vs_*
     char name[96] = "";
 };
 
@@ -2138,8 +2154,12 @@ static bool rgbin_tile_shape(const RgbInRect &r, const AxisFilter &h, const Axis
 int rgbin_plan_create(const tts_geom &g, RgbInPlan **out)
 {
     *out = nullptr;
-    const bool half = rgb_in_half_chroma(g.pre_w, g.sc_w);           // sws_init_context()'s chrSrcHSubSample for this context
-    if (g.in_fmt == TTS_FMT_YUV420P || g.out_fmt != TTS_FMT_YUV420P || g.out_range != TTS_RANGE_KEEP || (half && (g.pre_w & 1))) {
+    // A pad on RGB pixels in front of the conversion (no scale in the chain, include/ttscale.h TTS_RGB_AT_END): the context
+    // converts the padded canvas at its own size; the kernels read it through RgbInArgs' vs_* rectangle, never stored
+    const bool canvas = g.rgb_stage == TTS_RGB_AT_END;
+    const int src_w = canvas ? g.out_w : g.pre_w, src_h = canvas ? g.out_h : g.pre_h, dst_w = canvas ? g.out_w : g.sc_w, dst_h = canvas ? g.out_h : g.sc_h;
+    const bool half = rgb_in_half_chroma(src_w, dst_w);              // sws_init_context()'s chrSrcHSubSample for this context
+    if (g.in_fmt == TTS_FMT_YUV420P || g.out_fmt != TTS_FMT_YUV420P || g.out_range != TTS_RANGE_KEEP || (half && (src_w & 1))) {
         set_last_error("packed RGB in: the chain must hand out yuv420p (no range step) and, unless it widens the picture, read an even width");
         return TTS_ERR_UNSUPPORTED;
     }
@@ -2149,22 +2169,23 @@ int rgbin_plan_create(const tts_geom &g, RgbInPlan **out)
     p->half = half;
     p->pb = packed_pixel_bytes(g.in_fmt);
     p->blue_first = packed_blue_first(g.in_fmt);
+    p->canvas = canvas;
     p->yv12 = bgr24_special_converter(g);
-    if (p->yv12 && (g.pre_w & 1)) {
+    if (p->yv12 && (src_w & 1)) {
         set_last_error("swscale's bgr24 -> yuv420p converter for pictures of the same size never writes the last column of an odd width: not supported");
         delete p;
         return TTS_ERR_UNSUPPORTED;
     }
-    const bool three = p->pb == 3 && !p->yv12;   // the walks read 3-byte pixels; 4-byte sources run the tiled / general kernels
+    const bool three = p->pb == 3 && !p->yv12 && !canvas;   // the walks read 3-byte pixels; 4-byte sources run the tiled / general kernels
     int rc = TTS_OK;
-    if (!build_axis_filter(g.pre_w, g.sc_w, 1 << 14, g.alg, p->lh) || !build_axis_filter(g.pre_h, g.sc_h, 1 << 12, g.alg, p->lv) ||
-        !build_axis_filter(half ? g.pre_w / 2 : g.pre_w, (g.sc_w + 1) >> 1, 1 << 14, g.alg, p->ch) || !build_axis_filter(g.pre_h, (g.sc_h + 1) >> 1, 1 << 12, g.alg, p->cv)) {
+    if (!build_axis_filter(src_w, dst_w, 1 << 14, g.alg, p->lh) || !build_axis_filter(src_h, dst_h, 1 << 12, g.alg, p->lv) ||
+        !build_axis_filter(half ? src_w / 2 : src_w, (dst_w + 1) >> 1, 1 << 14, g.alg, p->ch) || !build_axis_filter(src_h, (dst_h + 1) >> 1, 1 << 12, g.alg, p->cv)) {
         set_last_error("filter tables"); rc = TTS_ERR_INVALID_INPUT;
     }
     const AxisFilter *f[4] = {&p->lh, &p->lv, &p->ch, &p->cv};
     for (int i = 0; i < 4 && !rc; ++i)
         if (!upload_vec(p->d_pos[i], f[i]->pos) || !upload_vec(p->d_taps[i], f[i]->taps)) { set_last_error("table upload failed (hipMalloc / hipMemcpy)"); rc = TTS_ERR_INITIALIZATION_FAILED; }
-    if (!rc && !p->yv12 && !std::getenv("TTS_FORCE_GENERIC")) {
+    if (!rc && !p->yv12 && !canvas && !std::getenv("TTS_FORCE_GENERIC")) {
         // 32 KiB a workgroup if some tile height fits that (five workgroups on a CU's 160 KiB), else 64 KiB
         const RgbInRect r0 = rgbin_rect(g, 0), r1 = rgbin_rect(g, 1);
         for (size_t budget : {size_t(32768), size_t(65536)})        // (64 KiB: the most a workgroup gets without opting in)
@@ -2313,7 +2334,8 @@ int rgbin_plan_create(const tts_geom &g, RgbInPlan **out)
     else if (p->walk) std::snprintf(p->name, sizeof p->name, "rgbin_walk<%d>", p->cv.size);
     else if (p->strip) std::snprintf(p->name, sizeof p->name, "rgbin_strip<%d,%d,%d,%d,%dpx>", p->lh.size, p->lv.size, p->ch.size, p->cv.size, p->pxl);   // luma taps across / down, chroma taps across / down
     else if (p->tiled) std::snprintf(p->name, sizeof p->name, "rgbin_tile<%d,%d>", p->th[0], p->th[1]);
-    else std::snprintf(p->name, sizeof p->name, "rgbin_generic<%d,%d,%d,%d>", p->lh.size, p->lv.size, p->ch.size, p->cv.size);
+    else std::snprintf(p->name, sizeof p->name, "rgbin_generic<%d,%d,%d,%d>%s", p->lh.size, p->lv.size, p->ch.size, p->cv.size, canvas ? "+rgb_pad" : "");
+    if (p->yv12 && canvas) std::snprintf(p->name, sizeof p->name, "bgr24_yv12+rgb_pad");
     if (rc) { rgbin_plan_destroy(p); return rc; }
     *out = p;
     return TTS_OK;
@@ -2340,7 +2362,8 @@ int rgbin_launch(const RgbInPlan *p, const uint8_t *src, uint8_t *dst, int n, in
     a.lhtaps = p->d_taps[0]; a.lvtaps = p->d_taps[1]; a.chtaps = p->d_taps[2]; a.cvtaps = p->d_taps[3];
     a.lht = p->lh.size; a.lvt = p->lv.size; a.cht = p->ch.size; a.cvt = p->cv.size;
     for (int k = 0; k < 2; ++k) {
-        const RgbInRect r = rgbin_rect(g, k);
+        RgbInRect r = rgbin_rect(g, k);
+        if (p->canvas) r = {(g.out_w + k) >> k, (g.out_h + k) >> k, 0, 0, (g.out_w + k) >> k, (g.out_h + k) >> k, 0, 0};   // every output sample comes out of the conversion
         a.canvas_w[k] = r.canvas_w; a.canvas_h[k] = r.canvas_h;
         a.px[k] = r.px; a.py[k] = r.py; a.pw[k] = r.pw; a.ph[k] = r.ph; a.ox[k] = r.ox; a.oy[k] = r.oy;
         a.dst_stride[k] = dst_stride[k];
@@ -2352,6 +2375,11 @@ int rgbin_launch(const RgbInPlan *p, const uint8_t *src, uint8_t *dst, int n, in
     a.src_origin = uint32_t(g.pre_y) * uint32_t(src_stride) + uint32_t(g.pre_x) * uint32_t(p->pb);
     a.src_extent = uint32_t(size_t(g.in_h - 1) * size_t(src_stride) + size_t(g.in_w) * size_t(p->pb));
     a.fill[0] = g.fill_y; a.fill[1] = g.fill_u; a.fill[2] = g.fill_v;
+    if (p->canvas) {
+        a.vs_on = 1; a.vs_x = g.pad_x; a.vs_y = g.pad_y; a.vs_w = g.pre_w; a.vs_h = g.pre_h;
+        const int fr = (g.fill_rgb >> 16) & 255, fg = (g.fill_rgb >> 8) & 255, fb = g.fill_rgb & 255;
+        a.vs_fill[0] = p->blue_first ? fb : fr; a.vs_fill[1] = fg; a.vs_fill[2] = p->blue_first ? fr : fb;
+    }
     int coef[9];
     rgbin_coefficients(coef, p->blue_first);
     for (int i = 0; i < 9; ++i) a.coef[i] = coef[i];

@@ -431,10 +431,9 @@ int parse_vf(const char *vf, int iw, int ih, tts_geom &g, std::string &err, int 
                 if (y < 0 || y + ch > h) y = (h - ch) / 2;
                 if (grid() == 2) { w &= ~1; h &= ~1; x &= ~1; y &= ~1; }   // round down to the chroma grid (none on RGB)
                 if (!parse_color(o.get("color", "black"), g)) { err = "pad: unsupported colour"; return TTS_ERR_INVALID_FORMAT; }
-                if (stage == kBeforeScale && g.in_fmt != TTS_FMT_YUV420P) {
-                    // the pad would run on RGB pixels and the conversion pass behind it would resample its border
-                    err = "packed RGB in: pad needs a scale in front of it"; return TTS_ERR_UNSUPPORTED;
-                }
+                // packed RGB in and no scale in front: the pad runs on RGB pixels and the conversion pass libavfilter inserts
+                // behind it reads the padded canvas, border included (include/ttscale.h, TTS_RGB_AT_END)
+                if (stage == kBeforeScale && g.in_fmt != TTS_FMT_YUV420P) g.rgb_stage = TTS_RGB_AT_END;
                 if (stage == kBeforeScale) { g.pre_x = cx; g.pre_y = cy; g.pre_w = cw; g.pre_h = ch; g.sc_w = cw; g.sc_h = ch; cx = cy = 0; }
                 g.crop_x = cx; g.crop_y = cy; g.crop_w = cw; g.crop_h = ch;
                 g.do_pad = 1; g.pad_x = x; g.pad_y = y; g.out_w = w; g.out_h = h;
