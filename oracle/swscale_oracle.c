@@ -220,9 +220,34 @@ void tto_filter_free(tto_filter *f)
 
 static uint8_t tto_clip_u8(int v) { return v < 0 ? 0 : v > 255 ? 255 : (uint8_t)v; }
 
+/* swscale.c lumRangeToJpeg_c / chrRangeToJpeg_c / lumRangeFromJpeg_c / chrRangeFromJpeg_c on one 15-bit sample
+ * (c->lumConvertRange / chrConvertRange: run on the horizontal pass's output row, before the vertical pass).
+ * range: 1 limited -> full, 2 full -> limited.  Constants of FFmpeg 4.x-6.0, recalled, UNVERIFIED. */
+static int tto_range15(int v, int chroma, int range)
+{
+    if (range == 1) {
+        if (chroma) { if (v > 30775) v = 30775; return (v * 4663 - 9289992) >> 12; }
+        if (v > 30189) v = 30189;
+        return (v * 19077 - 39057361) >> 14;
+    }
+    if (range == 2) return chroma ? (v * 1799 + 4081085) >> 11 : (v * 14071 + 33561947) >> 14;
+    return v;
+}
+
+static int tto_scale_plane_range(const uint8_t *src, int sstride, int sw, int sh,
+                                 uint8_t *dst, int dstride, int dw, int dh, int alg, int chroma, int range);
+
 /* hScale8To15_c then yuv2planeX_8_c / yuv2plane1_8_c (dither = ff_sws_pb_64 for 8-bit sources) */
 int tto_scale_plane(const uint8_t *src, int sstride, int sw, int sh,
                     uint8_t *dst, int dstride, int dw, int dh, int alg)
+{
+    return tto_scale_plane_range(src, sstride, sw, sh, dst, dstride, dw, dh, alg, 0, 0);
+}
+
+/* ... with the range step of a context whose source and destination ranges differ (yuv420p in, yuvj420p out of the SAME
+ * scale: vf_scale is the converter when nothing pins the link behind it to yuv420p) between the two passes */
+static int tto_scale_plane_range(const uint8_t *src, int sstride, int sw, int sh,
+                                 uint8_t *dst, int dstride, int dw, int dh, int alg, int chroma, int range)
 {
     tto_filter hf, vf;
     int16_t *tmp;
@@ -237,7 +262,8 @@ int tto_scale_plane(const uint8_t *src, int sstride, int sw, int sh,
             int val = 0, p = hf.pos[x];
             for (j = 0; j < hf.size; j++) val += (int)s[p + j] * hf.coef[hf.size * x + j];
             val >>= 7;
-            t[x] = (int16_t)(val < (1 << 15) - 1 ? val : (1 << 15) - 1);
+            val = val < (1 << 15) - 1 ? val : (1 << 15) - 1;
+            t[x] = (int16_t)tto_range15(val, chroma, range);
         }
     }
     for (y = 0; y < dh; y++) {
@@ -330,8 +356,12 @@ int tto_run_chain(const tto_chain *c,
         uint8_t *scaled = NULL;
         const uint8_t *q; int qs;
         if (c->do_scale) {
+            /* rgb_stage 1 on a chain that stays yuv: `format=yuvj420p` behind the scale with nothing pinning the link to yuv420p
+             * in between -- the scale's own context converts the range (on its 15-bit rows); crop and pad behind it then work
+             * on yuvj420p (the pad colour arrives as full-range values), and no second pass follows */
+            const int in_scale = c->rgb_stage == 1 && c->out_fmt == 0 ? c->out_range : 0;
             scaled = (uint8_t *)malloc((size_t)vw * vh);
-            if (tto_scale_plane(s, sst[p], pw, ph, scaled, vw, vw, vh, c->alg)) { free(scaled); return -1; }
+            if (tto_scale_plane_range(s, sst[p], pw, ph, scaled, vw, vw, vh, c->alg, p != 0, in_scale)) { free(scaled); return -1; }
             q = scaled; qs = vw;
         } else { q = s; qs = sst[p]; }
         /* vf_crop (after scale) */
@@ -357,7 +387,7 @@ int tto_run_chain(const tto_chain *c,
      * (v = p << 7), lum/chrConvertRange on the 15-bit row (swscale.c lumRangeToJpeg_c,
      * chrRangeToJpeg_c, lumRangeFromJpeg_c, chrRangeFromJpeg_c -- constants of FFmpeg 4.x-6.0,
      * recalled, UNVERIFIED), then yuv2plane1_8_c: (v + 64) >> 7 clipped.  Borders included. */
-    if (c->out_range) {
+    if (c->out_range && !(c->rgb_stage == 1 && c->out_fmt == 0 && c->do_scale)) {
         for (int p = 0; p < 3; p++) {
             const int sub = p ? 1 : 0;
             const int ow = (c->out_w + sub) >> sub, oh = (c->out_h + sub) >> sub;

@@ -52,6 +52,8 @@ CASES = {
     "portrait_rgb24_192x108": geom(192, 108, 341, 192, crop=(116, 0, 108, 192), rgb=(1, 1, 0)),
     "thumb_pad_rgb24_72x128": geom(72, 128, 101, 180, pad=(109, 0, 320, 180), rgb=(1, 1, 0)),
     "convert_only_bgra_64x48": geom(64, 48, 64, 48, rgb=(4, 2, 0)),
+    # round 3: the scale itself writes yuvj420p (range step on its 15-bit rows, between the passes; the pad colour in full range)
+    "scale_writes_yuvj_72x128": dict(geom(72, 128, 101, 180, pad=(108, 0, 320, 180), fill=(0, 128, 128), out_range=1), out_fmt=0, rgb_stage=1, fill_rgb=0),
     # round 3: rows through swscale's 2-line writer (bilinear enlargement to RGB), and RGB from a full-range link
     "bilinear_rgb24_64x48_to_128x96": geom(64, 48, 128, 96, alg=2, rgb=(1, 1, 0)),
     "thumb_pad_jpeg_rgb24_72x128": geom(72, 128, 101, 180, pad=(108, 0, 320, 180), out_range=1, rgb=(1, 2, 0)),

@@ -31,8 +31,8 @@ def _case(rng):
         vf += ",crop=%d:%d" % (int(rng.integers(8, ow)), int(rng.integers(8, oh)))
     if rng.random() < 0.2:
         vf += ",pad=iw+%d:ih+%d:-1:-1:color=black" % (2 * int(rng.integers(0, 20)), 2 * int(rng.integers(0, 20)))
-    if rng.random() < 0.15:
-        vf += ",format=yuvj420p"
+    if rng.random() < 0.15:                                  # the range step: inside the scale's context, or pinned to a pass of its own
+        vf += str(rng.choice([",format=yuvj420p", ",format=yuv420p,format=yuvj420p"]))
     return vf, iw, ih, int(rng.choice([1, 2, 3, 7, 19, 70]))
 
 

@@ -40,7 +40,9 @@ CASES = [
     ("scale=iw/2:-2,pad=iw+20:ih+10:10:4:color=red", 200, 150),
     ("format=yuv420p", 64, 48),                        # identity
     (THUMB_REF + ",format=yuvj420p", 720, 1280),       # video.js:329-334: the mjpeg encoder's full-range pass, borders included
-    ("scale=320:180,format=yuvj420p", 1280, 720),
+    ("scale=320:180,format=yuvj420p", 1280, 720),      # the scale itself writes yuvj420p: its context converts the range between its two passes
+    ("scale=320:180,format=yuv420p,format=yuvj420p", 1280, 720),   # pinned to yuv420p first (the reference's chain): a range pass of its own at the end
+    ("scale=301:171:flags=area,crop=200:100:40:30,pad=240:128:-1:-1:color=red,format=yuvj420p", 1280, 720),   # ... crop and pad then work on yuvj420p: the pad colour in full range
     ("format=yuvj420p", 64, 48),                       # range step alone
 ]
 
@@ -489,7 +491,7 @@ def test_more_planes_than_grid_z(tts, oracle):
     (65,535 at most), so the launch is repeated over frame ranges."""
     import torch
     iw, ih, n, distinct = 16, 16, 40000, 5
-    plan = tts.Plan.from_vf("scale=24:20,pad=32:24:-1:-1:color=white,format=yuvj420p", iw, ih)
+    plan = tts.Plan.from_vf("scale=24:20,pad=32:24:-1:-1:color=white,format=yuv420p,format=yuvj420p", iw, ih)
     base = synth.frames("random", iw, ih, distinct)
     want = torch.from_numpy(oracle.run_chain(plan.geom, base)).cuda()
     src = torch.from_numpy(base).cuda().repeat(n // distinct, 1).contiguous()
@@ -580,7 +582,7 @@ def test_runs_under_hip_graph_capture(tts, oracle):
     and replay it: capture on a side stream, replay with new frames in the same buffers."""
     import torch
     iw, ih, n = 320, 180, 6
-    plan = tts.Plan.from_vf("scale=320x180:force_original_aspect_ratio=decrease,pad=320x180:-1:-1:color=black,format=yuvj420p", 180, 320)
+    plan = tts.Plan.from_vf("scale=320x180:force_original_aspect_ratio=decrease,pad=320x180:-1:-1:color=black,format=yuv420p,format=yuvj420p", 180, 320)
     plan2 = tts.Plan.from_vf("scale=568:320", iw, ih)
     a = synth.frames("random", 180, 320, n)
     b = synth.frames("random", iw, ih, n)

@@ -57,6 +57,10 @@ PARSE_CASES = [
     ("scale=320x180:force_original_aspect_ratio=decrease,pad=320x180:-1:-1:color=black,format=yuv420p,format=yuvj420p", 720, 1280,
      dict(sc_w=101, sc_h=180, do_pad=1, pad_x=108, out_range=1)),
     ("format=pix_fmts=yuvj420p", 64, 48, dict(do_scale=0, out_range=1)),
+    # the scale itself writes yuvj420p unless a format=yuv420p pins the link behind it: range step inside its context, pad colour in full range
+    ("scale=32:24,pad=40:30:-1:-1:color=red,format=yuvj420p", 64, 48, dict(do_scale=1, out_range=1, rgb_stage=1, fill_y=76, fill_u=85, fill_v=255)),
+    ("scale=32:24,pad=40:30:-1:-1:color=red,format=yuv420p,format=yuvj420p", 64, 48, dict(do_scale=1, out_range=1, rgb_stage=0, fill_y=81, fill_u=90, fill_v=240)),
+    ("scale=64:48,format=yuvj420p", 64, 48, dict(do_scale=0, out_range=1, rgb_stage=0)),
     # ff_scale_adjust_dimensions: the aspect-derived size is rounded to the NEAREST multiple of force_divisible_by
     # first (101.25 -> 102), then min'ed and rounded down
     ("scale=320:180:force_original_aspect_ratio=decrease:force_divisible_by=2", 720, 1280, dict(sc_w=102, sc_h=180)),
@@ -87,7 +91,7 @@ def test_parse_vf(tts, vf, iw, ih, want):
 
 @pytest.mark.parametrize("vf,name", [
     ("hflip", "INVALID_FORMAT"), ("scale=abc:def", "INVALID_FORMAT"), ("scale=10:10:flags=lanczos", "UNSUPPORTED"),
-    ("format=gray", "UNSUPPORTED"), ("format=rgb24,crop=10:10", "UNSUPPORTED"), ("format=yuvj420p,scale=64:36,format=rgb24", "UNSUPPORTED"),
+    ("format=gray", "UNSUPPORTED"), ("format=rgb24,crop=10:10", "UNSUPPORTED"), ("format=yuvj420p,scale=64:36,format=rgb24", "UNSUPPORTED"), ("format=yuvj420p,scale=64:36", "UNSUPPORTED"), ("scale=64:36,format=yuvj420p,format=rgb24", "UNSUPPORTED"),
     ("crop=4000:10", "INVALID_INPUT"), ("pad=10:10", "INVALID_INPUT"),
     ("scale=64:64,scale=32:32", "UNSUPPORTED"), ("scale=100:100:unknown=1", "INVALID_FORMAT"),
 ])

@@ -231,3 +231,37 @@ def test_rgb_in_pad_without_scale_runs_on_rgb_pixels():
     out3 = oracle.run_chain(g3, src[..., ::-1].copy().reshape(1, -1))[0]
     U3 = out3[W * H:W * H + W * H // 4].reshape(H // 2, W // 2)
     assert out3[0] == ((ry * 255) >> 15) + 16 and U3[mid, 2] == (((ru * 255) >> 15) + 128) & 255 and U3[mid, 3] == (((ru + gu + bu) * 100 >> 15) + 128) & 255
+
+
+def test_range_step_inside_the_scale_context():
+    """`scale=...,format=yuvj420p` with nothing pinning the link to yuv420p in between: the scale's own context writes
+    yuvj420p, so lumRangeToJpeg_c / chrRangeToJpeg_c run on its 15-bit rows BETWEEN the two passes (rgb_stage 1 on a chain that
+    stays yuv); behind `format=yuv420p` the step is a pass of its own on the finished bytes.  Rows that are constant across
+    (the horizontal pass then gives p << 7 exactly) make both forms computable by hand from the vertical taps."""
+    from oracle import oracle
+    iw, ih, ow, oh = 16, 12, 16, 30
+    rng = np.random.default_rng(3)
+    rows_y, rows_c = rng.integers(0, 256, ih), rng.integers(0, 256, ih // 2)
+    frame = np.concatenate([np.repeat(rows_y, iw), np.repeat(rows_c, iw // 2), np.repeat(rows_c[::-1], iw // 2)]).astype(np.uint8)
+    g = dict(in_w=iw, in_h=ih, pre_x=0, pre_y=0, pre_w=iw, pre_h=ih, do_scale=1, sc_w=ow, sc_h=oh, alg=0, crop_x=0, crop_y=0, crop_w=ow, crop_h=oh,
+             do_pad=0, pad_x=0, pad_y=0, out_w=ow, out_h=oh, fill_y=16, fill_u=128, fill_v=128, out_range=1, out_fmt=0, rgb_stage=1, fill_rgb=0, in_fmt=0)
+    inside = oracle.run_chain(g, frame[None])[0]
+    at_end = oracle.run_chain(dict(g, rgb_stage=0), frame[None])[0]
+
+    def lum15(v): return (min(v, 30189) * 19077 - 39057361) >> 14
+    def chr15(v): return (min(v, 30775) * 4663 - 9289992) >> 12
+    def clip(v): return max(0, min(255, v))
+    for name, rows, n_out, f15, off in (("luma", rows_y, oh, lum15, 0), ("chroma", rows_c, oh // 2, chr15, ow * oh)):
+        coef, pos = oracle.filter_table(len(rows), n_out, 1 << 12)
+        w = ow if name == "luma" else ow // 2
+        for y in range(n_out):
+            taps = [(int(coef[y, j]), int(rows[pos[y] + j]) << 7) for j in range(coef.shape[1])]
+            want_inside = clip(((64 << 12) + sum(t * f15(v) for t, v in taps)) >> 19)
+            plain = clip(((64 << 12) + sum(t * v for t, v in taps)) >> 19)
+            want_end = clip((f15(plain << 7) + 64) >> 7)
+            assert inside[off + y * w] == want_inside and at_end[off + y * w] == want_end, (name, y)
+    assert not np.array_equal(inside, at_end)
+    # no resizing: one-tap filters around the step either way -- the same bytes
+    g1 = dict(g, do_scale=0, sc_w=iw, sc_h=ih, crop_w=iw, crop_h=ih, out_w=iw, out_h=ih, rgb_stage=0)
+    a = oracle.run_chain(g1, frame[None])[0]
+    assert a[0] == clip((lum15(int(rows_y[0]) << 7) + 64) >> 7)

@@ -64,6 +64,9 @@ CHAINS = [
     # RGB from a full-range link and through swscale's 1- / 2-line packed writers, round 3
     (THUMB_REF + ",format=yuvj420p,format=rgb24", 720, 1280, "rgb24"),
     ("scale=128:96:flags=bilinear,format=rgb24", 64, 48, "rgb24"),
+    # the scale itself writes yuvj420p (nothing pins the link behind it to yuv420p): its context converts the range between its passes
+    ("scale=320:180,format=yuvj420p", 1280, 720, "yuvj420p"),
+    ("scale=301:171:flags=area,crop=200:100:40:30,pad=240:128:-1:-1:color=red,format=yuvj420p", 1280, 720, "yuvj420p"),
     # bgr24 in at the same size: swscale_unscaled.c's bgr24toYV12 converter (ff_rgb24toyv12_c), which accurate_rnd would
     # switch off -- run with `bitexact` alone.  x86 builds replace that function with SIMD that averages 2 x 2 chroma:
     # the default-flags run of this chain is reported, not bounded.

@@ -239,12 +239,16 @@ int check_geom(const tts_geom &g)
     const bool rgb_pad = g.in_fmt != TTS_FMT_YUV420P && g.rgb_stage == TTS_RGB_AT_END;
     if (rgb_pad && (!g.do_pad || g.do_scale || g.sc_w != g.pre_w || g.sc_h != g.pre_h || g.crop_x || g.crop_y || g.crop_w != g.sc_w || g.crop_h != g.sc_h)) return TTS_ERR_INVALID_INPUT;
     if (rgb_pad && (g.out_w & 1)) return TTS_ERR_UNSUPPORTED;      // (the pair-summing chroma reader / bgr24's own converter over an odd canvas)
-    if (!rgb_pad && ((g.out_fmt == TTS_FMT_YUV420P) != (g.rgb_stage == TTS_RGB_NONE) || g.rgb_stage < 0 || g.rgb_stage > TTS_RGB_AT_END)) return TTS_ERR_INVALID_INPUT;
+    // (a chain that stays yuv420p: TTS_RGB_AT_SCALE marks a RANGE step inside the scale's own context -- `format=yuvj420p` behind
+    // a scale with nothing pinning the link in between; crop and pad behind it then work on yuvj420p)
+    const bool range_in_scale = g.in_fmt == TTS_FMT_YUV420P && g.out_fmt == TTS_FMT_YUV420P && g.rgb_stage == TTS_RGB_AT_SCALE;
+    if (range_in_scale && (!g.do_scale || g.out_range == TTS_RANGE_KEEP)) return TTS_ERR_INVALID_INPUT;
+    if (!rgb_pad && !range_in_scale && ((g.out_fmt == TTS_FMT_YUV420P) != (g.rgb_stage == TTS_RGB_NONE) || g.rgb_stage < 0 || g.rgb_stage > TTS_RGB_AT_END)) return TTS_ERR_INVALID_INPUT;
     // packed RGB from a full-range link (`format=yuvj420p,format=rgb24`): the range pass, then a conversion pass of its own
     if (g.out_fmt != TTS_FMT_YUV420P && g.out_range != TTS_RANGE_KEEP && !(g.out_range == TTS_RANGE_TO_FULL && g.rgb_stage == TTS_RGB_AT_END)) return TTS_ERR_UNSUPPORTED;
     if (g.fill_rgb & ~0xffffff) return TTS_ERR_INVALID_INPUT;
     // crop and pad behind an RGB-writing scale work on RGB pixels: no chroma grid
-    if (g.rgb_stage == TTS_RGB_AT_SCALE || rgb_pad) even = [](int) { return true; };
+    if ((g.rgb_stage == TTS_RGB_AT_SCALE && !range_in_scale) || rgb_pad) even = [](int) { return true; };
     if (g.crop_w < 1 || g.crop_h < 1 || g.crop_x < 0 || g.crop_y < 0 ||
         g.crop_x + g.crop_w > g.sc_w || g.crop_y + g.crop_h > g.sc_h) return TTS_ERR_INVALID_INPUT;
     const bool has_crop = g.crop_x || g.crop_y || g.crop_w != g.sc_w || g.crop_h != g.sc_h;

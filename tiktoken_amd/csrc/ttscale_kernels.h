@@ -1044,6 +1044,7 @@ struct GenericArgs {
     int32_t src_stride, dst_stride;
     int32_t planes, plane0;
     int32_t frame0;                    // first frame of this launch (grid.z holds at most 65535 planes)
+    int32_t range15;                   // TTS_RANGE_*: the context's own range step on the 15-bit rows between the passes (0: none)
     FrameAddr addr;
 };
 
@@ -1073,9 +1074,12 @@ __global__ __launch_bounds__(kBlock) void generic_kernel(const GenericArgs a)
         for (int k = 0; k < a.ht; ++k) acc += int(row[k]) * int(hc[k]);
         acc >>= 7;
         acc = acc < 32767 ? acc : 32767;
+        // swscale.c lumRangeToJpeg_c / chrRangeToJpeg_c / lumRangeFromJpeg_c / chrRangeFromJpeg_c (c->lumConvertRange, chrConvertRange)
+        if (a.range15 == TTS_RANGE_TO_FULL) acc = plane ? (min(acc, 30775) * 4663 - 9289992) >> 12 : (min(acc, 30189) * 19077 - 39057361) >> 14;
+        else if (a.range15 == TTS_RANGE_TO_LIMITED) acc = plane ? (acc * 1799 + 4081085) >> 11 : (acc * 14071 + 33561947) >> 14;
         val += acc * int(vc[j]);
     }
-    val >>= 19;
+    val >>= 19;                                            // (a one-tap vertical filter gives (t + 64) >> 7: the same value)
     val = val < 0 ? 0 : val > 255 ? 255 : val;
     a.dst[doff + size_t(y) * size_t(a.dst_stride) + x] = uint8_t(val);
 }

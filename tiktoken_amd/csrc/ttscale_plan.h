@@ -309,11 +309,15 @@ int build_class(const tts_geom &g, int sub, ClassPlan &c, std::vector<uint32_t> 
     const int HT = c.h.size, VT = c.v.size;
     const int LW = HT <= 4 ? 4 : 8;
     const int R = VT <= 4 ? 4 : VT <= 6 ? 6 : 8;
+    // A range step INSIDE the scale's context (filter.cpp check_geom: `format=yuvj420p` right behind the scale) converts the
+    // 15-bit rows between the two passes: the general kernel alone carries that (GenericArgs.range15); speed later
+    const bool range_in_scale = g.in_fmt == TTS_FMT_YUV420P && g.out_fmt == TTS_FMT_YUV420P && g.rgb_stage == TTS_RGB_AT_SCALE;
     const bool strip_ok = !force_column && HT <= 8 && VT <= 8 && c.src_w >= LW && monotone(c.v.pos) &&
-                          !env_int("TTS_FORCE_GENERIC", 0);
+                          !env_int("TTS_FORCE_GENERIC", 0) && !range_in_scale;
     if (!strip_ok) {
         // Many taps: the column walk, if the taps fit its windows and ring and the runs fit its slot.
         c.kind = 0;
+        if (range_in_scale) return TTS_OK;
         // one instantiation per 4 taps of the larger tap count of the two axes: 6, 8, ... 32 tap pairs
         // (windows of 2 NTP bytes, ring of 2 NTP rows) -- the work is one v_perm + v_dot2 per tap pair per
         // source row, so a window cut to fit the taps is that much less arithmetic
@@ -827,8 +831,11 @@ int launch_all(const tts_plan *p, const uint8_t *src, uint8_t *dst, int n, const
         // store int16 luma; the caller falls back)
         if (p->y16 && (c.kind == 0 || to_generic[ci]) && active(ci)) { g_last_error = "scratch pass needs the column walk or an LDS strip kernel"; return TTS_ERR_UNSUPPORTED; }
     }
+    // (a range step inside the scale's context is the general kernel's business: nothing follows it here)
+    const bool range_in_scale = p->g.in_fmt == TTS_FMT_YUV420P && p->g.out_fmt == TTS_FMT_YUV420P && p->g.rgb_stage == TTS_RGB_AT_SCALE;
+    const int range_at_end = range_in_scale ? TTS_RANGE_KEEP : p->g.out_range;
     RangeStep range{};
-    if (p->g.out_range != TTS_RANGE_KEEP) {
+    if (range_at_end != TTS_RANGE_KEEP) {
         range.on = 1;
         for (int ci = 0; ci < 2; ++ci)
             if (!tts::range_affine(p->g.out_range, ci != 0, range.mul[ci], range.add[ci], range.shift[ci])) range.on = 0;
@@ -1046,6 +1053,7 @@ int launch_all(const tts_plan *p, const uint8_t *src, uint8_t *dst, int n, const
         a.x0 = c.x0; a.y0 = c.y0; a.ow = c.ow; a.oh = c.oh;
         a.src_stride = src_stride[ci]; a.dst_stride = dst_stride[ci];
         a.planes = nplanes(ci); a.plane0 = plane0(ci);
+        a.range15 = range_in_scale ? p->g.out_range : 0;
         a.addr = addr;
         z_launches(a.planes, [&](int f0, int nf) {
             a.frame0 = f0;
@@ -1054,7 +1062,7 @@ int launch_all(const tts_plan *p, const uint8_t *src, uint8_t *dst, int n, const
         });
         if (lrc) return lrc;
     }
-    if (p->g.out_range != TTS_RANGE_KEEP) {
+    if (range_at_end != TTS_RANGE_KEEP) {
         for (int ci = 0; ci < 2; ++ci) {
             if (!active(ci) || (fuse_range && !to_generic[ci])) continue;
             const ClassPlan &c = p->cls[ci];

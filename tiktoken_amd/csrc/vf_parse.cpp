@@ -8,6 +8,7 @@
 // and resolves them with libavfilter's sizing rules into a tts_geom.
 #include "filter.h"
 
+#include <algorithm>
 #include <cctype>
 #include <cmath>
 #include <cstring>
@@ -199,6 +200,15 @@ void rgb_to_yuv(int r, int g, int b, tts_geom &o)
                  fix(0.08131 * 224.0 / 255.0) * b + 511) >> 10) + 128;
 }
 
+// RGB -> full-range BT.601 (a pad on a yuvj420p link): libavutil/colorspace.h RGB_TO_Y_JPEG / RGB_TO_U_JPEG / RGB_TO_V_JPEG
+void rgb_to_yuv_full(int r, int g, int b, tts_geom &o)
+{
+    auto fix = [](double v) { return int(v * 1024 + 0.5); };
+    o.fill_y = std::min((fix(0.29900) * r + fix(0.58700) * g + fix(0.11400) * b + 512) >> 10, 255);
+    o.fill_u = ((-fix(0.16874) * r - fix(0.33126) * g + fix(0.50000) * b + 511) >> 10) + 128;
+    o.fill_v = ((fix(0.50000) * r - fix(0.41869) * g - fix(0.08131) * b + 511) >> 10) + 128;
+}
+
 int parse_pix_fmt(const std::string &f)
 {
     if (f == "yuv420p" || f == "yuvj420p") return TTS_FMT_YUV420P;
@@ -278,20 +288,36 @@ int parse_vf(const char *vf, int iw, int ih, tts_geom &g, std::string &err, int 
     // that link to yuv, or the chain has no scale; then a conversion pass of its own is inserted in front of
     // the `format` filter, i.e. at the very end.  First pass over the chain: find that out, because every
     // filter between the conversion and the end then works on RGB pixels (no chroma grid to round to).
+    // The same negotiation decides where a RANGE step sits: `format=yuvj420p` behind a scale, with nothing pinning the link
+    // to yuv420p in between, makes that scale's own context convert the range (on its 15-bit rows, between the two passes;
+    // crop and pad behind it then work on yuvj420p); behind a `format=yuv420p` -- the reference's thumbnail chain -- or in
+    // a chain without a scale it is a pass of its own at the end.
+    bool range_in_scale = false;
     try {
-        bool seen_scale = false, yuv_pinned = false;
+        bool seen_scale = false, yuv_pinned = false, link_full = false;
         for (const std::string &raw : split(vf, ',')) {
             const std::string f = trim(raw);
             if (f.empty()) continue;
             const size_t eq = f.find('=');
             const std::string name = trim(f.substr(0, eq));
             if (g.out_fmt != TTS_FMT_YUV420P && name != "setsar") { err = "an RGB format must end the chain"; return TTS_ERR_UNSUPPORTED; }
-            if (name == "scale") { seen_scale = true; yuv_pinned = false; }
+            if (name == "scale") {
+                if (link_full) { err = "format=yuvj420p in front of the scale: the range step would run first, at the source's size: not supported"; return TTS_ERR_UNSUPPORTED; }
+                seen_scale = true; yuv_pinned = false;
+            }
             if (name != "format") continue;
             const std::string pf = format_arg(eq == std::string::npos ? "" : f.substr(eq + 1));
             const int fmt = parse_pix_fmt(pf);
             if (fmt < 0) { err = "format: only yuv420p, yuvj420p, rgb24, bgr24, rgba, bgra are supported"; return TTS_ERR_UNSUPPORTED; }
+            if (pf == "yuvj420p") {
+                if (seen_scale && !yuv_pinned && !link_full && g.in_fmt == TTS_FMT_YUV420P) range_in_scale = true;
+                link_full = true;
+            } else if (pf == "yuv420p") {
+                if (range_in_scale) { err = "format=yuv420p behind a scale that writes yuvj420p: not supported"; return TTS_ERR_UNSUPPORTED; }
+                link_full = false;
+            }
             if (fmt == TTS_FMT_YUV420P) { yuv_pinned = true; continue; }
+            if (range_in_scale) { err = "packed RGB behind a scale that writes yuvj420p: write format=yuv420p,format=yuvj420p in front of it (a range pass of its own)"; return TTS_ERR_UNSUPPORTED; }
             // (RGB from a full-range link, `format=yuvj420p,format=rgb24`: the range pass stays in out_range and the conversion
             // pass behind it reads a yuvj420p source -- full-range yuv2rgb tables; yuv_pinned is set, so it sits at the end)
             g.out_fmt = fmt;
@@ -452,6 +478,15 @@ int parse_vf(const char *vf, int iw, int ih, tts_geom &g, std::string &err, int 
     if (stage != kAfterPad) {
         g.crop_x = cx; g.crop_y = cy; g.crop_w = cw; g.crop_h = ch;
         g.out_w = cw; g.out_h = ch;
+    }
+    if (range_in_scale && g.out_range == TTS_RANGE_TO_FULL) {
+        if (g.do_scale) {
+            g.rgb_stage = TTS_RGB_AT_SCALE;
+            // the pad sits on a yuvj420p link: drawutils.c ff_draw_color() with full_range, libavutil/colorspace.h RGB_TO_Y_JPEG & co.
+            if (g.do_pad) rgb_to_yuv_full((g.fill_rgb >> 16) & 255, (g.fill_rgb >> 8) & 255, g.fill_rgb & 255, g);
+        } else if (g.do_pad) {
+            err = "a scale to the same size that writes yuvj420p, then a pad: not supported"; return TTS_ERR_UNSUPPORTED;
+        }   // (else: the same bytes as a pass of its own -- one-tap filters around the range step)
     }
     const int rc = check_geom(g);
     if (rc) err = "resolved geometry is invalid";
