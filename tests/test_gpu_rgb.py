@@ -538,6 +538,7 @@ BGR24_SAME_SIZE_CASES = [
     ("scale=100:60,crop=64:32:12:8", 100, 60),          # a scale to the same size is still that converter; the crop behind it is planar
     ("scale=100:60,pad=128:96:-1:-1:color=red", 100, 60),
     ("crop=80:40:3:5,scale=80:40,crop=64:32,pad=96:64:-1:-1", 100, 60),
+    ("crop=80:40:3:5,format=yuv420p,crop=64:32,pad=96:64:-1:-1", 100, 60),   # format=yuv420p as the conversion point: the same chain
 ]
 
 

@@ -138,6 +138,11 @@ def test_parse_vf_rgb24_input(tts):
     with pytest.raises(tts.TtsError, match="UNSUPPORTED"):
         tts.parse_vf("pad=81:60", 64, 36, in_fmt="rgb24")               # an odd canvas into the pair-summing chroma reader
     assert tts.parse_vf("scale=64:36,pad=80:60", 64, 36, in_fmt="rgb24").as_dict()["rgb_stage"] == 0
+    # a format=yuv420p in front of everything else is where the conversion pass goes: behind it the chain sees yuv420p
+    g = tts.parse_vf("crop=32:20:3:1,format=yuv420p,crop=16:10:2:2,pad=40:30", 64, 36, in_fmt="rgb24").as_dict()
+    assert (g["pre_x"], g["pre_y"], g["pre_w"], g["do_scale"], g["crop_x"], g["crop_y"], g["crop_w"], g["do_pad"], g["rgb_stage"]) == (3, 1, 32, 0, 2, 2, 16, 1, 0)
+    with pytest.raises(tts.TtsError, match="two swscale contexts"):
+        tts.parse_vf("format=yuv420p,scale=96:54", 64, 36, in_fmt="rgb24")
     with pytest.raises(tts.TtsError, match="UNSUPPORTED"):
         tts.parse_vf("scale=10:10,format=rgb24", 64, 36, in_fmt="rgb24")
     with pytest.raises(tts.TtsError, match="UNSUPPORTED"):

@@ -280,6 +280,7 @@ int parse_vf(const char *vf, int iw, int ih, tts_geom &g, std::string &err, int 
     g.fill_y = 16; g.fill_u = 128; g.fill_v = 128;
 
     enum { kBeforeScale, kAfterScale, kAfterPad } stage = kBeforeScale;
+    bool converted_by_format = false;       // packed RGB in: a format=yuv420p stood where a scale would have converted
     int cw = iw, ch = ih;                   // size of the picture at the current point of the chain
     int cx = 0, cy = 0;                     // accumulated crop origin at the current stage
 
@@ -346,6 +347,15 @@ int parse_vf(const char *vf, int iw, int ih, tts_geom &g, std::string &err, int 
             if (name == "format" || name == "setsar") {
                 if (name == "format") {
                     const std::string pf = format_arg(args);
+                    // fed with packed RGB: a `format=yuv420p` in front of every scale is where the conversion pass goes (a context
+                    // of its own, same size) -- the rest of the chain sees yuv420p, exactly as behind a scale to the same size
+                    if (g.in_fmt != TTS_FMT_YUV420P && stage == kBeforeScale && (pf == "yuv420p" || pf == "yuvj420p")) {
+                        g.pre_x = cx; g.pre_y = cy; g.pre_w = cw; g.pre_h = ch;
+                        g.do_scale = 0; g.sc_w = cw; g.sc_h = ch;
+                        cx = cy = 0;
+                        stage = kAfterScale;
+                        converted_by_format = true;
+                    }
                     // yuvj420p = the same planes in full range: the range step of a second, unscaled swscale pass
                     if (pf == "yuvj420p") g.out_range = TTS_RANGE_TO_FULL;
                     else if (pf == "yuv420p") g.out_range = TTS_RANGE_KEEP;
@@ -355,6 +365,7 @@ int parse_vf(const char *vf, int iw, int ih, tts_geom &g, std::string &err, int 
             if (stage == kAfterPad) { err = "no filter may follow pad"; return TTS_ERR_UNSUPPORTED; }
 
             if (name == "scale") {
+                if (converted_by_format) { err = "packed RGB in: a scale behind the format=yuv420p that converts (two swscale contexts): not supported"; return TTS_ERR_UNSUPPORTED; }
                 if (stage != kBeforeScale) { err = "only one scale per chain"; return TTS_ERR_UNSUPPORTED; }
                 Options o = parse_options(args, {"w", "h", "flags"},
                     {{"width", "w"}, {"height", "h"}, {"size", "s"}, {"sws_flags", "flags"}});
