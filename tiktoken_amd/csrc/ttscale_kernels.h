@@ -30,6 +30,9 @@ struct StripClass {
 // pass computes (p << 7, lum/chrRangeToJpeg_c, (v + 64) >> 7), folded (the host checks it against
 // build_range_lut for all 256 values before a plan uses it).
 struct RangeStep { int32_t on; int32_t mul[2], add[2], shift[2]; };
+// The range step of a context that converts the range ITSELF (`scale=...,format=yuvj420p`): swscale.c lumRangeToJpeg_c & co.
+// on the 15-bit rows between the two passes, (min(v, cap) * mul + add) >> shift per plane class (column_lds_kernel<..., RNG>)
+struct RangeStep15 { int32_t cap[2], mul[2], add[2], shift[2]; };
 
 // The pad border of one plane class, written by extra workgroups of the SAME launch (they follow the scaler's
 // workgroups in the logical block order).  Only the border is tiled: the full-width rows above and below the
@@ -60,6 +63,7 @@ struct StripArgs {
     // queue == nullptr: one workgroup per logical block, grid_scaler == scaler_blocks.
     uint32_t grid_scaler;
     uint32_t *queue;
+    RangeStep15 r15;               // column walk, RNG instantiations only
     int32_t  y16;                  // column walk only: class 0 (luma) stores its UNCLIPPED vertical sums as int16 (2 bytes a column): the
                                    // intermediate of the packed-RGB thumbnail path (ttscale_rgb.hip rgb_scratch_convert_kernel)
     uint64_t *dbg;                 // -DTTS_EXPERIMENTS builds: (start, end) clock of every workgroup of strip_lds_kernel; else null, unused
@@ -822,7 +826,8 @@ __device__ __forceinline__ void lds_read_dwords(uint32_t (&w)[NDW], uint32_t p)
 // one LDS read and one xor pass for both; column 1's digits sit `delta` bytes further on.  (Its dword 0 holds
 // taps only where swscale folded windows at a row's edge -- but two waves in five hold such a strip, a branch
 // around that pair of v_dot4 cost 50 % when taken, and if-converted it cost six instructions: it just runs.)
-template <int NTP, int R, int NDMA, int NC, int D = 1, bool D4 = false>
+// RNG: the context's own range step on the 15-bit rows (StripArgs.r15), between hfinish and the ring.
+template <int NTP, int R, int NDMA, int NC, int D = 1, bool D4 = false, bool RNG = false>
 __global__ __launch_bounds__(kBlock, (D4 && NC == 2 && NTP == 12 && NDMA == 1) ? 6 : 1) void column_lds_kernel(const uint8_t *__restrict__ src, uint8_t *__restrict__ dst,
                                                             const uint32_t *__restrict__ tab, const StripArgs a)
 {
@@ -929,6 +934,7 @@ __global__ __launch_bounds__(kBlock, (D4 && NC == 2 && NTP == 12 && NDMA == 1) ?
     const int dst_stride = int(uni(uint32_t(c.dst_stride)));
     const bool rng = a.range.on != 0;
     const int rmul = a.range.mul[ci], radd = a.range.add[ci], rsh = a.range.shift[ci];
+    [[maybe_unused]] const int r15cap = a.r15.cap[ci], r15mul = a.r15.mul[ci], r15add = a.r15.add[ci], r15sh = a.r15.shift[ci];
 
     const __amdgpu_buffer_rsrc_t srs = __builtin_amdgcn_make_buffer_rsrc(const_cast<uint8_t *>(wsrc), 0, src_rec, 0x00020000);
     const uint64_t dbase = reinterpret_cast<uint64_t>(wdst);
@@ -992,7 +998,8 @@ __global__ __launch_bounds__(kBlock, (D4 && NC == 2 && NTP == 12 && NDMA == 1) ?
                     for (int tp = 0; tp < NTP; ++tp)
                         acc = dot2(__builtin_amdgcn_perm(w[j][tp / 2 + 1], w[j][tp / 2], psel[j][tp % 2]), hc[j][tp], acc);
                 }
-                const uint32_t t = hfinish(acc);
+                uint32_t t = hfinish(acc);
+                if constexpr (RNG) t = uint32_t((min(int(t), r15cap) * r15mul + r15add) >> r15sh);
                 ring[j][s / 2] = (s & 1) ? __builtin_amdgcn_perm(t, ring[j][s / 2], 0x05040100)
                                          : __builtin_amdgcn_perm(ring[j][s / 2], t, 0x07060100);
             }

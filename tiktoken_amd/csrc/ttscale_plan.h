@@ -310,14 +310,14 @@ int build_class(const tts_geom &g, int sub, ClassPlan &c, std::vector<uint32_t> 
     const int LW = HT <= 4 ? 4 : 8;
     const int R = VT <= 4 ? 4 : VT <= 6 ? 6 : 8;
     // A range step INSIDE the scale's context (filter.cpp check_geom: `format=yuvj420p` right behind the scale) converts the
-    // 15-bit rows between the two passes: the general kernel alone carries that (GenericArgs.range15); speed later
+    // 15-bit rows between the two passes: the column walk carries that (its RNG instantiations, whatever the tap count), and
+    // the general kernel (GenericArgs.range15) where the column walk does not fit
     const bool range_in_scale = g.in_fmt == TTS_FMT_YUV420P && g.out_fmt == TTS_FMT_YUV420P && g.rgb_stage == TTS_RGB_AT_SCALE;
     const bool strip_ok = !force_column && HT <= 8 && VT <= 8 && c.src_w >= LW && monotone(c.v.pos) &&
                           !env_int("TTS_FORCE_GENERIC", 0) && !range_in_scale;
     if (!strip_ok) {
         // Many taps: the column walk, if the taps fit its windows and ring and the runs fit its slot.
         c.kind = 0;
-        if (range_in_scale) return TTS_OK;
         // one instantiation per 4 taps of the larger tap count of the two axes: 6, 8, ... 32 tap pairs
         // (windows of 2 NTP bytes, ring of 2 NTP rows) -- the work is one v_perm + v_dot2 per tap pair per
         // source row, so a window cut to fit the taps is that much less arithmetic
@@ -691,7 +691,7 @@ bool column_dot4(const ClassPlan &c, const Knobs &k)
 
 constexpr int column_depth(int) { return 4; }    // source rows in flight per wave, every tap count (see pick_column)
 
-struct ColMode { int nc, dmas, d4; };              // columns per lane, LDS-DMAs per row, v_dot4 form: of one launch (per class)
+struct ColMode { int nc, dmas, d4, rng = 0; };     // columns per lane, LDS-DMAs per row, v_dot4 form, range step on the 15-bit rows: of one launch (per class)
 
 strip_fn pick_column(const ClassPlan &c, const ColMode m)
 {
@@ -699,10 +699,11 @@ strip_fn pick_column(const ClassPlan &c, const ColMode m)
     // so four rows are kept in flight (four LDS slots): the 1080p thumbnail chain 35 -> 39-41 % of peak,
     // 4K -> 720p 46 -> 51 %, the 48-tap 4K thumbnail chain 48 -> 54 %.  Eight measured worse than four
     // (1080p chain 34 %, 4K chain 51 %).
-#define TTS_COL_PICK(NTP_, NC_) (m.d4 ? (m.dmas == 1 ? column_lds_kernel<NTP_, 2 * NTP_, 1, NC_, column_depth(NTP_), true> \
-                                                            : column_lds_kernel<NTP_, 2 * NTP_, 2, NC_, column_depth(NTP_), true>) \
-                                       : (m.dmas == 1 ? column_lds_kernel<NTP_, 2 * NTP_, 1, NC_, column_depth(NTP_)> \
-                                                            : column_lds_kernel<NTP_, 2 * NTP_, 2, NC_, column_depth(NTP_)>))
+#define TTS_COL_PICK_(NTP_, NC_, RNG_) (m.d4 ? (m.dmas == 1 ? column_lds_kernel<NTP_, 2 * NTP_, 1, NC_, column_depth(NTP_), true, RNG_> \
+                                                            : column_lds_kernel<NTP_, 2 * NTP_, 2, NC_, column_depth(NTP_), true, RNG_>) \
+                                       : (m.dmas == 1 ? column_lds_kernel<NTP_, 2 * NTP_, 1, NC_, column_depth(NTP_), false, RNG_> \
+                                                            : column_lds_kernel<NTP_, 2 * NTP_, 2, NC_, column_depth(NTP_), false, RNG_>))
+#define TTS_COL_PICK(NTP_, NC_) (m.rng ? TTS_COL_PICK_(NTP_, NC_, true) : TTS_COL_PICK_(NTP_, NC_, false))
     if (c.Rc != 2 * c.NTP) return nullptr;
     if (m.nc == 2)
         switch (c.NTP) {
@@ -730,6 +731,7 @@ strip_fn pick_column(const ClassPlan &c, const ColMode m)
     default: return nullptr;
     }
 #undef TTS_COL_PICK
+#undef TTS_COL_PICK_
 }
 
 void fill_column_class(const tts_plan *p, int ci, const ColMode m, int n, int src_stride, int dst_stride, const SegTables &st,
@@ -981,7 +983,8 @@ int launch_all(const tts_plan *p, const uint8_t *src, uint8_t *dst, int n, const
         // the v_dot4 form where every class of the launch has its digit tables (for either column count)
         int d4 = 1;
         for (int k = 0; k < nc; ++k) d4 &= int(column_dot4(p->cls[col_cls[k]], p->knobs));
-        ColMode cm[2] = {{p->cls[0].col_nc, p->cls[0].col_dmas, d4}, {p->cls[1].col_nc, p->cls[1].col_dmas, d4}};
+        const int rng15 = range_in_scale ? 1 : 0;
+        ColMode cm[2] = {{p->cls[0].col_nc, p->cls[0].col_dmas, d4, rng15}, {p->cls[1].col_nc, p->cls[1].col_dmas, d4, rng15}};
         auto cmerged_now = [&] { return nc == 2 && !p->knobs.no_merge && pick_column(p->cls[0], cm[0]) == pick_column(p->cls[1], cm[1]); };
         // Above 8 tap pairs two columns per lane pay only on large launches (1080p thumbnail chain: +2 % at
         // 300 frames, +8.5 % at 600, but -10 % at 120 and -5 % at 30): half as many workgroups want shorter
@@ -1004,7 +1007,7 @@ int launch_all(const tts_plan *p, const uint8_t *src, uint8_t *dst, int n, const
                 }
             }
             decided = two;
-            if (!two) cm[ci] = {1, c.col_dmas1, d4};
+            if (!two) cm[ci] = {1, c.col_dmas1, d4, rng15};
         }
         const bool cmerged = cmerged_now();
         for (int k = 0; k < nc; ++k) {
@@ -1028,6 +1031,15 @@ int launch_all(const tts_plan *p, const uint8_t *src, uint8_t *dst, int n, const
             a.scaler_blocks = a.c[0].nblocks + (cmerged ? a.c[1].nblocks : 0);
             a.grid_scaler = a.scaler_blocks; a.queue = nullptr;
             a.y16 = p->y16 && (cmerged || ci == 0);
+            if (rng15) {                                   // swscale.c lumRangeToJpeg_c / chrRangeToJpeg_c / lumRangeFromJpeg_c / chrRangeFromJpeg_c
+                static const int32_t to_full[2][4] = {{30189, 19077, -39057361, 14}, {30775, 4663, -9289992, 12}};
+                static const int32_t to_limited[2][4] = {{32767, 14071, 33561947, 14}, {32767, 1799, 4081085, 11}};
+                const int32_t (*t)[4] = p->g.out_range == TTS_RANGE_TO_FULL ? to_full : to_limited;
+                for (int slot = 0; slot < 2; ++slot) {
+                    const int cls_of_slot = cmerged ? slot : ci;   // (a single class rides in slot 0)
+                    a.r15.cap[slot] = t[cls_of_slot][0]; a.r15.mul[slot] = t[cls_of_slot][1]; a.r15.add[slot] = t[cls_of_slot][2]; a.r15.shift[slot] = t[cls_of_slot][3];
+                }
+            }
 #ifdef TTS_EXPERIMENTS
             a.dbg = exp_dbg_buffer(a.scaler_blocks);
 #endif

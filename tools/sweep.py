@@ -48,6 +48,10 @@ CASES = {
     "web_rgbin": ("scale=720:1280", 1080, 1920, 6220800 + 1382400),                     # the web box from RGB: 1.5x
     "thumb_rgbin": ("scale=320:568:flags=area", 1080, 1920, 6220800 + 272640),          # BASELINE's thumbnails from RGB
     "cvt_yuvj": ("format=yuvj420p", 1920, 1080, 3110400 * 2),                               # range step alone
+    "thumbref_yuvj": ("scale=320x180:force_original_aspect_ratio=decrease,pad=320x180:-1:-1:color=black,format=yuv420p,format=yuvj420p", 1920, 1080, 3110400 + 86400),   # the reference's chain + the mjpeg encoder's range pass (fused into the store)
+    "thumbref_yuvj_inscale": ("scale=320x180:force_original_aspect_ratio=decrease,pad=320x180:-1:-1:color=black,format=yuvj420p", 1920, 1080, 3110400 + 86400),   # nothing pins yuv420p: the scale's own context converts the range (column walk, RNG)
+    "half_yuvj_inscale": ("scale=1920:1080,format=yuvj420p", 3840, 2160, 12441600 + 3110400),
+    "portrait_yuvj_inscale": ("scale=1080:1920:force_original_aspect_ratio=increase,crop=1080:1920,format=yuvj420p", 1920, 1080, 4095360),
     "pad_only": ("pad=1920:1280:-1:-1:color=black", 1920, 1080, 3110400 + 1920 * 1280 * 3 // 2),
     "crop_only": ("crop=1080:1080", 1920, 1080, 1080 * 1080 * 3),
     "cvt_rgb24": ("format=rgb24", 1920, 1080, 3110400 + 6220800),                          # conversion alone (yuv2rgb_c_24_rgb)
