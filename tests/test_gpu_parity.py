@@ -708,3 +708,33 @@ def test_host_frames_through_tts_run(tts, oracle):
     S[0].width, S[0].height, D[0].width, D[0].height = iw, ih, ow, oh
     S[0].mem, D[0].mem = 1, 0
     assert tts._lib.lib().tts_run(plan._h, S, D, 1, None) == -1
+
+
+@pytest.mark.parametrize("vf,iw,ih,family", [
+    ("scale=320x180:force_original_aspect_ratio=decrease,pad=320x180:-1:-1:color=black,format=yuvj420p", 1920, 1080, "column_lds"),   # many taps
+    ("scale=1080:1920:force_original_aspect_ratio=increase,crop=1080:1920,format=yuvj420p", 1280, 720, "column_lds"),                  # four taps: the column walk all the same
+    ("scale=640:360:flags=area,format=yuvj420p", 1280, 720, "column_lds"),
+    ("scale=12:10,format=yuvj420p", 8, 8, "generic"),                                                                                  # too small for the walk
+])
+def test_range_step_inside_the_scale(tts, oracle, vf, iw, ih, family):
+    """`scale=...,format=yuvj420p` with nothing pinning yuv420p in between: swscale converts the range on the scale's 15-bit rows
+    (oracle: tto_scale_plane_range).  The column walk carries the step for every tap count (",range15" in its name), the general
+    kernel behind it; the pinned form of the same chain gives other bytes."""
+    import torch
+    plan = tts.Plan.from_vf(vf, iw, ih)
+    assert plan.geom.rgb_stage == 1 and plan.geom.out_range == 1
+    name = plan.kernel_name(0)
+    assert name.startswith(family) and (family == "generic" or name.endswith(",range15>")), name
+    pinned = tts.Plan.from_vf(vf.replace(",format=yuvj420p", ",format=yuv420p,format=yuvj420p"), iw, ih)
+    assert pinned.geom.rgb_stage == 0 and "range15" not in pinned.kernel_name(0)
+    for pat in ("random", "impulse", "limited"):
+        src = synth.frames(pat, iw, ih, 3)
+        d = torch.from_numpy(src).cuda()
+        got = plan.run_batch(d).cpu().numpy()
+        want = oracle.run_chain(plan.geom, src)
+        bad = np.flatnonzero(got != want)
+        assert bad.size == 0, "%s %dx%d %s [%s]: %d bytes differ, first at %d" % (vf, iw, ih, pat, name, bad.size, bad[0])
+        other = pinned.run_batch(d).cpu().numpy()
+        assert np.array_equal(other, oracle.run_chain(pinned.geom, src))
+        if pat == "random" and iw > 16:   # (a tiny picture may well agree)
+            assert not np.array_equal(got, other)
