@@ -693,7 +693,9 @@ int tto_rgb_in_half_chroma(int sw, int dw) { return (dw >> 1) <= (sw >> 1); }
 /* bgr24 -> yuv420p at the same size takes swscale's special converter (see tto_sws_packed_to_yuv420) */
 int tto_bgr24_special_converter(int fmt, int sw, int sh, int dw, int dh) { return fmt == TTO_FMT_BGR24 && sw == dw && sh == dh; }
 
-static void tto_hscale16_plane(const int16_t *src, int sw, int sh, const tto_filter *hf, int16_t *tmp)
+/* swscale.c hScale16To15_c (sh = 13 for RGB sources), then the context's range step on the 15-bit row where its ranges
+ * differ (c->lumConvertRange / chrConvertRange; range 0: none) */
+static void tto_hscale16_plane_range(const int16_t *src, int sw, int sh, const tto_filter *hf, int16_t *tmp, int chroma, int range)
 {
     for (int y = 0; y < sh; y++) {
         const int16_t *s = src + (size_t)y * sw;
@@ -702,7 +704,8 @@ static void tto_hscale16_plane(const int16_t *src, int sw, int sh, const tto_fil
             int val = 0, p = hf->pos[x];
             for (int j = 0; j < hf->size; j++) val += (int)s[p + j] * hf->coef[hf->size * x + j];
             val >>= 13;
-            t[x] = (int16_t)(val < (1 << 15) - 1 ? val : (1 << 15) - 1);
+            val = val < (1 << 15) - 1 ? val : (1 << 15) - 1;
+            t[x] = (int16_t)tto_range15(val, chroma, range);
         }
     }
 }
@@ -735,6 +738,17 @@ int tto_sws_rgb24_to_yuv420(const uint8_t *src, int sstride, int sw, int sh,
 int tto_sws_packed_to_yuv420(int fmt, const uint8_t *src, int sstride, int sw, int sh,
                              uint8_t *dy, uint8_t *du, uint8_t *dv, int dys, int dus, int dvs, int dw, int dh, int alg)
 {
+    return tto_sws_packed_to_yuv420_range(fmt, src, sstride, sw, sh, dy, du, dv, dys, dus, dvs, dw, dh, alg, 0);
+}
+
+/* ... into yuvj420p (full = 1): an RGB source has srcRange 0 (sws_setColorspaceDetails()), utils.c fill_rgb2yuv_table()
+ * builds the LIMITED-range table whatever the destination ("dstRange = 0; //FIXME range = 1 is handled elsewhere"), and
+ * elsewhere is ff_sws_init_range_convert(): srcRange != dstRange -> lumRangeToJpeg_c / chrRangeToJpeg_c on the 15-bit rows
+ * between the passes.  Ranges differ, so sws_init_context() never asks ff_get_unscaled_swscale(): no bgr24 special case
+ * here.  RECALLED, UNVERIFIED. */
+int tto_sws_packed_to_yuv420_range(int fmt, const uint8_t *src, int sstride, int sw, int sh,
+                                   uint8_t *dy, uint8_t *du, uint8_t *dv, int dys, int dus, int dvs, int dw, int dh, int alg, int full)
+{
     const int pb = (fmt == TTO_FMT_RGBA || fmt == TTO_FMT_BGRA) ? 4 : 3;    /* bytes a pixel */
     const int ro = (fmt == TTO_FMT_BGR24 || fmt == TTO_FMT_BGRA) ? 2 : 0, bo = 2 - ro;   /* where red and blue sit */
     const int S = 15;                                                      /* RGB2YUV_SHIFT */
@@ -746,7 +760,7 @@ int tto_sws_packed_to_yuv420(int fmt, const uint8_t *src, int sstride, int sw, i
     tto_filter lh, lv, ch, cv;
     int16_t *y14, *u14, *v14, *ty, *tu, *tv;
     if (fmt < TTO_FMT_RGB24 || fmt > TTO_FMT_BGRA || sw < 1 || sh < 1 || dw < 1 || dh < 1) return -1;
-    if (tto_bgr24_special_converter(fmt, sw, sh, dw, dh)) {
+    if (!full && tto_bgr24_special_converter(fmt, sw, sh, dw, dh)) {
         /* swscale_unscaled.c ff_get_unscaled_swscale(), "bgr24toYV12": srcFormat == BGR24 && dstFormat == YUV420P &&
          * !(flags & SWS_ACCURATE_RND) -> bgr24ToYv12Wrapper -> rgb2rgb_template.c ff_rgb24toyv12_c() (FFmpeg 4.3: "Chrominance
          * data is only taken from every second line, others are ignored in the C version"): no 14-bit intermediates, no
@@ -798,9 +812,9 @@ int tto_sws_packed_to_yuv420(int fmt, const uint8_t *src, int sstride, int sw, i
     ty = (int16_t *)malloc((size_t)dw * sh * sizeof(int16_t));
     tu = (int16_t *)malloc((size_t)cdw * sh * sizeof(int16_t));
     tv = (int16_t *)malloc((size_t)cdw * sh * sizeof(int16_t));
-    tto_hscale16_plane(y14, sw, sh, &lh, ty);
-    tto_hscale16_plane(u14, csw, sh, &ch, tu);
-    tto_hscale16_plane(v14, csw, sh, &ch, tv);
+    tto_hscale16_plane_range(y14, sw, sh, &lh, ty, 0, full ? 1 : 0);
+    tto_hscale16_plane_range(u14, csw, sh, &ch, tu, 1, full ? 1 : 0);
+    tto_hscale16_plane_range(v14, csw, sh, &ch, tv, 1, full ? 1 : 0);
     tto_vscale_plane(ty, dw, &lv, dy, dys);
     tto_vscale_plane(tu, cdw, &cv, du, dus);
     tto_vscale_plane(tv, cdw, &cv, dv, dvs);
@@ -839,17 +853,20 @@ int tto_run_chain_rgbin(const tto_chain *c, const uint8_t *src, int sstride,
         }
         for (int y = 0; y < c->pre_h; y++)
             memcpy(canvas + ((size_t)(c->pad_y + y) * W + c->pad_x) * pb, src + (size_t)(c->pre_y + y) * sstride + (size_t)c->pre_x * pb, (size_t)c->pre_w * pb);
-        rcc = tto_sws_packed_to_yuv420(c->in_fmt, canvas, W * pb, W, H, dy, du, dv, dys, dus, dvs, W, H, c->alg);
+        rcc = tto_sws_packed_to_yuv420_range(c->in_fmt, canvas, W * pb, W, H, dy, du, dv, dys, dus, dvs, W, H, c->alg, c->out_range == 1);
         (void)cw2;
         free(canvas);
         free(buf);
         return rcc;
     }
-    int rc = tto_sws_packed_to_yuv420(c->in_fmt, src + (size_t)c->pre_y * sstride + (size_t)c->pre_x * pb, sstride, c->pre_w, c->pre_h,
-                                      py, pu, pv, vw, cw, cw, vw, vh, c->alg);
+    /* out_range 1 on a chain fed with RGB: the converting context itself writes yuvj420p (`scale=...,format=yuvj420p`, or no
+     * scale and `format=yuvj420p`); what follows works on yuvj420p (pad colour in full range), no pass of its own */
+    int rc = tto_sws_packed_to_yuv420_range(c->in_fmt, src + (size_t)c->pre_y * sstride + (size_t)c->pre_x * pb, sstride, c->pre_w, c->pre_h,
+                                            py, pu, pv, vw, cw, cw, vw, vh, c->alg, c->out_range == 1);
     if (!rc) {
         /* what is left of the chain sees a yuv420p frame of the scaled size */
         rest.in_fmt = 0; rest.in_w = vw; rest.in_h = vh; rest.pre_x = rest.pre_y = 0; rest.pre_w = vw; rest.pre_h = vh; rest.do_scale = 0;
+        rest.out_range = 0;
         rc = tto_run_chain(&rest, py, pu, pv, vw, cw, cw, dy, du, dv, dys, dus, dvs);
     }
     free(buf);

@@ -99,6 +99,9 @@ int tto_bgr24_special_converter(int fmt, int sw, int sh, int dw, int dh);
  * sw x sh, scaled to ceil(dw / 2) x ceil(dh / 2). */
 int tto_sws_packed_to_yuv420(int fmt, const uint8_t *src, int sstride, int sw, int sh,
                              uint8_t *dy, uint8_t *du, uint8_t *dv, int dys, int dus, int dvs, int dw, int dh, int alg);
+/* ... into yuvj420p when full = 1: the same limited-range samples, lumRangeToJpeg_c / chrRangeToJpeg_c between the passes */
+int tto_sws_packed_to_yuv420_range(int fmt, const uint8_t *src, int sstride, int sw, int sh,
+                                   uint8_t *dy, uint8_t *du, uint8_t *dv, int dys, int dus, int dvs, int dw, int dh, int alg, int full);
 int tto_sws_rgb24_to_yuv420(const uint8_t *src, int sstride, int sw, int sh,
                             uint8_t *dy, uint8_t *du, uint8_t *dv, int dys, int dus, int dvs, int dw, int dh, int alg);
 

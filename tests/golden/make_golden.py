@@ -65,6 +65,7 @@ RGBIN_CASES = {
     "rgbin_portrait_192x108": dict(geom(192, 108, 341, 192, crop=(116, 0, 108, 192)), in_fmt=1),   # widened: chroma read per pixel (rgb24ToUV_c)
     "rgbin_shrink_96x170_to_54x96": dict(geom(96, 170, 54, 96), in_fmt=1),                          # shrunk: chroma read from pixel pairs
     "rgbin_pad_on_rgb_64x36_in_80x61": dict(geom(64, 36, 64, 36, pad=(7, 5, 80, 61)), in_fmt=1, rgb_stage=2, fill_rgb=0x336699, out_fmt=0),   # no scale: the pad on RGB pixels, then the conversion of the canvas
+    "rgbin_to_yuvj_96x170_to_54x96": dict(geom(96, 170, 54, 96, out_range=1), in_fmt=1),            # the converting context writes full range (range step on its 15-bit rows)
     "bgr24_same_size_66x37": dict(geom(66, 37, 66, 37), in_fmt=2),                                 # swscale's bgr24toYV12 converter (ff_rgb24toyv12_c), odd height
 }
 PATTERNS = ("random", "impulse", "zone")

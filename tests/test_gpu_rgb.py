@@ -699,7 +699,7 @@ def test_rgb24_input_host_path_and_rejections(tts, oracle):
     plan = tts.Plan.from_vf("scale=96:54", 64, 36, in_fmt="rgb24")
     src = rgb_frames("zone", 64, 36, 5)
     assert np.array_equal(plan.run_host(src), oracle.run_chain(plan.geom, src))
-    for vf, iw in (("scale=96:54,format=rgb24", 64), ("scale=48:27", 63), ("format=yuv420p", 63), ("pad=81:60", 64), ("format=yuvj420p", 64)):
+    for vf, iw in (("scale=96:54,format=rgb24", 64), ("scale=48:27", 63), ("format=yuv420p", 63), ("pad=81:60", 64), ("scale=96:54,format=yuv420p,format=yuvj420p", 64)):
         with pytest.raises(tts.TtsError, match="UNSUPPORTED"):
             tts.Plan.from_vf(vf, iw, 36, in_fmt="rgb24")
 
@@ -731,3 +731,31 @@ def test_packed_rgb_input_pad_without_scale(tts, oracle, vf, iw, ih, fmt):
     if "crop" not in vf:
         other = tts.Plan.from_vf("scale=%d:%d,%s" % (iw, ih, vf), iw, ih, in_fmt=fmt)
         assert other.geom.rgb_stage == 0 and not other.kernel_name(0).endswith("+rgb_pad")
+
+
+RGBIN_YUVJ_CASES = [
+    ("format=yuvj420p", 64, 36),                                         # the inserted conversion pass writes full range itself
+    ("scale=96:54,format=yuvj420p", 64, 36),                             # ... or the scale does (an enlargement: chroma per pixel)
+    ("scale=640:360,format=yuvj420p", 1280, 720),                        # a shrink (chroma from pixel pairs)
+    ("crop=100:60:7:3,scale=50:30,pad=64:40:-1:-1:color=red,format=yuvj420p", 128, 72),   # the pad behind it on a yuvj420p link
+    ("pad=80:60:7:5:color=red,format=yuvj420p", 64, 36),                 # a pad on the RGB pixels in front of it
+]
+
+
+@pytest.mark.parametrize("fmt", ["rgb24", "bgr24", "rgba"])
+@pytest.mark.parametrize("vf,iw,ih", RGBIN_YUVJ_CASES)
+def test_packed_rgb_input_into_yuvj420p(tts, oracle, vf, iw, ih, fmt):
+    """Fed with packed RGB, handing out yuvj420p: the converting context applies lumRangeToJpeg_c / chrRangeToJpeg_c to its 15-bit
+    rows (oracle: tto_sws_packed_to_yuv420_range); the general kernel carries that (+range15 in its name)."""
+    import torch
+    plan = tts.Plan.from_vf(vf, iw, ih, in_fmt=fmt)
+    assert plan.geom.out_range == 1 and "+range15" in plan.kernel_name(0), plan.kernel_name(0)
+    limited = tts.Plan.from_vf(vf.replace(",format=yuvj420p", "").replace("format=yuvj420p", "format=yuv420p"), iw, ih, in_fmt=fmt)
+    for pat in ("random", "impulse"):
+        src = repack(rgb_frames(pat, iw, ih, 3), iw, ih, fmt)
+        want = oracle.run_chain(plan.geom, src)
+        d = torch.from_numpy(src).cuda()
+        got = plan.run_batch(d).cpu().numpy()
+        bad = np.flatnonzero(got != want)
+        assert bad.size == 0, "%s %s %dx%d %s [%s]: %d bytes differ, first at %d" % (fmt, vf, iw, ih, pat, plan.kernel_name(0), bad.size, bad[0])
+        assert not np.array_equal(got, limited.run_batch(d).cpu().numpy())

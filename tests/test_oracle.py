@@ -265,3 +265,35 @@ def test_range_step_inside_the_scale_context():
     g1 = dict(g, do_scale=0, sc_w=iw, sc_h=ih, crop_w=iw, crop_h=ih, out_w=iw, out_h=ih, rgb_stage=0)
     a = oracle.run_chain(g1, frame[None])[0]
     assert a[0] == clip((lum15(int(rows_y[0]) << 7) + 64) >> 7)
+
+
+def test_rgb_in_to_yuvj420p_known_answers():
+    """Packed RGB into yuvj420p: the converting context writes full range itself -- the limited-range table (fill_rgb2yuv_table's
+    "dstRange = 0"), then lumRangeToJpeg_c / chrRangeToJpeg_c on its 15-bit rows.  White 255, black 0, grey chroma 128; a red
+    worked by hand; bgr24 at the same size is NOT its special converter here (ranges differ: the general path)."""
+    from oracle import oracle
+    iw, ih = 16, 12
+
+    def geom(fmt):
+        return dict(in_w=iw, in_h=ih, pre_x=0, pre_y=0, pre_w=iw, pre_h=ih, do_scale=0, sc_w=iw, sc_h=ih, alg=0, crop_x=0, crop_y=0, crop_w=iw, crop_h=ih,
+                    do_pad=0, pad_x=0, pad_y=0, out_w=iw, out_h=ih, fill_y=16, fill_u=128, fill_v=128, out_range=1, out_fmt=0, rgb_stage=0, fill_rgb=0, in_fmt=fmt)
+    px = np.empty((1, ih, iw, 3), np.uint8)
+    ry, gy, by, ru, gu, bu = 8414, 16519, 3208, -4865, -9528, 14392
+
+    def y_full(c):
+        v = 2 * ((ry * c[0] + gy * c[1] + by * c[2] + (32 << 14) + (1 << 8)) >> 9)
+        return max(0, min(255, (((min(v, 30189) * 19077 - 39057361) >> 14) + 64) >> 7))
+
+    def u_full(c):
+        v = 2 * ((2 * (ru * c[0] + gu * c[1] + bu * c[2]) + (256 << 15) + (1 << 9)) >> 10)
+        return max(0, min(255, (((min(v, 30775) * 4663 - 9289992) >> 12) + 64) >> 7))
+    for c, want_y in (((255, 255, 255), 255), ((0, 0, 0), 0), ((255, 0, 0), None), ((100, 100, 100), None)):
+        px[...] = c
+        out = oracle.run_chain(geom(1), px.reshape(1, -1))[0]
+        assert out[0] == y_full(c) and (want_y is None or out[0] == want_y), (c, out[0], y_full(c))
+        assert out[iw * ih] == u_full(c), (c, out[iw * ih], u_full(c))
+        if c[0] == c[1] == c[2]:
+            assert out[iw * ih] == 128 and out[-1] == 128
+        # bgr24 with the same pixels: the same bytes (the general path, not ff_rgb24toyv12_c: that one would give Y 234 for white before any range step)
+        assert np.array_equal(oracle.run_chain(geom(2), px[..., ::-1].copy().reshape(1, -1))[0], out)
+    assert y_full((255, 0, 0)) == 76                               # limited 81 -> (81 - 16) * 255 / 219 = 75.7

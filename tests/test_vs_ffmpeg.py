@@ -76,6 +76,9 @@ CHAINS = [
     # behind it reads the canvas -- settles where libavfilter's negotiation puts that pass
     ("pad=80:60:7:5:color=red", 64, 36, "yuv420p", "rgb24"),
     ("pad=320:180:-1:-1:color=black", 102, 180, "yuv420p", "rgba"),
+    # packed RGB in, yuvj420p out: the converting context writes full range itself (limited-range table + lum/chrRangeToJpeg_c on its 15-bit rows)
+    ("scale=640:360,format=yuvj420p", 1280, 720, "yuvj420p", "rgb24"),
+    ("format=yuvj420p", 64, 48, "yuvj420p", "bgr24"),
 ]
 CHAINS = [c if len(c) == 5 else c + ("yuv420p",) for c in CHAINS]
 

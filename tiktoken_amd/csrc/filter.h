@@ -32,7 +32,9 @@ inline bool rgb_in_half_chroma(int src_w, int dst_w) { return (dst_w >> 1) <= (s
 // bgr24 into yuv420p at the SAME size (no accurate_rnd) is not that path at all: swscale_unscaled.c's "bgr24toYV12" entry
 // hands the frame to rgb2rgb_template.c ff_rgb24toyv12_c() (truncating sums, chroma from the left pixel of each pair of
 // the even rows only).  Its chromWidth = width >> 1 pairs leave the last column of an odd width unwritten: refused.
-inline bool bgr24_special_converter(const tts_geom &g) { return g.in_fmt == TTS_FMT_BGR24 && g.sc_w == g.pre_w && g.sc_h == g.pre_h; }
+// (Ranges that differ -- bgr24 into yuvj420p -- keep the context on the general path: sws_init_context() only asks for an unscaled
+// converter when srcRange == dstRange.)
+inline bool bgr24_special_converter(const tts_geom &g) { return g.in_fmt == TTS_FMT_BGR24 && g.sc_w == g.pre_w && g.sc_h == g.pre_h && g.out_range == TTS_RANGE_KEEP; }
 
 // Validate a resolved geometry; returns TTS_OK or an error.
 int  check_geom(const tts_geom &g);

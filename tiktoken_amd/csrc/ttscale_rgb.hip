@@ -971,6 +971,7 @@ struct RgbInArgs {
     int32_t  chr_half;                 // 1: chroma samples are pixel-pair sums (rgb24ToUV_half_c), 0: one per pixel (rgb24ToUV_c); filter.h rgb_in_half_chroma()
     int32_t  pb;                       // bytes a source pixel: 3 (rgb24, bgr24) or 4 (rgba, bgra: the fourth is ignored); coef is by byte of a pixel
     uint32_t src_origin, src_extent;   // bytes from a frame's first byte to the pre-cropped origin / to one past its last byte
+    int32_t  range15;                  // 1: the context writes yuvj420p -- lumRangeToJpeg_c / chrRangeToJpeg_c on the 15-bit rows between the passes
     int32_t  vs_on, vs_x, vs_y, vs_w, vs_h, vs_fill[3];   // a pad on RGB pixels in front of the conversion: the picture's rectangle in the canvas the conversion reads, the colour by byte of a pixel
     FrameAddr addr;
 };
@@ -1041,6 +1042,7 @@ __global__ __launch_bounds__(kBlock) void rgbin_generic_kernel(const RgbInArgs a
             }
             acc >>= 13;
             acc = acc < 32767 ? acc : 32767;
+            if (a.range15) acc = ci ? (min(acc, 30775) * 4663 - 9289992) >> 12 : (min(acc, 30189) * 19077 - 39057361) >> 14;
             val += acc * int(vc[j]);
         }
         val >>= 19;                                            // (a 1-tap vertical filter gives (t + 64) >> 7: the same value)
@@ -2111,6 +2113,7 @@ struct RgbInPlan {
     RgbInShrinkPlan *shrink = nullptr; // shrinks with at most 8 taps across: the source-row walk of ttscale_rgbin_shrink.hip
     bool yv12 = false;                 // bgr24 at the same size: swscale's special converter (bgr24_yv12_kernel), none of the above
     bool yv12_rows = false;            // ... with nothing behind it: bgr24_yv12_rows_kernel
+    bool range15 = false;              // into yuvj420p: the context's own range step (RgbInArgs.range15), general kernel only
     bool canvas = false;               // a pad on RGB pixels in front of the conversion (TTS_RGB_AT_END): the general kernels read the canvas through vs_*
     char name[96] = "";
 };
@@ -2159,8 +2162,8 @@ int rgbin_plan_create(const tts_geom &g, RgbInPlan **out)
     const bool canvas = g.rgb_stage == TTS_RGB_AT_END;
     const int src_w = canvas ? g.out_w : g.pre_w, src_h = canvas ? g.out_h : g.pre_h, dst_w = canvas ? g.out_w : g.sc_w, dst_h = canvas ? g.out_h : g.sc_h;
     const bool half = rgb_in_half_chroma(src_w, dst_w);              // sws_init_context()'s chrSrcHSubSample for this context
-    if (g.in_fmt == TTS_FMT_YUV420P || g.out_fmt != TTS_FMT_YUV420P || g.out_range != TTS_RANGE_KEEP || (half && (src_w & 1))) {
-        set_last_error("packed RGB in: the chain must hand out yuv420p (no range step) and, unless it widens the picture, read an even width");
+    if (g.in_fmt == TTS_FMT_YUV420P || g.out_fmt != TTS_FMT_YUV420P || g.out_range == TTS_RANGE_TO_LIMITED || (half && (src_w & 1))) {
+        set_last_error("packed RGB in: the chain must hand out yuv420p or yuvj420p and, unless it widens the picture, read an even width");
         return TTS_ERR_UNSUPPORTED;
     }
     RgbInPlan *p = new (std::nothrow) RgbInPlan();
@@ -2170,13 +2173,14 @@ int rgbin_plan_create(const tts_geom &g, RgbInPlan **out)
     p->pb = packed_pixel_bytes(g.in_fmt);
     p->blue_first = packed_blue_first(g.in_fmt);
     p->canvas = canvas;
+    p->range15 = g.out_range == TTS_RANGE_TO_FULL;            // the converting context writes yuvj420p: the general kernel alone carries its range step
     p->yv12 = bgr24_special_converter(g);
     if (p->yv12 && (src_w & 1)) {
         set_last_error("swscale's bgr24 -> yuv420p converter for pictures of the same size never writes the last column of an odd width: not supported");
         delete p;
         return TTS_ERR_UNSUPPORTED;
     }
-    const bool three = p->pb == 3 && !p->yv12 && !canvas;   // the walks read 3-byte pixels; 4-byte sources run the tiled / general kernels
+    const bool three = p->pb == 3 && !p->yv12 && !canvas && !p->range15;   // the walks read 3-byte pixels; 4-byte sources run the tiled / general kernels
     int rc = TTS_OK;
     if (!build_axis_filter(src_w, dst_w, 1 << 14, g.alg, p->lh) || !build_axis_filter(src_h, dst_h, 1 << 12, g.alg, p->lv) ||
         !build_axis_filter(half ? src_w / 2 : src_w, (dst_w + 1) >> 1, 1 << 14, g.alg, p->ch) || !build_axis_filter(src_h, (dst_h + 1) >> 1, 1 << 12, g.alg, p->cv)) {
@@ -2185,7 +2189,7 @@ int rgbin_plan_create(const tts_geom &g, RgbInPlan **out)
     const AxisFilter *f[4] = {&p->lh, &p->lv, &p->ch, &p->cv};
     for (int i = 0; i < 4 && !rc; ++i)
         if (!upload_vec(p->d_pos[i], f[i]->pos) || !upload_vec(p->d_taps[i], f[i]->taps)) { set_last_error("table upload failed (hipMalloc / hipMemcpy)"); rc = TTS_ERR_INITIALIZATION_FAILED; }
-    if (!rc && !p->yv12 && !canvas && !std::getenv("TTS_FORCE_GENERIC")) {
+    if (!rc && !p->yv12 && !canvas && !p->range15 && !std::getenv("TTS_FORCE_GENERIC")) {
         // 32 KiB a workgroup if some tile height fits that (five workgroups on a CU's 160 KiB), else 64 KiB
         const RgbInRect r0 = rgbin_rect(g, 0), r1 = rgbin_rect(g, 1);
         for (size_t budget : {size_t(32768), size_t(65536)})        // (64 KiB: the most a workgroup gets without opting in)
@@ -2334,7 +2338,7 @@ int rgbin_plan_create(const tts_geom &g, RgbInPlan **out)
     else if (p->walk) std::snprintf(p->name, sizeof p->name, "rgbin_walk<%d>", p->cv.size);
     else if (p->strip) std::snprintf(p->name, sizeof p->name, "rgbin_strip<%d,%d,%d,%d,%dpx>", p->lh.size, p->lv.size, p->ch.size, p->cv.size, p->pxl);   // luma taps across / down, chroma taps across / down
     else if (p->tiled) std::snprintf(p->name, sizeof p->name, "rgbin_tile<%d,%d>", p->th[0], p->th[1]);
-    else std::snprintf(p->name, sizeof p->name, "rgbin_generic<%d,%d,%d,%d>%s", p->lh.size, p->lv.size, p->ch.size, p->cv.size, canvas ? "+rgb_pad" : "");
+    else std::snprintf(p->name, sizeof p->name, "rgbin_generic<%d,%d,%d,%d>%s%s", p->lh.size, p->lv.size, p->ch.size, p->cv.size, p->range15 ? "+range15" : "", canvas ? "+rgb_pad" : "");
     if (p->yv12 && canvas) std::snprintf(p->name, sizeof p->name, "bgr24_yv12+rgb_pad");
     if (rc) { rgbin_plan_destroy(p); return rc; }
     *out = p;
@@ -2372,6 +2376,7 @@ int rgbin_launch(const RgbInPlan *p, const uint8_t *src, uint8_t *dst, int n, in
     a.only_plane = only_plane;
     a.chr_half = p->half ? 1 : 0;
     a.pb = p->pb;
+    a.range15 = p->range15 ? 1 : 0;
     a.src_origin = uint32_t(g.pre_y) * uint32_t(src_stride) + uint32_t(g.pre_x) * uint32_t(p->pb);
     a.src_extent = uint32_t(size_t(g.in_h - 1) * size_t(src_stride) + size_t(g.in_w) * size_t(p->pb));
     a.fill[0] = g.fill_y; a.fill[1] = g.fill_u; a.fill[2] = g.fill_v;

@@ -312,6 +312,9 @@ int parse_vf(const char *vf, int iw, int ih, tts_geom &g, std::string &err, int 
             if (fmt < 0) { err = "format: only yuv420p, yuvj420p, rgb24, bgr24, rgba, bgra are supported"; return TTS_ERR_UNSUPPORTED; }
             if (pf == "yuvj420p") {
                 if (seen_scale && !yuv_pinned && !link_full && g.in_fmt == TTS_FMT_YUV420P) range_in_scale = true;
+                // fed with packed RGB: the context that converts (the scale, or the pass inserted here) writes yuvj420p itself unless
+                // a format=yuv420p came first -- then this would be a range pass of its own behind it
+                if (g.in_fmt != TTS_FMT_YUV420P && (yuv_pinned || link_full)) { err = "packed RGB in: format=yuvj420p behind a format=yuv420p (a range pass of its own): not supported"; return TTS_ERR_UNSUPPORTED; }
                 link_full = true;
             } else if (pf == "yuv420p") {
                 if (range_in_scale) { err = "format=yuv420p behind a scale that writes yuvj420p: not supported"; return TTS_ERR_UNSUPPORTED; }
@@ -490,6 +493,10 @@ int parse_vf(const char *vf, int iw, int ih, tts_geom &g, std::string &err, int 
         g.crop_x = cx; g.crop_y = cy; g.crop_w = cw; g.crop_h = ch;
         g.out_w = cw; g.out_h = ch;
     }
+    // fed with packed RGB into yuvj420p: a pad behind the converting context sits on a yuvj420p link (a pad on the RGB pixels in
+    // front of it keeps its RGB colour)
+    if (g.in_fmt != TTS_FMT_YUV420P && g.out_range == TTS_RANGE_TO_FULL && g.do_pad && g.rgb_stage != TTS_RGB_AT_END)
+        rgb_to_yuv_full((g.fill_rgb >> 16) & 255, (g.fill_rgb >> 8) & 255, g.fill_rgb & 255, g);
     if (range_in_scale && g.out_range == TTS_RANGE_TO_FULL) {
         if (g.do_scale) {
             g.rgb_stage = TTS_RGB_AT_SCALE;
