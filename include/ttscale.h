@@ -43,12 +43,7 @@ enum { TTS_FMT_YUV420P = 0, TTS_FMT_RGB24 = 1, TTS_FMT_BGR24 = 2, TTS_FMT_RGBA =
  * (everything after it -- crop, pad -- then works on RGB pixels: no chroma-grid rounding, pad colour in
  * RGB), or, in a chain without one, in a pass of its own at the very end (after pad, borders included). */
 enum { TTS_RGB_NONE = 0, TTS_RGB_AT_SCALE = 1, TTS_RGB_AT_END = 2 };
-/* The same field places a RANGE step on a chain that stays yuv420p (out_fmt 0, out_range != 0): TTS_RGB_AT_SCALE = the
- * chain's scale writes yuvj420p itself (`scale=...,format=yuvj420p` with no `format=yuv420p` between the two): swscale converts
- * the range on its 15-bit rows between the horizontal and the vertical pass, crop and pad behind it work on yuvj420p
- * (fill_y/u/v are full-range values); 0 = a pass of its own over the finished frame (the reference's thumbnail chain, which
- * pins format=yuv420p before the mjpeg encoder asks for yuvj420p; also every chain without a resizing scale).
- * A chain FED with packed RGB (in_fmt != 0) converts inside its `scale` too (rgb_stage 0).  Without a scale the
+/* A chain FED with packed RGB (in_fmt != 0) converts inside its `scale` too (rgb_stage 0).  Without a scale the
  * conversion pass is inserted at the end, which only matters behind a `pad`: the pad then runs on RGB pixels (any
  * offset, colour in RGB) and the conversion reads the padded canvas, border included -- rgb_stage TTS_RGB_AT_END. */
 
@@ -71,6 +66,12 @@ typedef struct tts_geom {
     int32_t rgb_stage;                        /* TTS_RGB_*: where the colour conversion sits (0 when the chain stays yuv420p, or is fed RGB and has a scale or no pad) */
     int32_t fill_rgb;                         /* pad colour as 0xRRGGBB, used when the pad stage works on RGB pixels */
     int32_t in_fmt;                           /* TTS_FMT_*: what the chain is fed (tts_parse_vf_fmt); 0 = yuv420p */
+    int32_t sc_range;                         /* TTS_RANGE_*: a range step INSIDE the chain's converting context -- the scale writes the other
+                                               * range itself (`scale=...,format=yuvj420p` with no format=yuv420p between the two; a packed-RGB
+                                               * source converted straight into yuvj420p): swscale runs it on its 15-bit rows BETWEEN the
+                                               * horizontal and the vertical pass; crop and pad behind it work on the new range (fill_y/u/v are
+                                               * values of that range).  out_range is a pass of its own over the finished frame (the reference's
+                                               * thumbnail chain pins format=yuv420p before the mjpeg encoder asks for yuvj420p); both may be set */
 } tts_geom;
 
 /* One frame: Y, U, V plane pointers and byte strides (yuv420p), or plane[0] / stride[0] alone (packed RGB). */

@@ -75,7 +75,7 @@ napi_value ParseVf(napi_env env, napi_callback_info info)
     napi_create_object(env, &obj);
     const char *names[] = {"in_w", "in_h", "pre_x", "pre_y", "pre_w", "pre_h", "do_scale", "alg", "sc_w", "sc_h",
                            "crop_x", "crop_y", "crop_w", "crop_h", "do_pad", "pad_x", "pad_y", "out_w", "out_h",
-                           "fill_y", "fill_u", "fill_v", "out_range", "out_fmt", "rgb_stage", "fill_rgb", "in_fmt"};
+                           "fill_y", "fill_u", "fill_v", "out_range", "out_fmt", "rgb_stage", "fill_rgb", "in_fmt", "sc_range"};
     static_assert(sizeof(tts_geom) == sizeof(names) / sizeof(names[0]) * sizeof(int32_t), "names[] lists every field of tts_geom, in order");
     const int32_t *vals = &g.in_w;
     for (size_t i = 0; i < sizeof(names) / sizeof(names[0]); ++i) {

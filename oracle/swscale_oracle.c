@@ -356,10 +356,10 @@ int tto_run_chain(const tto_chain *c,
         uint8_t *scaled = NULL;
         const uint8_t *q; int qs;
         if (c->do_scale) {
-            /* rgb_stage 1 on a chain that stays yuv: `format=yuvj420p` behind the scale with nothing pinning the link to yuv420p
-             * in between -- the scale's own context converts the range (on its 15-bit rows); crop and pad behind it then work
-             * on yuvj420p (the pad colour arrives as full-range values), and no second pass follows */
-            const int in_scale = c->rgb_stage == 1 && c->out_fmt == 0 ? c->out_range : 0;
+            /* sc_range: `format=yuvj420p` behind the scale with nothing pinning the link to yuv420p in between (or a full-range
+             * source scaled into a link pinned to yuv420p) -- the scale's own context converts the range, on its 15-bit rows;
+             * crop and pad behind it then work on the new range (the pad colour arrives as values of that range) */
+            const int in_scale = c->out_fmt == 0 ? c->sc_range : 0;
             scaled = (uint8_t *)malloc((size_t)vw * vh);
             if (tto_scale_plane_range(s, sst[p], pw, ph, scaled, vw, vw, vh, c->alg, p != 0, in_scale)) { free(scaled); return -1; }
             q = scaled; qs = vw;
@@ -387,7 +387,7 @@ int tto_run_chain(const tto_chain *c,
      * (v = p << 7), lum/chrConvertRange on the 15-bit row (swscale.c lumRangeToJpeg_c,
      * chrRangeToJpeg_c, lumRangeFromJpeg_c, chrRangeFromJpeg_c -- constants of FFmpeg 4.x-6.0,
      * recalled, UNVERIFIED), then yuv2plane1_8_c: (v + 64) >> 7 clipped.  Borders included. */
-    if (c->out_range && !(c->rgb_stage == 1 && c->out_fmt == 0 && c->do_scale)) {
+    if (c->out_range) {
         for (int p = 0; p < 3; p++) {
             const int sub = p ? 1 : 0;
             const int ow = (c->out_w + sub) >> sub, oh = (c->out_h + sub) >> sub;
@@ -853,20 +853,20 @@ int tto_run_chain_rgbin(const tto_chain *c, const uint8_t *src, int sstride,
         }
         for (int y = 0; y < c->pre_h; y++)
             memcpy(canvas + ((size_t)(c->pad_y + y) * W + c->pad_x) * pb, src + (size_t)(c->pre_y + y) * sstride + (size_t)c->pre_x * pb, (size_t)c->pre_w * pb);
-        rcc = tto_sws_packed_to_yuv420_range(c->in_fmt, canvas, W * pb, W, H, dy, du, dv, dys, dus, dvs, W, H, c->alg, c->out_range == 1);
+        rcc = tto_sws_packed_to_yuv420_range(c->in_fmt, canvas, W * pb, W, H, dy, du, dv, dys, dus, dvs, W, H, c->alg, c->sc_range == 1);
         (void)cw2;
         free(canvas);
         free(buf);
         return rcc;
     }
-    /* out_range 1 on a chain fed with RGB: the converting context itself writes yuvj420p (`scale=...,format=yuvj420p`, or no
+    /* sc_range 1 on a chain fed with RGB: the converting context itself writes yuvj420p (`scale=...,format=yuvj420p`, or no
      * scale and `format=yuvj420p`); what follows works on yuvj420p (pad colour in full range), no pass of its own */
     int rc = tto_sws_packed_to_yuv420_range(c->in_fmt, src + (size_t)c->pre_y * sstride + (size_t)c->pre_x * pb, sstride, c->pre_w, c->pre_h,
-                                            py, pu, pv, vw, cw, cw, vw, vh, c->alg, c->out_range == 1);
+                                            py, pu, pv, vw, cw, cw, vw, vh, c->alg, c->sc_range == 1);
     if (!rc) {
         /* what is left of the chain sees a yuv420p frame of the scaled size */
         rest.in_fmt = 0; rest.in_w = vw; rest.in_h = vh; rest.pre_x = rest.pre_y = 0; rest.pre_w = vw; rest.pre_h = vh; rest.do_scale = 0;
-        rest.out_range = 0;
+        rest.sc_range = 0;
         rc = tto_run_chain(&rest, py, pu, pv, vw, cw, cw, dy, du, dv, dys, dus, dvs);
     }
     free(buf);

@@ -49,6 +49,7 @@ typedef struct tto_chain {
     int rgb_stage;                    /* 0 none, 1 inside the chain's scale (crop / pad then work on RGB), 2 a pass of its own at the end */
     int fill_rgb;                     /* pad colour 0xRRGGBB for pads that work on RGB */
     int in_fmt;                       /* TTO_FMT_YUV420P, or a packed layout (rgb24, bgr24, rgba, bgra): the chain's swscale pass reads packed RGB */
+    int sc_range;                     /* 0 none, 1 limited->full, 2 full->limited: a range step INSIDE the converting context (on its 15-bit rows, between the passes) */
 } tto_chain;
 
 enum { TTO_FMT_YUV420P = 0, TTO_FMT_RGB24 = 1, TTO_FMT_BGR24 = 2, TTO_FMT_RGBA = 3, TTO_FMT_BGRA = 4 };

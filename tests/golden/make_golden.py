@@ -53,7 +53,7 @@ CASES = {
     "thumb_pad_rgb24_72x128": geom(72, 128, 101, 180, pad=(109, 0, 320, 180), rgb=(1, 1, 0)),
     "convert_only_bgra_64x48": geom(64, 48, 64, 48, rgb=(4, 2, 0)),
     # round 3: the scale itself writes yuvj420p (range step on its 15-bit rows, between the passes; the pad colour in full range)
-    "scale_writes_yuvj_72x128": dict(geom(72, 128, 101, 180, pad=(108, 0, 320, 180), fill=(0, 128, 128), out_range=1), out_fmt=0, rgb_stage=1, fill_rgb=0),
+    "scale_writes_yuvj_72x128": dict(geom(72, 128, 101, 180, pad=(108, 0, 320, 180), fill=(0, 128, 128)), sc_range=1),
     # round 3: rows through swscale's 2-line writer (bilinear enlargement to RGB), and RGB from a full-range link
     "bilinear_rgb24_64x48_to_128x96": geom(64, 48, 128, 96, alg=2, rgb=(1, 1, 0)),
     "thumb_pad_jpeg_rgb24_72x128": geom(72, 128, 101, 180, pad=(108, 0, 320, 180), out_range=1, rgb=(1, 2, 0)),
@@ -65,7 +65,7 @@ RGBIN_CASES = {
     "rgbin_portrait_192x108": dict(geom(192, 108, 341, 192, crop=(116, 0, 108, 192)), in_fmt=1),   # widened: chroma read per pixel (rgb24ToUV_c)
     "rgbin_shrink_96x170_to_54x96": dict(geom(96, 170, 54, 96), in_fmt=1),                          # shrunk: chroma read from pixel pairs
     "rgbin_pad_on_rgb_64x36_in_80x61": dict(geom(64, 36, 64, 36, pad=(7, 5, 80, 61)), in_fmt=1, rgb_stage=2, fill_rgb=0x336699, out_fmt=0),   # no scale: the pad on RGB pixels, then the conversion of the canvas
-    "rgbin_to_yuvj_96x170_to_54x96": dict(geom(96, 170, 54, 96, out_range=1), in_fmt=1),            # the converting context writes full range (range step on its 15-bit rows)
+    "rgbin_to_yuvj_96x170_to_54x96": dict(geom(96, 170, 54, 96), in_fmt=1, sc_range=1),            # the converting context writes full range (range step on its 15-bit rows)
     "bgr24_same_size_66x37": dict(geom(66, 37, 66, 37), in_fmt=2),                                 # swscale's bgr24toYV12 converter (ff_rgb24toyv12_c), odd height
 }
 PATTERNS = ("random", "impulse", "zone")

@@ -722,11 +722,11 @@ def test_range_step_inside_the_scale(tts, oracle, vf, iw, ih, family):
     kernel behind it; the pinned form of the same chain gives other bytes."""
     import torch
     plan = tts.Plan.from_vf(vf, iw, ih)
-    assert plan.geom.rgb_stage == 1 and plan.geom.out_range == 1
+    assert plan.geom.sc_range == 1 and plan.geom.out_range == 0
     name = plan.kernel_name(0)
     assert name.startswith(family) and (family == "generic" or name.endswith(",range15>")), name
     pinned = tts.Plan.from_vf(vf.replace(",format=yuvj420p", ",format=yuv420p,format=yuvj420p"), iw, ih)
-    assert pinned.geom.rgb_stage == 0 and "range15" not in pinned.kernel_name(0)
+    assert pinned.geom.sc_range == 0 and pinned.geom.out_range == 1 and "range15" not in pinned.kernel_name(0)
     for pat in ("random", "impulse", "limited"):
         src = synth.frames(pat, iw, ih, 3)
         d = torch.from_numpy(src).cuda()

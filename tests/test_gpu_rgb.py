@@ -749,7 +749,7 @@ def test_packed_rgb_input_into_yuvj420p(tts, oracle, vf, iw, ih, fmt):
     rows (oracle: tto_sws_packed_to_yuv420_range); the general kernel carries that (+range15 in its name)."""
     import torch
     plan = tts.Plan.from_vf(vf, iw, ih, in_fmt=fmt)
-    assert plan.geom.out_range == 1 and "+range15" in plan.kernel_name(0), plan.kernel_name(0)
+    assert plan.geom.sc_range == 1 and plan.geom.out_range == 0 and "+range15" in plan.kernel_name(0), plan.kernel_name(0)
     limited = tts.Plan.from_vf(vf.replace(",format=yuvj420p", "").replace("format=yuvj420p", "format=yuv420p"), iw, ih, in_fmt=fmt)
     for pat in ("random", "impulse"):
         src = repack(rgb_frames(pat, iw, ih, 3), iw, ih, fmt)

@@ -58,9 +58,9 @@ PARSE_CASES = [
      dict(sc_w=101, sc_h=180, do_pad=1, pad_x=108, out_range=1)),
     ("format=pix_fmts=yuvj420p", 64, 48, dict(do_scale=0, out_range=1)),
     # the scale itself writes yuvj420p unless a format=yuv420p pins the link behind it: range step inside its context, pad colour in full range
-    ("scale=32:24,pad=40:30:-1:-1:color=red,format=yuvj420p", 64, 48, dict(do_scale=1, out_range=1, rgb_stage=1, fill_y=76, fill_u=85, fill_v=255)),
-    ("scale=32:24,pad=40:30:-1:-1:color=red,format=yuv420p,format=yuvj420p", 64, 48, dict(do_scale=1, out_range=1, rgb_stage=0, fill_y=81, fill_u=90, fill_v=240)),
-    ("scale=64:48,format=yuvj420p", 64, 48, dict(do_scale=0, out_range=1, rgb_stage=0)),
+    ("scale=32:24,pad=40:30:-1:-1:color=red,format=yuvj420p", 64, 48, dict(do_scale=1, out_range=0, sc_range=1, rgb_stage=0, fill_y=76, fill_u=85, fill_v=255)),
+    ("scale=32:24,pad=40:30:-1:-1:color=red,format=yuv420p,format=yuvj420p", 64, 48, dict(do_scale=1, out_range=1, sc_range=0, rgb_stage=0, fill_y=81, fill_u=90, fill_v=240)),
+    ("scale=64:48,format=yuvj420p", 64, 48, dict(do_scale=0, out_range=1, sc_range=0, rgb_stage=0)),
     # ff_scale_adjust_dimensions: the aspect-derived size is rounded to the NEAREST multiple of force_divisible_by
     # first (101.25 -> 102), then min'ed and rounded down
     ("scale=320:180:force_original_aspect_ratio=decrease:force_divisible_by=2", 720, 1280, dict(sc_w=102, sc_h=180)),

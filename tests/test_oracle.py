@@ -235,8 +235,7 @@ def test_rgb_in_pad_without_scale_runs_on_rgb_pixels():
 
 def test_range_step_inside_the_scale_context():
     """`scale=...,format=yuvj420p` with nothing pinning the link to yuv420p in between: the scale's own context writes
-    yuvj420p, so lumRangeToJpeg_c / chrRangeToJpeg_c run on its 15-bit rows BETWEEN the two passes (rgb_stage 1 on a chain that
-    stays yuv); behind `format=yuv420p` the step is a pass of its own on the finished bytes.  Rows that are constant across
+    yuvj420p, so lumRangeToJpeg_c / chrRangeToJpeg_c run on its 15-bit rows BETWEEN the two passes (tts_geom.sc_range); behind `format=yuv420p` the step is a pass of its own on the finished bytes.  Rows that are constant across
     (the horizontal pass then gives p << 7 exactly) make both forms computable by hand from the vertical taps."""
     from oracle import oracle
     iw, ih, ow, oh = 16, 12, 16, 30
@@ -244,9 +243,9 @@ def test_range_step_inside_the_scale_context():
     rows_y, rows_c = rng.integers(0, 256, ih), rng.integers(0, 256, ih // 2)
     frame = np.concatenate([np.repeat(rows_y, iw), np.repeat(rows_c, iw // 2), np.repeat(rows_c[::-1], iw // 2)]).astype(np.uint8)
     g = dict(in_w=iw, in_h=ih, pre_x=0, pre_y=0, pre_w=iw, pre_h=ih, do_scale=1, sc_w=ow, sc_h=oh, alg=0, crop_x=0, crop_y=0, crop_w=ow, crop_h=oh,
-             do_pad=0, pad_x=0, pad_y=0, out_w=ow, out_h=oh, fill_y=16, fill_u=128, fill_v=128, out_range=1, out_fmt=0, rgb_stage=1, fill_rgb=0, in_fmt=0)
+             do_pad=0, pad_x=0, pad_y=0, out_w=ow, out_h=oh, fill_y=16, fill_u=128, fill_v=128, out_range=0, out_fmt=0, rgb_stage=0, fill_rgb=0, in_fmt=0, sc_range=1)
     inside = oracle.run_chain(g, frame[None])[0]
-    at_end = oracle.run_chain(dict(g, rgb_stage=0), frame[None])[0]
+    at_end = oracle.run_chain(dict(g, sc_range=0, out_range=1), frame[None])[0]
 
     def lum15(v): return (min(v, 30189) * 19077 - 39057361) >> 14
     def chr15(v): return (min(v, 30775) * 4663 - 9289992) >> 12
@@ -262,7 +261,7 @@ def test_range_step_inside_the_scale_context():
             assert inside[off + y * w] == want_inside and at_end[off + y * w] == want_end, (name, y)
     assert not np.array_equal(inside, at_end)
     # no resizing: one-tap filters around the step either way -- the same bytes
-    g1 = dict(g, do_scale=0, sc_w=iw, sc_h=ih, crop_w=iw, crop_h=ih, out_w=iw, out_h=ih, rgb_stage=0)
+    g1 = dict(g, do_scale=0, sc_w=iw, sc_h=ih, crop_w=iw, crop_h=ih, out_w=iw, out_h=ih, sc_range=0, out_range=1)
     a = oracle.run_chain(g1, frame[None])[0]
     assert a[0] == clip((lum15(int(rows_y[0]) << 7) + 64) >> 7)
 
@@ -276,7 +275,7 @@ def test_rgb_in_to_yuvj420p_known_answers():
 
     def geom(fmt):
         return dict(in_w=iw, in_h=ih, pre_x=0, pre_y=0, pre_w=iw, pre_h=ih, do_scale=0, sc_w=iw, sc_h=ih, alg=0, crop_x=0, crop_y=0, crop_w=iw, crop_h=ih,
-                    do_pad=0, pad_x=0, pad_y=0, out_w=iw, out_h=ih, fill_y=16, fill_u=128, fill_v=128, out_range=1, out_fmt=0, rgb_stage=0, fill_rgb=0, in_fmt=fmt)
+                    do_pad=0, pad_x=0, pad_y=0, out_w=iw, out_h=ih, fill_y=16, fill_u=128, fill_v=128, out_range=0, out_fmt=0, rgb_stage=0, fill_rgb=0, in_fmt=fmt, sc_range=1)
     px = np.empty((1, ih, iw, 3), np.uint8)
     ry, gy, by, ru, gu, bu = 8414, 16519, 3208, -4865, -9528, 14392
 

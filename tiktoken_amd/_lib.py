@@ -14,7 +14,7 @@ class Geom(ctypes.Structure):
     _fields_ = [(n, ctypes.c_int32) for n in (
         "in_w", "in_h", "pre_x", "pre_y", "pre_w", "pre_h", "do_scale", "alg", "sc_w", "sc_h",
         "crop_x", "crop_y", "crop_w", "crop_h", "do_pad", "pad_x", "pad_y", "out_w", "out_h",
-        "fill_y", "fill_u", "fill_v", "out_range", "out_fmt", "rgb_stage", "fill_rgb", "in_fmt")]
+        "fill_y", "fill_u", "fill_v", "out_range", "out_fmt", "rgb_stage", "fill_rgb", "in_fmt", "sc_range")]
 
     def as_dict(self):
         return {n: getattr(self, n) for n, _ in self._fields_}

@@ -227,8 +227,9 @@ int check_geom(const tts_geom &g)
     if (g.in_fmt != TTS_FMT_YUV420P) {
         // a crop in front of the conversion works on RGB pixels (any offset); rgb24ToUV_half_c reads pixel pairs
         const bool canvas = g.rgb_stage == TTS_RGB_AT_END;      // (the conversion reads a padded RGB canvas: its width is checked below)
-        // (out_range TO_FULL on a chain fed with RGB: the converting context itself writes yuvj420p -- the range step on its 15-bit rows)
-        if (g.out_fmt != TTS_FMT_YUV420P || g.out_range == TTS_RANGE_TO_LIMITED || (!canvas && (g.pre_w & 1) && rgb_in_half_chroma(g.pre_w, g.sc_w))) return TTS_ERR_UNSUPPORTED;
+        // (sc_range TO_FULL on a chain fed with RGB: the converting context itself writes yuvj420p -- the range step on its 15-bit rows;
+        // a range pass of its own behind such a chain is not built)
+        if (g.out_fmt != TTS_FMT_YUV420P || g.out_range != TTS_RANGE_KEEP || g.sc_range == TTS_RANGE_TO_LIMITED || (!canvas && (g.pre_w & 1) && rgb_in_half_chroma(g.pre_w, g.sc_w))) return TTS_ERR_UNSUPPORTED;
         if (!canvas && bgr24_special_converter(g) && (g.pre_w & 1)) return TTS_ERR_UNSUPPORTED;   // (already covered: the same size is never an enlargement)
     } else if (has_pre && !(even(g.pre_x) && even(g.pre_y) && even(g.pre_w) && even(g.pre_h))) return TTS_ERR_INVALID_INPUT;
     if (g.sc_w < 1 || g.sc_h < 1 || g.sc_w > 16384 || g.sc_h > 16384) return TTS_ERR_INVALID_INPUT;
@@ -240,16 +241,15 @@ int check_geom(const tts_geom &g)
     const bool rgb_pad = g.in_fmt != TTS_FMT_YUV420P && g.rgb_stage == TTS_RGB_AT_END;
     if (rgb_pad && (!g.do_pad || g.do_scale || g.sc_w != g.pre_w || g.sc_h != g.pre_h || g.crop_x || g.crop_y || g.crop_w != g.sc_w || g.crop_h != g.sc_h)) return TTS_ERR_INVALID_INPUT;
     if (rgb_pad && (g.out_w & 1)) return TTS_ERR_UNSUPPORTED;      // (the pair-summing chroma reader / bgr24's own converter over an odd canvas)
-    // (a chain that stays yuv420p: TTS_RGB_AT_SCALE marks a RANGE step inside the scale's own context -- `format=yuvj420p` behind
-    // a scale with nothing pinning the link in between; crop and pad behind it then work on yuvj420p)
-    const bool range_in_scale = g.in_fmt == TTS_FMT_YUV420P && g.out_fmt == TTS_FMT_YUV420P && g.rgb_stage == TTS_RGB_AT_SCALE;
-    if (range_in_scale && (!g.do_scale || g.out_range == TTS_RANGE_KEEP)) return TTS_ERR_INVALID_INPUT;
-    if (!rgb_pad && !range_in_scale && ((g.out_fmt == TTS_FMT_YUV420P) != (g.rgb_stage == TTS_RGB_NONE) || g.rgb_stage < 0 || g.rgb_stage > TTS_RGB_AT_END)) return TTS_ERR_INVALID_INPUT;
+    // (sc_range: a range step inside the converting context -- planar chains: the scale's; it needs one that resizes, and yuv out)
+    if (g.sc_range < TTS_RANGE_KEEP || g.sc_range > TTS_RANGE_TO_LIMITED) return TTS_ERR_INVALID_INPUT;
+    if (g.sc_range != TTS_RANGE_KEEP && (g.out_fmt != TTS_FMT_YUV420P || (g.in_fmt == TTS_FMT_YUV420P && !g.do_scale))) return TTS_ERR_INVALID_INPUT;
+    if (!rgb_pad && ((g.out_fmt == TTS_FMT_YUV420P) != (g.rgb_stage == TTS_RGB_NONE) || g.rgb_stage < 0 || g.rgb_stage > TTS_RGB_AT_END)) return TTS_ERR_INVALID_INPUT;
     // packed RGB from a full-range link (`format=yuvj420p,format=rgb24`): the range pass, then a conversion pass of its own
     if (g.out_fmt != TTS_FMT_YUV420P && g.out_range != TTS_RANGE_KEEP && !(g.out_range == TTS_RANGE_TO_FULL && g.rgb_stage == TTS_RGB_AT_END)) return TTS_ERR_UNSUPPORTED;
     if (g.fill_rgb & ~0xffffff) return TTS_ERR_INVALID_INPUT;
     // crop and pad behind an RGB-writing scale work on RGB pixels: no chroma grid
-    if ((g.rgb_stage == TTS_RGB_AT_SCALE && !range_in_scale) || rgb_pad) even = [](int) { return true; };
+    if (g.rgb_stage == TTS_RGB_AT_SCALE || rgb_pad) even = [](int) { return true; };
     if (g.crop_w < 1 || g.crop_h < 1 || g.crop_x < 0 || g.crop_y < 0 ||
         g.crop_x + g.crop_w > g.sc_w || g.crop_y + g.crop_h > g.sc_h) return TTS_ERR_INVALID_INPUT;
     const bool has_crop = g.crop_x || g.crop_y || g.crop_w != g.sc_w || g.crop_h != g.sc_h;

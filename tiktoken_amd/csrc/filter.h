@@ -34,7 +34,7 @@ inline bool rgb_in_half_chroma(int src_w, int dst_w) { return (dst_w >> 1) <= (s
 // the even rows only).  Its chromWidth = width >> 1 pairs leave the last column of an odd width unwritten: refused.
 // (Ranges that differ -- bgr24 into yuvj420p -- keep the context on the general path: sws_init_context() only asks for an unscaled
 // converter when srcRange == dstRange.)
-inline bool bgr24_special_converter(const tts_geom &g) { return g.in_fmt == TTS_FMT_BGR24 && g.sc_w == g.pre_w && g.sc_h == g.pre_h && g.out_range == TTS_RANGE_KEEP; }
+inline bool bgr24_special_converter(const tts_geom &g) { return g.in_fmt == TTS_FMT_BGR24 && g.sc_w == g.pre_w && g.sc_h == g.pre_h && g.sc_range == TTS_RANGE_KEEP; }
 
 // Validate a resolved geometry; returns TTS_OK or an error.
 int  check_geom(const tts_geom &g);

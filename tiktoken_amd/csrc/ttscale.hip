@@ -239,7 +239,7 @@ const char *tts_plan_kernel_name(const tts_plan *p, int plane_class)
         bool d4 = true;                                  // (as launch_all decides: every column class of the launch)
         for (int ci = 0; ci < 2; ++ci)
             if (p->cls[ci].kind == 2) d4 &= column_dot4(p->cls[ci], p->knobs);
-        const bool rng15 = p->g.in_fmt == TTS_FMT_YUV420P && p->g.out_fmt == TTS_FMT_YUV420P && p->g.rgb_stage == TTS_RGB_AT_SCALE;   // the scale's own range step
+        const bool rng15 = p->g.in_fmt == TTS_FMT_YUV420P && p->g.out_fmt == TTS_FMT_YUV420P && p->g.sc_range != TTS_RANGE_KEEP;   // the scale's own range step
         std::snprintf(buf, sizeof buf, "column_lds<%d,%d,%d,%d,%d%s%s>", c.NTP, c.Rc, c.col_dmas, c.col_nc, column_depth(c.NTP), d4 ? ",dot4" : "", rng15 ? ",range15" : "");
     }
     else {

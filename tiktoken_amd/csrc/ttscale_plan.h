@@ -312,7 +312,7 @@ int build_class(const tts_geom &g, int sub, ClassPlan &c, std::vector<uint32_t> 
     // A range step INSIDE the scale's context (filter.cpp check_geom: `format=yuvj420p` right behind the scale) converts the
     // 15-bit rows between the two passes: the column walk carries that (its RNG instantiations, whatever the tap count), and
     // the general kernel (GenericArgs.range15) where the column walk does not fit
-    const bool range_in_scale = g.in_fmt == TTS_FMT_YUV420P && g.out_fmt == TTS_FMT_YUV420P && g.rgb_stage == TTS_RGB_AT_SCALE;
+    const bool range_in_scale = g.in_fmt == TTS_FMT_YUV420P && g.out_fmt == TTS_FMT_YUV420P && g.sc_range != TTS_RANGE_KEEP;
     const bool strip_ok = !force_column && HT <= 8 && VT <= 8 && c.src_w >= LW && monotone(c.v.pos) &&
                           !env_int("TTS_FORCE_GENERIC", 0) && !range_in_scale;
     if (!strip_ok) {
@@ -833,9 +833,10 @@ int launch_all(const tts_plan *p, const uint8_t *src, uint8_t *dst, int n, const
         // store int16 luma; the caller falls back)
         if (p->y16 && (c.kind == 0 || to_generic[ci]) && active(ci)) { g_last_error = "scratch pass needs the column walk or an LDS strip kernel"; return TTS_ERR_UNSUPPORTED; }
     }
-    // (a range step inside the scale's context is the general kernel's business: nothing follows it here)
-    const bool range_in_scale = p->g.in_fmt == TTS_FMT_YUV420P && p->g.out_fmt == TTS_FMT_YUV420P && p->g.rgb_stage == TTS_RGB_AT_SCALE;
-    const int range_at_end = range_in_scale ? TTS_RANGE_KEEP : p->g.out_range;
+    // (sc_range, a range step inside the scale's context: the column walk's RNG instantiations and the general kernel carry it;
+    // out_range, the pass at the end, is independent of it -- a full-range source thumbnailed the reference's way has both)
+    const bool range_in_scale = p->g.in_fmt == TTS_FMT_YUV420P && p->g.out_fmt == TTS_FMT_YUV420P && p->g.sc_range != TTS_RANGE_KEEP;
+    const int range_at_end = p->g.out_range;
     RangeStep range{};
     if (range_at_end != TTS_RANGE_KEEP) {
         range.on = 1;
@@ -1034,7 +1035,7 @@ int launch_all(const tts_plan *p, const uint8_t *src, uint8_t *dst, int n, const
             if (rng15) {                                   // swscale.c lumRangeToJpeg_c / chrRangeToJpeg_c / lumRangeFromJpeg_c / chrRangeFromJpeg_c
                 static const int32_t to_full[2][4] = {{30189, 19077, -39057361, 14}, {30775, 4663, -9289992, 12}};
                 static const int32_t to_limited[2][4] = {{32767, 14071, 33561947, 14}, {32767, 1799, 4081085, 11}};
-                const int32_t (*t)[4] = p->g.out_range == TTS_RANGE_TO_FULL ? to_full : to_limited;
+                const int32_t (*t)[4] = p->g.sc_range == TTS_RANGE_TO_FULL ? to_full : to_limited;
                 for (int slot = 0; slot < 2; ++slot) {
                     const int cls_of_slot = cmerged ? slot : ci;   // (a single class rides in slot 0)
                     a.r15.cap[slot] = t[cls_of_slot][0]; a.r15.mul[slot] = t[cls_of_slot][1]; a.r15.add[slot] = t[cls_of_slot][2]; a.r15.shift[slot] = t[cls_of_slot][3];
@@ -1065,7 +1066,7 @@ int launch_all(const tts_plan *p, const uint8_t *src, uint8_t *dst, int n, const
         a.x0 = c.x0; a.y0 = c.y0; a.ow = c.ow; a.oh = c.oh;
         a.src_stride = src_stride[ci]; a.dst_stride = dst_stride[ci];
         a.planes = nplanes(ci); a.plane0 = plane0(ci);
-        a.range15 = range_in_scale ? p->g.out_range : 0;
+        a.range15 = range_in_scale ? p->g.sc_range : 0;
         a.addr = addr;
         z_launches(a.planes, [&](int f0, int nf) {
             a.frame0 = f0;

@@ -495,11 +495,13 @@ int parse_vf(const char *vf, int iw, int ih, tts_geom &g, std::string &err, int 
     }
     // fed with packed RGB into yuvj420p: a pad behind the converting context sits on a yuvj420p link (a pad on the RGB pixels in
     // front of it keeps its RGB colour)
-    if (g.in_fmt != TTS_FMT_YUV420P && g.out_range == TTS_RANGE_TO_FULL && g.do_pad && g.rgb_stage != TTS_RGB_AT_END)
-        rgb_to_yuv_full((g.fill_rgb >> 16) & 255, (g.fill_rgb >> 8) & 255, g.fill_rgb & 255, g);
+    if (g.in_fmt != TTS_FMT_YUV420P && g.out_range == TTS_RANGE_TO_FULL) {
+        if (g.do_pad && g.rgb_stage != TTS_RGB_AT_END) rgb_to_yuv_full((g.fill_rgb >> 16) & 255, (g.fill_rgb >> 8) & 255, g.fill_rgb & 255, g);
+        g.sc_range = TTS_RANGE_TO_FULL; g.out_range = TTS_RANGE_KEEP;     // (the converting context's own step, not a pass at the end)
+    }
     if (range_in_scale && g.out_range == TTS_RANGE_TO_FULL) {
         if (g.do_scale) {
-            g.rgb_stage = TTS_RGB_AT_SCALE;
+            g.sc_range = TTS_RANGE_TO_FULL; g.out_range = TTS_RANGE_KEEP;
             // the pad sits on a yuvj420p link: drawutils.c ff_draw_color() with full_range, libavutil/colorspace.h RGB_TO_Y_JPEG & co.
             if (g.do_pad) rgb_to_yuv_full((g.fill_rgb >> 16) & 255, (g.fill_rgb >> 8) & 255, g.fill_rgb & 255, g);
         } else if (g.do_pad) {
