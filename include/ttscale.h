@@ -38,7 +38,10 @@ enum { TTS_RANGE_KEEP = 0, TTS_RANGE_TO_FULL = 1, TTS_RANGE_TO_LIMITED = 2 };
  * as without full_chroma_int).  The stage right after the thumbnail filters of
  * src/services/video.js:329-334 and the colour conversion BASELINE.json's north_star names.
  * Frames of a packed format are ONE plane of out_w * bpp bytes a row (bpp 3 or 4; alpha = 255). */
-enum { TTS_FMT_YUV420P = 0, TTS_FMT_RGB24 = 1, TTS_FMT_BGR24 = 2, TTS_FMT_RGBA = 3, TTS_FMT_BGRA = 4 };
+enum { TTS_FMT_YUV420P = 0, TTS_FMT_RGB24 = 1, TTS_FMT_BGR24 = 2, TTS_FMT_RGBA = 3, TTS_FMT_BGRA = 4,
+       TTS_FMT_YUVJ420P = 5 };   /* tts_parse_vf_fmt's in_fmt only: yuv420p planes that hold FULL-range samples (`-pix_fmt yuvj420p -i`, what some
+                                  * phone cameras record).  The geometry it gives has in_fmt TTS_FMT_YUV420P -- the planes are the same -- and
+                                  * says what differs through sc_range / out_range and the pad colour */
 /* Where the conversion sits, as libavfilter's format negotiation places it: inside the chain's `scale`
  * (everything after it -- crop, pad -- then works on RGB pixels: no chroma-grid rounding, pad colour in
  * RGB), or, in a chain without one, in a pass of its own at the very end (after pad, borders included). */

@@ -58,6 +58,7 @@ bool get_in_fmt(napi_env env, napi_callback_info info, size_t index, int &in_fmt
     else if (f == "bgr24") in_fmt = TTS_FMT_BGR24;
     else if (f == "rgba") in_fmt = TTS_FMT_RGBA;
     else if (f == "bgra") in_fmt = TTS_FMT_BGRA;
+    else if (f == "yuvj420p") in_fmt = TTS_FMT_YUVJ420P;   // the same planes, full-range samples
     else if (f != "yuv420p") return false;
     return true;
 }

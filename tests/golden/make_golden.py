@@ -54,6 +54,8 @@ CASES = {
     "convert_only_bgra_64x48": geom(64, 48, 64, 48, rgb=(4, 2, 0)),
     # round 3: the scale itself writes yuvj420p (range step on its 15-bit rows, between the passes; the pad colour in full range)
     "scale_writes_yuvj_72x128": dict(geom(72, 128, 101, 180, pad=(108, 0, 320, 180), fill=(0, 128, 128)), sc_range=1),
+    # round 3: a full-range source through the thumbnail chain: full -> limited inside the scale (sc_range 2), back to full at the end (out_range 1)
+    "thumb_pad_full_range_source_72x128": dict(geom(72, 128, 101, 180, pad=(108, 0, 320, 180), out_range=1), sc_range=2),
     # round 3: rows through swscale's 2-line writer (bilinear enlargement to RGB), and RGB from a full-range link
     "bilinear_rgb24_64x48_to_128x96": geom(64, 48, 128, 96, alg=2, rgb=(1, 1, 0)),
     "thumb_pad_jpeg_rgb24_72x128": geom(72, 128, 101, 180, pad=(108, 0, 320, 180), out_range=1, rgb=(1, 2, 0)),

@@ -43,8 +43,11 @@ def test_random_geometries(tts, oracle, seed):
     seen = set()
     for _ in range(16):
         vf, iw, ih, n = _case(rng)
+        in_fmt = "yuvj420p" if rng.random() < 0.2 else "yuv420p"   # a full-range source: the same planes, other range steps
+        if in_fmt == "yuvj420p" and rng.random() < 0.5 and "format" not in vf:
+            vf += ",format=yuv420p"                            # (the reference's pin: the scale converts full -> limited inside its context)
         try:
-            plan = tts.Plan.from_vf(vf, iw, ih)
+            plan = tts.Plan.from_vf(vf, iw, ih, in_fmt=in_fmt)
         except tts.TtsError:
             continue                                           # a chain the parser rejects (crop larger than the frame ...)
         seen.add(plan.kernel_name(0).split("<")[0])

@@ -738,3 +738,38 @@ def test_range_step_inside_the_scale(tts, oracle, vf, iw, ih, family):
         assert np.array_equal(other, oracle.run_chain(pinned.geom, src))
         if pat == "random" and iw > 16:   # (a tiny picture may well agree)
             assert not np.array_equal(got, other)
+
+
+THUMB_PINNED = "scale=320x180:force_original_aspect_ratio=decrease,pad=320x180:-1:-1:color=black,format=yuv420p"
+FULL_RANGE_SOURCE_CASES = [
+    ("scale=w=720:h=1280", 480, 854, (0, 0)),                                    # R1: no format anywhere, the link stays full: no step at all
+    (THUMB_PINNED, 720, 1280, (2, 0)),                                            # R2: the scale writes the pinned yuv420p: full -> limited inside its context
+    (THUMB_PINNED + ",format=yuvj420p", 720, 1280, (2, 1)),                       # ... and the mjpeg encoder's pass back to full range at the end: both steps
+    (THUMB_PINNED + ",format=yuvj420p", 1920, 1080, (2, 1)),
+    ("scale=320:180,pad=400:200:-1:-1:color=red", 1280, 720, (0, 0)),             # the pad on a full-range link: its colour through RGB_TO_Y_JPEG & co.
+    ("crop=640:360:100:50,scale=1080:1920:force_original_aspect_ratio=increase,crop=1080:1920,format=yuv420p", 1280, 720, (2, 0)),   # four taps
+    ("format=yuv420p", 64, 48, (0, 2)),                                           # no scale: a pass of its own, full -> limited
+    ("crop=32:20:4:2,pad=64:48:-1:-1:color=white,format=yuv420p", 64, 48, (0, 2)),
+]
+
+
+@pytest.mark.parametrize("vf,iw,ih,steps", FULL_RANGE_SOURCE_CASES)
+def test_full_range_source(tts, oracle, vf, iw, ih, steps):
+    """`-pix_fmt yuvj420p -i ...` (what some phone cameras record): the same planes, so the same kernels -- what changes is
+    where range steps sit.  The reference's thumbnail chain pins format=yuv420p: its scale then converts full -> limited inside
+    its context (tts_geom.sc_range), and the mjpeg encoder's yuvj420p is a second step at the end (out_range)."""
+    import torch
+    plan = tts.Plan.from_vf(vf, iw, ih, in_fmt="yuvj420p")
+    assert (plan.geom.sc_range, plan.geom.out_range) == steps and plan.geom.in_fmt == 0
+    limited = tts.Plan.from_vf(vf, iw, ih)
+    if steps[0]:
+        assert "range15" in plan.kernel_name(0) or plan.kernel_name(0) == "generic", plan.kernel_name(0)
+    for pat in ("random", "impulse", "zone"):
+        src = synth.frames(pat, iw, ih, 3)
+        d = torch.from_numpy(src).cuda()
+        got = plan.run_batch(d).cpu().numpy()
+        want = oracle.run_chain(plan.geom, src)
+        bad = np.flatnonzero(got != want)
+        assert bad.size == 0, "%s %dx%d %s [%s]: %d bytes differ, first at %d" % (vf, iw, ih, pat, plan.kernel_name(0), bad.size, bad[0])
+        same = np.array_equal(got, limited.run_batch(d).cpu().numpy())
+        assert same == (steps == (0, 0) and "pad" not in vf), "a limited-range source of the same bytes: %s" % same

@@ -61,6 +61,7 @@ PARSE_CASES = [
     ("scale=32:24,pad=40:30:-1:-1:color=red,format=yuvj420p", 64, 48, dict(do_scale=1, out_range=0, sc_range=1, rgb_stage=0, fill_y=76, fill_u=85, fill_v=255)),
     ("scale=32:24,pad=40:30:-1:-1:color=red,format=yuv420p,format=yuvj420p", 64, 48, dict(do_scale=1, out_range=1, sc_range=0, rgb_stage=0, fill_y=81, fill_u=90, fill_v=240)),
     ("scale=64:48,format=yuvj420p", 64, 48, dict(do_scale=0, out_range=1, sc_range=0, rgb_stage=0)),
+    ("scale=32:24,format=yuvj420p,format=yuv420p", 64, 48, dict(do_scale=1, sc_range=1, out_range=2)),   # both steps may be set
     # ff_scale_adjust_dimensions: the aspect-derived size is rounded to the NEAREST multiple of force_divisible_by
     # first (101.25 -> 102), then min'ed and rounded down
     ("scale=320:180:force_original_aspect_ratio=decrease:force_divisible_by=2", 720, 1280, dict(sc_w=102, sc_h=180)),
@@ -184,3 +185,23 @@ def test_host_fuzz_under_sanitizers():
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     r = subprocess.run([os.path.join(root, "tools", "hostfuzz", "run.sh"), "20000"], capture_output=True, text=True, timeout=600)
     assert r.returncode == 0 and "no finding" in r.stdout, (r.stdout[-500:], r.stderr[-1500:])
+
+
+def test_parse_vf_full_range_source(tts):
+    """`-pix_fmt yuvj420p -i`: in_fmt stays 0 (the planes are the same); every link has a range and the steps sit where it changes."""
+    T = "scale=320x180:force_original_aspect_ratio=decrease,pad=320x180:-1:-1:color=red,format=yuv420p"
+    for vf, want in (("scale=w=720:h=1280", dict(sc_range=0, out_range=0)),
+                     (T, dict(sc_range=2, out_range=0, fill_y=81, fill_u=90, fill_v=240)),             # the pad behind the scale: on the limited link
+                     (T + ",format=yuvj420p", dict(sc_range=2, out_range=1, fill_y=81)),
+                     ("scale=320:180,pad=400:200:-1:-1:color=red", dict(sc_range=0, out_range=0, fill_y=76, fill_u=85, fill_v=255)),   # on a full-range link
+                     ("scale=320:180,format=yuvj420p", dict(sc_range=0, out_range=0)),
+                     ("format=yuv420p", dict(sc_range=0, out_range=2, do_scale=0))):
+        g = tts.parse_vf(vf, 640, 360, in_fmt="yuvj420p").as_dict()
+        assert g["in_fmt"] == 0
+        for k, v in want.items():
+            assert g[k] == v, (vf, k, g[k], v)
+    for vf in ("scale=320:180,format=rgb24", "format=yuv420p,scale=320:180", "format=rgb24"):
+        with pytest.raises(tts.TtsError, match="UNSUPPORTED"):
+            tts.parse_vf(vf, 640, 360, in_fmt="yuvj420p")
+    with pytest.raises(tts.TtsError, match="two range passes"):
+        tts.parse_vf("format=yuvj420p,format=yuv420p", 640, 360)

@@ -296,3 +296,28 @@ def test_rgb_in_to_yuvj420p_known_answers():
         # bgr24 with the same pixels: the same bytes (the general path, not ff_rgb24toyv12_c: that one would give Y 234 for white before any range step)
         assert np.array_equal(oracle.run_chain(geom(2), px[..., ::-1].copy().reshape(1, -1))[0], out)
     assert y_full((255, 0, 0)) == 76                               # limited 81 -> (81 - 16) * 255 / 219 = 75.7
+
+
+def test_full_range_source_two_range_steps():
+    """A yuvj420p source through the reference's thumbnail chain: its scale writes the pinned yuv420p -- full -> limited inside the
+    context (sc_range 2: lumRangeFromJpeg_c / chrRangeFromJpeg_c on the 15-bit rows) -- and the mjpeg encoder's yuvj420p is a pass
+    at the end (out_range 1).  Flat frames make both computable by hand; the round trip lands within one level of the source."""
+    from oracle import oracle
+    iw, ih, ow, oh = 16, 12, 32, 24
+
+    def clip(v): return max(0, min(255, v))
+    def to_full(v8, chroma):
+        v = v8 << 7
+        v = (min(v, 30775) * 4663 - 9289992) >> 12 if chroma else (min(v, 30189) * 19077 - 39057361) >> 14
+        return clip((v + 64) >> 7)
+    g = dict(in_w=iw, in_h=ih, pre_x=0, pre_y=0, pre_w=iw, pre_h=ih, do_scale=1, sc_w=ow, sc_h=oh, alg=0, crop_x=0, crop_y=0, crop_w=ow, crop_h=oh,
+             do_pad=0, pad_x=0, pad_y=0, out_w=ow, out_h=oh, fill_y=16, fill_u=128, fill_v=128, out_range=1, out_fmt=0, rgb_stage=0, fill_rgb=0, in_fmt=0, sc_range=2)
+    for py, pc in ((0, 128), (255, 255), (128, 0), (17, 200), (235, 16)):
+        frame = np.concatenate([np.full(iw * ih, py), np.full(iw * ih // 2, pc)]).astype(np.uint8)
+        out = oracle.run_chain(g, frame[None])[0]
+        lim_y = clip((((py << 7) * 14071 + 33561947) >> 14) + 64 >> 7)
+        lim_c = clip((((pc << 7) * 1799 + 4081085) >> 11) + 64 >> 7)
+        assert out[0] == to_full(lim_y, 0) and out[-1] == to_full(lim_c, 1), (py, pc, out[0], out[-1])
+        assert abs(int(out[0]) - py) <= 1 and abs(int(out[-1]) - pc) <= 1
+        mid = oracle.run_chain(dict(g, out_range=0), frame[None])[0]              # the limited-range frame in between
+        assert mid[0] == lim_y and mid[-1] == lim_c and 16 <= mid[0] <= 235 and 16 <= mid[-1] <= 240

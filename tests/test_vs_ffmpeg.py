@@ -76,6 +76,11 @@ CHAINS = [
     # behind it reads the canvas -- settles where libavfilter's negotiation puts that pass
     ("pad=80:60:7:5:color=red", 64, 36, "yuv420p", "rgb24"),
     ("pad=320:180:-1:-1:color=black", 102, 180, "yuv420p", "rgba"),
+    # a full-range source (`-pix_fmt yuvj420p` in front of `-i`) through the reference's chains: R1 has no step at all, R2's pinned
+    # format=yuv420p makes its scale convert full -> limited inside its context, the encoder's yuvj420p is a second step at the end
+    ("scale=w=720:h=1280", 480, 854, "yuvj420p", "yuvj420p"),
+    (THUMB_REF, 720, 1280, "yuv420p", "yuvj420p"),
+    (THUMB_REF + ",format=yuvj420p", 720, 1280, "yuvj420p", "yuvj420p"),
     # packed RGB in, yuvj420p out: the converting context writes full range itself (limited-range table + lum/chrRangeToJpeg_c on its 15-bit rows)
     ("scale=640:360,format=yuvj420p", 1280, 720, "yuvj420p", "rgb24"),
     ("format=yuvj420p", 64, 48, "yuvj420p", "bgr24"),
@@ -94,7 +99,7 @@ def exact_flags(chain, pix_fmt, in_fmt):
 def source_frames(pattern, iw, ih, n, in_fmt):
     """Seeded test frames in the chain's input format: packed I420, or packed rgb24 built from the same generator
     (three full-size planes interleaved)."""
-    if in_fmt == "yuv420p":
+    if in_fmt in ("yuv420p", "yuvj420p"):
         return synth.frames(pattern, iw, ih, n)
     y = synth.frames(pattern, 2 * iw, 2 * ih, n)
     out = np.empty((n, ih, iw, 3), np.uint8)
@@ -148,7 +153,7 @@ def diff_report(name, got, want):
 @needs_ffmpeg
 @pytest.mark.parametrize("chain,iw,ih,pix_fmt,in_fmt", CHAINS)
 def test_oracle_vs_ffmpeg(oracle, tts, tmp_path, chain, iw, ih, pix_fmt, in_fmt):
-    rgb = pix_fmt == "rgb24" or in_fmt != "yuv420p"
+    rgb = pix_fmt == "rgb24" or in_fmt not in ("yuv420p", "yuvj420p")
     geom = tts.parse_vf(chain, iw, ih, in_fmt=in_fmt)
     for pattern in ("random", "limited", "zone", "impulse"):
         frames = source_frames(pattern, iw, ih, 2, in_fmt)
@@ -164,7 +169,7 @@ def test_oracle_vs_ffmpeg(oracle, tts, tmp_path, chain, iw, ih, pix_fmt, in_fmt)
 @pytest.mark.parametrize("chain,iw,ih,pix_fmt,in_fmt", CHAINS)
 def test_hip_vs_ffmpeg(tts, tmp_path, chain, iw, ih, pix_fmt, in_fmt):
     import torch
-    rgb = pix_fmt == "rgb24" or in_fmt != "yuv420p"
+    rgb = pix_fmt == "rgb24" or in_fmt not in ("yuv420p", "yuvj420p")
     plan = tts.Plan.from_vf(chain, iw, ih, in_fmt=in_fmt)
     frames = source_frames("random", iw, ih, 2, in_fmt)
     ours = plan.run_batch(torch.from_numpy(frames).cuda()).cpu().numpy().ravel()

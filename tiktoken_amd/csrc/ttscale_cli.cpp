@@ -38,7 +38,8 @@ int main(int argc, char **argv)
                 else if (f == "bgr24") in_fmt = TTS_FMT_BGR24;
                 else if (f == "rgba") in_fmt = TTS_FMT_RGBA;
                 else if (f == "bgra") in_fmt = TTS_FMT_BGRA;
-                else if (f != "yuv420p") { std::fprintf(stderr, "ttscale: input -pix_fmt yuv420p, rgb24, bgr24, rgba or bgra\n"); return 1; }
+                else if (f == "yuvj420p") in_fmt = TTS_FMT_YUVJ420P;   // the same planes, full-range samples
+                else if (f != "yuv420p") { std::fprintf(stderr, "ttscale: input -pix_fmt yuv420p, yuvj420p, rgb24, bgr24, rgba or bgra\n"); return 1; }
             } else out_fmt = f;
         }
         else if (a == "-f") { if (std::strcmp(next(), "rawvideo")) { std::fprintf(stderr, "ttscale: only -f rawvideo\n"); return 1; } }

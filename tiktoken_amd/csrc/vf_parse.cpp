@@ -271,7 +271,9 @@ int parse_alg(const std::string &flags, int &alg)
 int parse_vf(const char *vf, int iw, int ih, tts_geom &g, std::string &err, int in_fmt)
 {
     if (!vf || iw < 1 || ih < 1) { err = "bad arguments"; return TTS_ERR_INVALID_INPUT; }
-    if (in_fmt < TTS_FMT_YUV420P || in_fmt > TTS_FMT_BGRA) { err = "input format: yuv420p, rgb24, bgr24, rgba or bgra"; return TTS_ERR_UNSUPPORTED; }
+    if (in_fmt < TTS_FMT_YUV420P || in_fmt > TTS_FMT_YUVJ420P) { err = "input format: yuv420p, yuvj420p, rgb24, bgr24, rgba or bgra"; return TTS_ERR_UNSUPPORTED; }
+    const bool src_full = in_fmt == TTS_FMT_YUVJ420P;     // the same planes, full-range samples: only the range steps (and a pad's colour) differ
+    if (src_full) in_fmt = TTS_FMT_YUV420P;
     std::memset(&g, 0, sizeof(g));
     g.in_fmt = in_fmt;
     g.in_w = iw; g.in_h = ih;
@@ -289,39 +291,67 @@ int parse_vf(const char *vf, int iw, int ih, tts_geom &g, std::string &err, int 
     // that link to yuv, or the chain has no scale; then a conversion pass of its own is inserted in front of
     // the `format` filter, i.e. at the very end.  First pass over the chain: find that out, because every
     // filter between the conversion and the end then works on RGB pixels (no chroma grid to round to).
-    // The same negotiation decides where a RANGE step sits: `format=yuvj420p` behind a scale, with nothing pinning the link
-    // to yuv420p in between, makes that scale's own context convert the range (on its 15-bit rows, between the two passes;
-    // crop and pad behind it then work on yuvj420p); behind a `format=yuv420p` -- the reference's thumbnail chain -- or in
-    // a chain without a scale it is a pass of its own at the end.
-    bool range_in_scale = false;
+    // The same negotiation decides where RANGE steps sit.  Every link has a range -- the source's (yuv420p: limited, yuvj420p:
+    // full) until a filter changes it: a scale writes the range of the first yuv `format` behind it (it is the converter:
+    // the step runs inside its context, on its 15-bit rows between the two passes: sc_range), any other change of range is
+    // a pass of its own over the frame as it stands (out_range; here: at the end of the chain).  The reference's thumbnail
+    // chain pins `format=yuv420p` behind its scale and the mjpeg encoder then asks for yuvj420p: a limited source gets one
+    // pass at the end, a full-range one (some phone cameras) both steps.  A pad takes its colour in the range of its link.
+    int sc_step = TTS_RANGE_KEEP, end_step = TTS_RANGE_KEEP;
+    bool pad_full = src_full;
     try {
-        bool seen_scale = false, yuv_pinned = false, link_full = false;
-        for (const std::string &raw : split(vf, ',')) {
+        bool seen_scale = false, yuv_pinned = false, link_full = false;   // (the packed-RGB bookkeeping, as before)
+        bool cur_full = src_full, range_pass_seen = false;
+        const std::vector<std::string> filters = split(vf, ',');
+        auto yuv_format_of = [&](const std::string &raw, bool &is_format, bool &full) {   // true: a yuv format filter
             const std::string f = trim(raw);
+            const size_t eq = f.find('=');
+            is_format = trim(f.substr(0, eq)) == "format";
+            if (!is_format) return false;
+            const std::string pf = format_arg(eq == std::string::npos ? "" : f.substr(eq + 1));
+            full = pf == "yuvj420p";
+            return pf == "yuv420p" || pf == "yuvj420p";
+        };
+        for (size_t fi = 0; fi < filters.size(); ++fi) {
+            const std::string f = trim(filters[fi]);
             if (f.empty()) continue;
             const size_t eq = f.find('=');
             const std::string name = trim(f.substr(0, eq));
             if (g.out_fmt != TTS_FMT_YUV420P && name != "setsar") { err = "an RGB format must end the chain"; return TTS_ERR_UNSUPPORTED; }
             if (name == "scale") {
-                if (link_full) { err = "format=yuvj420p in front of the scale: the range step would run first, at the source's size: not supported"; return TTS_ERR_UNSUPPORTED; }
+                if (g.in_fmt == TTS_FMT_YUV420P) {
+                    if (range_pass_seen) { err = "a range step in front of the scale (it would run first, at the source's size): not supported"; return TTS_ERR_UNSUPPORTED; }
+                    bool mid = cur_full;                       // the scale's output link: the first yuv format behind it says
+                    for (size_t fj = fi + 1; fj < filters.size(); ++fj) {
+                        bool is_format, full;
+                        if (yuv_format_of(filters[fj], is_format, full)) { mid = full; break; }
+                        if (is_format) break;                  // (a packed-RGB format: the scale converts to that; no range of its own)
+                    }
+                    if (mid != cur_full) sc_step = mid ? TTS_RANGE_TO_FULL : TTS_RANGE_TO_LIMITED;
+                    cur_full = mid;
+                }
                 seen_scale = true; yuv_pinned = false;
             }
+            if (name == "pad") pad_full = cur_full;
             if (name != "format") continue;
             const std::string pf = format_arg(eq == std::string::npos ? "" : f.substr(eq + 1));
             const int fmt = parse_pix_fmt(pf);
             if (fmt < 0) { err = "format: only yuv420p, yuvj420p, rgb24, bgr24, rgba, bgra are supported"; return TTS_ERR_UNSUPPORTED; }
+            if (g.in_fmt == TTS_FMT_YUV420P && fmt == TTS_FMT_YUV420P && (pf == "yuvj420p") != cur_full) {
+                if (end_step != TTS_RANGE_KEEP) { err = "two range passes in one chain: not supported"; return TTS_ERR_UNSUPPORTED; }
+                end_step = pf == "yuvj420p" ? TTS_RANGE_TO_FULL : TTS_RANGE_TO_LIMITED;
+                cur_full = pf == "yuvj420p";
+                range_pass_seen = true;
+            }
             if (pf == "yuvj420p") {
-                if (seen_scale && !yuv_pinned && !link_full && g.in_fmt == TTS_FMT_YUV420P) range_in_scale = true;
                 // fed with packed RGB: the context that converts (the scale, or the pass inserted here) writes yuvj420p itself unless
                 // a format=yuv420p came first -- then this would be a range pass of its own behind it
                 if (g.in_fmt != TTS_FMT_YUV420P && (yuv_pinned || link_full)) { err = "packed RGB in: format=yuvj420p behind a format=yuv420p (a range pass of its own): not supported"; return TTS_ERR_UNSUPPORTED; }
                 link_full = true;
-            } else if (pf == "yuv420p") {
-                if (range_in_scale) { err = "format=yuv420p behind a scale that writes yuvj420p: not supported"; return TTS_ERR_UNSUPPORTED; }
-                link_full = false;
-            }
+            } else if (pf == "yuv420p") link_full = false;
             if (fmt == TTS_FMT_YUV420P) { yuv_pinned = true; continue; }
-            if (range_in_scale) { err = "packed RGB behind a scale that writes yuvj420p: write format=yuv420p,format=yuvj420p in front of it (a range pass of its own)"; return TTS_ERR_UNSUPPORTED; }
+            if (sc_step != TTS_RANGE_KEEP) { err = "packed RGB behind a scale that changes the range: pin the scale's output first (format=yuv420p,format=yuvj420p: a range pass of its own)"; return TTS_ERR_UNSUPPORTED; }
+            if (g.in_fmt == TTS_FMT_YUV420P && cur_full && end_step != TTS_RANGE_TO_FULL) { err = "packed RGB out of a full-range source: not supported"; return TTS_ERR_UNSUPPORTED; }
             // (RGB from a full-range link, `format=yuvj420p,format=rgb24`: the range pass stays in out_range and the conversion
             // pass behind it reads a yuvj420p source -- full-range yuv2rgb tables; yuv_pinned is set, so it sits at the end)
             g.out_fmt = fmt;
@@ -499,14 +529,15 @@ int parse_vf(const char *vf, int iw, int ih, tts_geom &g, std::string &err, int 
         if (g.do_pad && g.rgb_stage != TTS_RGB_AT_END) rgb_to_yuv_full((g.fill_rgb >> 16) & 255, (g.fill_rgb >> 8) & 255, g.fill_rgb & 255, g);
         g.sc_range = TTS_RANGE_TO_FULL; g.out_range = TTS_RANGE_KEEP;     // (the converting context's own step, not a pass at the end)
     }
-    if (range_in_scale && g.out_range == TTS_RANGE_TO_FULL) {
-        if (g.do_scale) {
-            g.sc_range = TTS_RANGE_TO_FULL; g.out_range = TTS_RANGE_KEEP;
-            // the pad sits on a yuvj420p link: drawutils.c ff_draw_color() with full_range, libavutil/colorspace.h RGB_TO_Y_JPEG & co.
-            if (g.do_pad) rgb_to_yuv_full((g.fill_rgb >> 16) & 255, (g.fill_rgb >> 8) & 255, g.fill_rgb & 255, g);
-        } else if (g.do_pad) {
-            err = "a scale to the same size that writes yuvj420p, then a pad: not supported"; return TTS_ERR_UNSUPPORTED;
-        }   // (else: the same bytes as a pass of its own -- one-tap filters around the range step)
+    if (g.in_fmt == TTS_FMT_YUV420P) {
+        g.out_range = end_step;
+        if (sc_step != TTS_RANGE_KEEP) {
+            if (g.do_scale) g.sc_range = sc_step;
+            else if (end_step == TTS_RANGE_KEEP && !g.do_pad) g.out_range = sc_step;   // (a scale to the same size: one-tap filters around the step -- the bytes of a pass of its own)
+            else { err = "a scale to the same size that changes the range, then a pad or another range step: not supported"; return TTS_ERR_UNSUPPORTED; }
+        }
+        // the pad's colour in the range of its link: drawutils.c ff_draw_color() with full_range, libavutil/colorspace.h RGB_TO_Y_JPEG & co.
+        if (g.do_pad && pad_full && g.rgb_stage != TTS_RGB_AT_SCALE) rgb_to_yuv_full((g.fill_rgb >> 16) & 255, (g.fill_rgb >> 8) & 255, g.fill_rgb & 255, g);
     }
     const int rc = check_geom(g);
     if (rc) err = "resolved geometry is invalid";

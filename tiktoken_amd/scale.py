@@ -18,12 +18,13 @@ def frame_bytes(w, h):
     return int(_lib.lib().tts_frame_bytes(w, h))
 
 
-FMT = {"yuv420p": 0, "rgb24": 1, "bgr24": 2, "rgba": 3, "bgra": 4}
+FMT = {"yuv420p": 0, "rgb24": 1, "bgr24": 2, "rgba": 3, "bgra": 4, "yuvj420p": 5}   # (yuvj420p: as an INPUT format only -- full-range planes)
 
 
 def parse_vf(vf, iw, ih, in_fmt="yuv420p"):
     """Resolve a filter chain for an iw x ih input -> Geom (raises TtsError).  in_fmt: "yuv420p", or "rgb24" /
-    "bgr24" / "rgba" / "bgra" for a chain fed with packed RGB (`-pix_fmt rgb24 -i ...`)."""
+    "bgr24" / "rgba" / "bgra" for a chain fed with packed RGB (`-pix_fmt rgb24 -i ...`), or "yuvj420p" for yuv420p planes that
+    hold full-range samples (the geometry then says what differs: sc_range / out_range, the pad colour)."""
     g = Geom()
     rc = _lib.lib().tts_parse_vf_fmt(vf.encode(), iw, ih, FMT[in_fmt], ctypes.byref(g))
     check(rc, _lib.lib().tts_last_error().decode() if rc else "")
