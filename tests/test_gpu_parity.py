@@ -130,6 +130,15 @@ def test_row_segmentation_is_invisible(tts, oracle, monkeypatch, seg):
     ("scale=136:96", 24, 60, 33, False),
     ("scale=320:200", 200, 6, 33, False),
     ("scale=20:4", 200, 6, 33, False),
+    # the range step inside the scale's context (tts_geom.sc_range) in pointer mode: the RNG strip and column kernels, and the
+    # general kernel where pointer mode would take the register walk (which has no such form)
+    ("scale=284:160,format=yuvj420p", 160, 90, 5, True),
+    ("scale=284:160,format=yuvj420p", 160, 90, 130, False),
+    ("scale=72:40,format=yuvj420p", 54, 30, 33, False),
+    ("scale=136:96,format=yuvj420p", 24, 60, 33, False),
+    ("scale=355:267,format=yuvj420p", 200, 150, 2, "planewise"),
+    ("scale=213:121,format=yuvj420p", 640, 360, 3, False),
+    ("scale=1080:1920:force_original_aspect_ratio=increase,crop=1080:1920,format=yuvj420p", 1280, 720, 1, "planewise"),
 ])
 def test_frame_pointer_api_matches_batch_api(tts, oracle, monkeypatch, vf, iw, ih, n, pad):
     """tts_run with per-frame plane pointers (every plane its own allocation, padded or tight strides)
@@ -712,14 +721,20 @@ def test_host_frames_through_tts_run(tts, oracle):
 
 @pytest.mark.parametrize("vf,iw,ih,family", [
     ("scale=320x180:force_original_aspect_ratio=decrease,pad=320x180:-1:-1:color=black,format=yuvj420p", 1920, 1080, "column_lds"),   # many taps
-    ("scale=1080:1920:force_original_aspect_ratio=increase,crop=1080:1920,format=yuvj420p", 1280, 720, "column_lds"),                  # four taps: the column walk all the same
-    ("scale=640:360:flags=area,format=yuvj420p", 1280, 720, "column_lds"),
-    ("scale=12:10,format=yuvj420p", 8, 8, "generic"),                                                                                  # too small for the walk
+    ("scale=1080:1920:force_original_aspect_ratio=increase,crop=1080:1920,format=yuvj420p", 1280, 720, "strip_lds<4,4,grouped"),       # four taps: the hot kernel's RNG form
+    ("scale=1080:1920:force_original_aspect_ratio=increase,crop=1080:1920,format=yuvj420p", 3840, 2160, "strip_lds<6,6,grouped"),      # 1.125x shrink: 12-byte windows, four columns each
+    ("scale=720:1280,format=yuvj420p", 1080, 1920, "strip_lds<6,6,grouped,"),                                                          # the web box, 1.5x
+    ("scale=1920:1080,format=yuvj420p", 3840, 2160, "strip_lds<8,8,grouped2"),                                                         # 2x: 8 taps, four rows in flight
+    ("scale=720:1280,pad=800:1300:-1:-1:color=red,format=yuvj420p", 480, 854, "strip_lds<4,4,grouped"),                                # R1 + a pad on the yuvj420p link
+    ("scale=640:360:flags=area,format=yuvj420p", 1280, 720, "column_lds"),                                                           # per-column windows have no RNG form: the column walk
+    ("scale=320:568:flags=area,format=yuvj420p", 1080, 1920, "strip_lds<6,6,grouped2"),                                                # 3.4x area thumbnails: two columns a window
+    ("scale=500:300:flags=bilinear,format=yuvj420p", 1280, 720, ""),                                                                   # whatever the planner picks
+    ("scale=12:10,format=yuvj420p", 8, 8, "generic"),                                                                                  # too small for the walks
 ])
 def test_range_step_inside_the_scale(tts, oracle, vf, iw, ih, family):
     """`scale=...,format=yuvj420p` with nothing pinning yuv420p in between: swscale converts the range on the scale's 15-bit rows
-    (oracle: tto_scale_plane_range).  The column walk carries the step for every tap count (",range15" in its name), the general
-    kernel behind it; the pinned form of the same chain gives other bytes."""
+    (oracle: tto_scale_plane_range).  The grouped-window strip kernels and the column walk carry the step (",range15" in their
+    names), the general kernel behind them; the pinned form of the same chain gives other bytes."""
     import torch
     plan = tts.Plan.from_vf(vf, iw, ih)
     assert plan.geom.sc_range == 1 and plan.geom.out_range == 0
@@ -728,7 +743,7 @@ def test_range_step_inside_the_scale(tts, oracle, vf, iw, ih, family):
     pinned = tts.Plan.from_vf(vf.replace(",format=yuvj420p", ",format=yuv420p,format=yuvj420p"), iw, ih)
     assert pinned.geom.sc_range == 0 and pinned.geom.out_range == 1 and "range15" not in pinned.kernel_name(0)
     for pat in ("random", "impulse", "limited"):
-        src = synth.frames(pat, iw, ih, 3)
+        src = synth.frames(pat, iw, ih, 2 if iw > 2000 else 3)
         d = torch.from_numpy(src).cuda()
         got = plan.run_batch(d).cpu().numpy()
         want = oracle.run_chain(plan.geom, src)

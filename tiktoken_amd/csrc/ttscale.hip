@@ -68,7 +68,17 @@ static int build_classes(tts_plan *p, const tts_geom &g, bool full_v, bool force
 {
     std::vector<uint32_t> tab;
     int rc = TTS_OK;
-    for (int ci = 0; ci < 2 && rc == TTS_OK; ++ci) rc = build_class(g, ci, p->cls[ci], tab, 0, full_v && ci, force_column);   // (full_v: a scratch plan)
+    // (a range step inside the scale's context: strip classes whose windows do not group have no instantiation for it and
+    // take the column walk, whatever their tap count)
+    const bool range_in_scale = g.in_fmt == TTS_FMT_YUV420P && g.out_fmt == TTS_FMT_YUV420P && g.sc_range != TTS_RANGE_KEEP;
+    for (int ci = 0; ci < 2 && rc == TTS_OK; ++ci) {
+        rc = build_class(g, ci, p->cls[ci], tab, 0, full_v && ci, force_column);   // (full_v: a scratch plan)
+        if (rc == TTS_OK && range_in_scale && p->cls[ci].kind == 1 && !strip_has_rng(strip_choice(p->cls[ci], p->knobs))) {
+            free_class(p->cls[ci]);
+            p->cls[ci] = ClassPlan();
+            rc = build_class(g, ci, p->cls[ci], tab, 0, full_v && ci, true);
+        }
+    }
     // Column walk: luma and chroma ratios differ by a rounding, so their tap counts may straddle an
     // instantiation boundary (720x1280 -> 101x180: 16 tap pairs luma, 14 chroma) and the chain would take two
     // launches.  The class with fewer is rebuilt with the other's window: a seventh more arithmetic on a third
@@ -244,7 +254,8 @@ const char *tts_plan_kernel_name(const tts_plan *p, int plane_class)
     }
     else {
         const StripChoice ch = strip_choice(c, p->knobs);
-        if (ch.lds) std::snprintf(buf, sizeof buf, "strip_lds<%d,%d,%s,%d,%d>", ch.LW, ch.R, ch.g12 == 2 ? "grouped2" : ch.g4 ? "grouped" : "percolumn", ch.lds, ch.depth);
+        const bool rng15 = p->g.in_fmt == TTS_FMT_YUV420P && p->g.out_fmt == TTS_FMT_YUV420P && p->g.sc_range != TTS_RANGE_KEEP;
+        if (ch.lds) std::snprintf(buf, sizeof buf, "strip_lds<%d,%d,%s,%d,%d%s>", ch.LW, ch.R, ch.g12 == 2 ? "grouped2" : ch.g4 ? "grouped" : "percolumn", ch.lds, ch.depth, rng15 ? ",range15" : "");
         else std::snprintf(buf, sizeof buf, "strip<%d,%d,%d,%s>", ch.LW, ch.R, ch.N, ch.g4 ? "grouped" : "percolumn");
     }
     return buf;

@@ -63,7 +63,7 @@ struct StripArgs {
     // queue == nullptr: one workgroup per logical block, grid_scaler == scaler_blocks.
     uint32_t grid_scaler;
     uint32_t *queue;
-    RangeStep15 r15;               // column walk, RNG instantiations only
+    RangeStep15 r15;               // RNG instantiations only (strip_lds_kernel, column_lds_kernel)
     int32_t  y16;                  // column walk only: class 0 (luma) stores its UNCLIPPED vertical sums as int16 (2 bytes a column): the
                                    // intermediate of the packed-RGB thumbnail path (ttscale_rgb.hip rgb_scratch_convert_kernel)
     uint64_t *dbg;                 // -DTTS_EXPERIMENTS builds: (start, end) clock of every workgroup of strip_lds_kernel; else null, unused
@@ -470,7 +470,11 @@ __device__ __forceinline__ void plan_runs(const StripArgs &a, const StripClass &
 // chunks); D: source rows in flight per wave, one LDS slot each.  Eight columns per lane.
 // Y16: with a.y16 set, slot 0 (luma) stores its sums UNCLIPPED as int16 (the RGB scratch planes, see the column
 // walk); a parameter rather than a test so that the planar instantiations keep their registers.
-template <int LW, int R, int GC, int NDMA, int D, bool Y16 = false>
+// RNG: the converting context's own range step on the 15-bit rows (StripArgs.r15; swscale's lumConvertRange / chrConvertRange),
+// between the horizontal finish and the ring: (min(t, cap) * mul + add) >> shift as ONE v_mad_i32_i24 whose product carries
+// 1 << (16 - shift), so that the sample lands in the high half and the ring insert picks it from there (every constant pair
+// of swscale.c's four functions keeps (min(t, cap) * mul + add) << (16 - shift) inside int32: 2,147,432,768 at most).
+template <int LW, int R, int GC, int NDMA, int D, bool Y16 = false, bool RNG = false>
 __global__ __launch_bounds__(kMaxLdsBlock, (GC == 4 && R == 4 && LW == 4) ? 8 : 4) void strip_lds_kernel(const uint8_t *__restrict__ src, uint8_t *__restrict__ dst,
                                                                                const uint32_t *__restrict__ tab, const StripArgs a)
 {
@@ -596,6 +600,11 @@ __global__ __launch_bounds__(kMaxLdsBlock, (GC == 4 && R == 4 && LW == 4) ? 8 : 
     const bool bar = c.paced != 0;
     const bool rng = a.range.on != 0;
     const int rmul = a.range.mul[ci], radd = a.range.add[ci], rsh = a.range.shift[ci];
+    [[maybe_unused]] int r15cap = 0, r15mul = 0, r15add = 0;
+    if constexpr (RNG) {
+        const int up = 1 << (16 - a.r15.shift[ci]);
+        r15cap = a.r15.cap[ci]; r15mul = a.r15.mul[ci] * up; r15add = a.r15.add[ci] * up;
+    }
 
     const __amdgpu_buffer_rsrc_t srs = __builtin_amdgcn_make_buffer_rsrc(const_cast<uint8_t *>(wsrc), 0, src_rec, 0x00020000);
     const uint64_t dbase = reinterpret_cast<uint64_t>(wdst);
@@ -681,7 +690,12 @@ __global__ __launch_bounds__(kMaxLdsBlock, (GC == 4 && R == 4 && LW == 4) ? 8 : 
                     for (int tp = 0; tp < LW / 2; ++tp)         // taps 2tp, 2tp+1 sit at bytes o + 2 (tp % 2) of dwords tp / 2, tp / 2 + 1
                         acc = dot2(__builtin_amdgcn_perm(wk[i][tp / 2 + 1], wk[i][tp / 2], psel[i][tp % 2]), hc[i][tp], acc);
                 }
-                if constexpr (HB) {
+                if constexpr (RNG) {
+                    // (every cap is <= 32767: the horizontal pass's own clip rides in the same v_min)
+                    const uint32_t t2 = uint32_t(__mul24(min(acc >> (HB ? 15 : 7), r15cap), r15mul) + r15add);
+                    ring[i][s / 2] = (s & 1) ? __builtin_amdgcn_perm(t2, ring[i][s / 2], 0x07060100)
+                                             : __builtin_amdgcn_perm(ring[i][s / 2], t2, 0x07060302);
+                } else if constexpr (HB) {
                     uint32_t t2;
                     asm("v_add_i32 %0, %1, %1 clamp" : "=v"(t2) : "v"(acc));
                     ring[i][s / 2] = (s & 1) ? __builtin_amdgcn_perm(t2, ring[i][s / 2], 0x07060100)

@@ -309,12 +309,11 @@ int build_class(const tts_geom &g, int sub, ClassPlan &c, std::vector<uint32_t> 
     const int HT = c.h.size, VT = c.v.size;
     const int LW = HT <= 4 ? 4 : 8;
     const int R = VT <= 4 ? 4 : VT <= 6 ? 6 : 8;
-    // A range step INSIDE the scale's context (filter.cpp check_geom: `format=yuvj420p` right behind the scale) converts the
-    // 15-bit rows between the two passes: the column walk carries that (its RNG instantiations, whatever the tap count), and
-    // the general kernel (GenericArgs.range15) where the column walk does not fit
-    const bool range_in_scale = g.in_fmt == TTS_FMT_YUV420P && g.out_fmt == TTS_FMT_YUV420P && g.sc_range != TTS_RANGE_KEEP;
+    // (A range step INSIDE the scale's context -- tts_geom.sc_range -- converts the 15-bit rows between the two passes: the
+    // grouped-window strip kernels and the column walk have RNG instantiations for it, the general kernel GenericArgs.range15;
+    // a class whose strip tables come out ungrouped is rebuilt for the column walk by the caller: force_column)
     const bool strip_ok = !force_column && HT <= 8 && VT <= 8 && c.src_w >= LW && monotone(c.v.pos) &&
-                          !env_int("TTS_FORCE_GENERIC", 0) && !range_in_scale;
+                          !env_int("TTS_FORCE_GENERIC", 0);
     if (!strip_ok) {
         // Many taps: the column walk, if the taps fit its windows and ring and the runs fit its slot.
         c.kind = 0;
@@ -541,16 +540,21 @@ StripChoice strip_choice(const ClassPlan &c, const Knobs &kn)
 
 // y16: the instantiation with the 16-bit luma store (scratch plans; the grouped 12-byte-window kernels only)
 bool strip_has_y16(const StripChoice &ch) { return ch.lds && ch.g12; }
+// rng: the instantiation with the range step on the 15-bit rows (tts_geom.sc_range; the grouped-window LDS kernels only:
+// every enlargement and the usual shrinks up to 2x -- what they do not cover takes the column walk, decided when the plan is built)
+bool strip_has_rng(const StripChoice &ch) { return ch.lds && ch.g4; }
 
-strip_fn pick_strip(const StripChoice &ch, const Knobs &kn, bool y16 = false)
+strip_fn pick_strip(const StripChoice &ch, const Knobs &kn, bool y16 = false, bool rng = false)
 {
     const int D = kn.strip_d;                          // rows in flight of the register kernels (tuning knob)
     if (y16 && !strip_has_y16(ch)) return nullptr;
+    if (rng && (y16 || !strip_has_rng(ch))) return nullptr;
+#define TTS_R(LW_, R_, GC_, NDMA_, D_) (rng ? strip_lds_kernel<LW_, R_, GC_, NDMA_, D_, false, true> : strip_lds_kernel<LW_, R_, GC_, NDMA_, D_>)
     if (ch.lds && ch.g4 && !ch.g12) {
-        if (ch.R == 4) return ch.depth == 2 ? strip_lds_kernel<4, 4, 4, 1, 2> : strip_lds_kernel<4, 4, 4, 1, 1>;
-        return ch.R == 6 ? strip_lds_kernel<4, 6, 4, 1, 1> : strip_lds_kernel<4, 8, 4, 1, 1>;
+        if (ch.R == 4) return ch.depth == 2 ? TTS_R(4, 4, 4, 1, 2) : TTS_R(4, 4, 4, 1, 1);
+        return ch.R == 6 ? TTS_R(4, 6, 4, 1, 1) : TTS_R(4, 8, 4, 1, 1);
     }
-#define TTS_Y(LW_, R_, GC_, NDMA_, D_) (y16 ? strip_lds_kernel<LW_, R_, GC_, NDMA_, D_, true> : strip_lds_kernel<LW_, R_, GC_, NDMA_, D_>)
+#define TTS_Y(LW_, R_, GC_, NDMA_, D_) (y16 ? strip_lds_kernel<LW_, R_, GC_, NDMA_, D_, true> : TTS_R(LW_, R_, GC_, NDMA_, D_))
     if (ch.lds && ch.g12 == 4) return ch.R == 4 ? TTS_Y(6, 4, 4, 1, 1) : ch.R == 6 ? TTS_Y(6, 6, 4, 1, 1) : TTS_Y(6, 8, 4, 1, 1);
     if (ch.lds && ch.g12 == 2) {
 #define TTS_G2_PICK(LW_, R_) (ch.lds == 1 ? TTS_Y(LW_, R_, 2, 1, 1) : ch.lds == 2 ? TTS_Y(LW_, R_, 2, 2, 1) : TTS_Y(LW_, R_, 2, 4, 1))
@@ -560,6 +564,7 @@ strip_fn pick_strip(const StripChoice &ch, const Knobs &kn, bool y16 = false)
 #undef TTS_G2_PICK
     }
 #undef TTS_Y
+#undef TTS_R
     if (ch.lds) {
 #define TTS_LDS_PICK(LW_, R_) (ch.lds == 1 ? strip_lds_kernel<LW_, R_, 0, 1, 1> : ch.lds == 2 ? strip_lds_kernel<LW_, R_, 0, 2, 1> : strip_lds_kernel<LW_, R_, 0, 4, 1>)
         if (ch.LW == 4) return ch.R == 4 ? TTS_LDS_PICK(4, 4) : ch.R == 6 ? TTS_LDS_PICK(4, 6) : TTS_LDS_PICK(4, 8);
@@ -824,7 +829,24 @@ int launch_all(const tts_plan *p, const uint8_t *src, uint8_t *dst, int n, const
     // of their own (fill_kernel before, range_kernel after); the strip and column walks carry both themselves:
     // the border is written by extra workgroups of the scaler's launch, the range step sits in its store
     // epilogue, so the reference's thumbnail chain (src/services/video.js:329-334) is ONE launch.
+    // (sc_range, a range step inside the scale's context: the RNG instantiations of the grouped strip kernels and of the column
+    // walk and the general kernel carry it; out_range, the pass at the end, is independent of it -- a full-range source
+    // thumbnailed the reference's way has both)
+    const bool range_in_scale = p->g.in_fmt == TTS_FMT_YUV420P && p->g.out_fmt == TTS_FMT_YUV420P && p->g.sc_range != TTS_RANGE_KEEP;
     bool to_generic[2] = {false, false};
+    if (range_in_scale) {
+        // the register strip kernels (tiny sources, per-frame pointers into short planes: see the strip classes below) have no
+        // such instantiation: then every strip class of the launch set takes the general kernel
+        bool short_plane = false, no_rng = false;
+        for (int ci = 0; ci < 2; ++ci) {
+            const ClassPlan &c = p->cls[ci];
+            if (c.kind != 1 || !active(ci)) continue;
+            short_plane |= c.segs[0].nseg < 2 || c.segs[0].spans_plane || c.src_w < 48 || c.src_h < 32;
+            no_rng |= !strip_has_rng(strip_choice(c, p->knobs));
+        }
+        if (no_rng || src_span < 4096u || (addr.use_table && short_plane))
+            for (int ci = 0; ci < 2; ++ci) if (p->cls[ci].kind == 1) to_generic[ci] = true;
+    }
     for (int ci = 0; ci < 2; ++ci) {
         const ClassPlan &c = p->cls[ci];
         if (c.kind == 0) to_generic[ci] = true;
@@ -833,9 +855,6 @@ int launch_all(const tts_plan *p, const uint8_t *src, uint8_t *dst, int n, const
         // store int16 luma; the caller falls back)
         if (p->y16 && (c.kind == 0 || to_generic[ci]) && active(ci)) { g_last_error = "scratch pass needs the column walk or an LDS strip kernel"; return TTS_ERR_UNSUPPORTED; }
     }
-    // (sc_range, a range step inside the scale's context: the column walk's RNG instantiations and the general kernel carry it;
-    // out_range, the pass at the end, is independent of it -- a full-range source thumbnailed the reference's way has both)
-    const bool range_in_scale = p->g.in_fmt == TTS_FMT_YUV420P && p->g.out_fmt == TTS_FMT_YUV420P && p->g.sc_range != TTS_RANGE_KEEP;
     const int range_at_end = p->g.out_range;
     RangeStep range{};
     if (range_at_end != TTS_RANGE_KEEP) {
@@ -898,7 +917,17 @@ int launch_all(const tts_plan *p, const uint8_t *src, uint8_t *dst, int n, const
     };
     // strip classes: one launch when both classes run the same instantiation, else one each
     int strip_cls[2], ns = 0;
-    for (int ci = 0; ci < 2; ++ci) if (p->cls[ci].kind == 1 && active(ci)) strip_cls[ns++] = ci;
+    for (int ci = 0; ci < 2; ++ci) if (p->cls[ci].kind == 1 && active(ci) && !to_generic[ci]) strip_cls[ns++] = ci;
+    // swscale.c lumRangeToJpeg_c / chrRangeToJpeg_c / lumRangeFromJpeg_c / chrRangeFromJpeg_c: {cap, mul, add, shift} per class
+    static const int32_t r15_to_full[2][4] = {{30189, 19077, -39057361, 14}, {30775, 4663, -9289992, 12}};
+    static const int32_t r15_to_limited[2][4] = {{32767, 14071, 33561947, 14}, {32767, 1799, 4081085, 11}};
+    auto set_r15 = [&](StripArgs &a, bool both, int ci) {   // (a single class rides in slot 0)
+        const int32_t (*t)[4] = p->g.sc_range == TTS_RANGE_TO_FULL ? r15_to_full : r15_to_limited;
+        for (int slot = 0; slot < 2; ++slot) {
+            const int k = both ? slot : ci;
+            a.r15.cap[slot] = t[k][0]; a.r15.mul[slot] = t[k][1]; a.r15.add[slot] = t[k][2]; a.r15.shift[slot] = t[k][3];
+        }
+    };
     bool merged = false;
     if (ns == 2 && !p->knobs.no_merge) {
         const StripChoice a0 = strip_choice(p->cls[0], p->knobs), a1 = strip_choice(p->cls[1], p->knobs);
@@ -924,8 +953,9 @@ int launch_all(const tts_plan *p, const uint8_t *src, uint8_t *dst, int n, const
         if (src_span < 4096u || (addr.use_table && short_plane)) { ch.lds = 0; ch.depth = 1; ch.LW = p->cls[ci].LW; if (ch.g12) { ch.g4 = false; ch.g12 = 0; } }
         a.y16 = p->y16 && (merged || ci == 0);
         if (p->y16 && !strip_has_y16(ch)) return TTS_ERR_UNSUPPORTED;   // (the caller falls back to the RGB kernels)
-        strip_fn fn = pick_strip(ch, p->knobs, a.y16 != 0);
+        strip_fn fn = pick_strip(ch, p->knobs, a.y16 != 0, range_in_scale);
         if (!fn) return TTS_ERR_UNSUPPORTED;
+        if (range_in_scale) set_r15(a, merged, ci);
         size_t si[2];
         int max_items = 0;
         int64_t total_items = 0;
@@ -1032,15 +1062,7 @@ int launch_all(const tts_plan *p, const uint8_t *src, uint8_t *dst, int n, const
             a.scaler_blocks = a.c[0].nblocks + (cmerged ? a.c[1].nblocks : 0);
             a.grid_scaler = a.scaler_blocks; a.queue = nullptr;
             a.y16 = p->y16 && (cmerged || ci == 0);
-            if (rng15) {                                   // swscale.c lumRangeToJpeg_c / chrRangeToJpeg_c / lumRangeFromJpeg_c / chrRangeFromJpeg_c
-                static const int32_t to_full[2][4] = {{30189, 19077, -39057361, 14}, {30775, 4663, -9289992, 12}};
-                static const int32_t to_limited[2][4] = {{32767, 14071, 33561947, 14}, {32767, 1799, 4081085, 11}};
-                const int32_t (*t)[4] = p->g.sc_range == TTS_RANGE_TO_FULL ? to_full : to_limited;
-                for (int slot = 0; slot < 2; ++slot) {
-                    const int cls_of_slot = cmerged ? slot : ci;   // (a single class rides in slot 0)
-                    a.r15.cap[slot] = t[cls_of_slot][0]; a.r15.mul[slot] = t[cls_of_slot][1]; a.r15.add[slot] = t[cls_of_slot][2]; a.r15.shift[slot] = t[cls_of_slot][3];
-                }
-            }
+            if (rng15) set_r15(a, cmerged, ci);
 #ifdef TTS_EXPERIMENTS
             a.dbg = exp_dbg_buffer(a.scaler_blocks);
 #endif
