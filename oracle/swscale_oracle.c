@@ -335,6 +335,33 @@ static void tto_copy_rect(const uint8_t *s, int ss, uint8_t *d, int ds, int w, i
     for (int y = 0; y < h; y++) memcpy(d + (size_t)y * ds, s + (size_t)y * ss, (size_t)w);
 }
 
+/* A range pass of its own over a finished frame (out_range 1: to full, 2: to limited), in place. */
+static void tto_range_pass(int out_range, int out_w, int out_h, uint8_t *dy, uint8_t *du, uint8_t *dv, int dys, int dus, int dvs)
+{
+    uint8_t *dp[3] = {dy, du, dv};
+    const int dst_[3] = {dys, dus, dvs};
+    if (!out_range) return;
+    for (int p = 0; p < 3; p++) {
+        const int sub = p ? 1 : 0;
+        const int ow = (out_w + sub) >> sub, oh = (out_h + sub) >> sub;
+        for (int y = 0; y < oh; y++) {
+            uint8_t *row = dp[p] + (size_t)y * dst_[p];
+            for (int x = 0; x < ow; x++) {
+                int v = row[x] << 7;
+                if (out_range == 1) {
+                    if (p) { if (v > 30775) v = 30775; v = (v * 4663 - 9289992) >> 12; }
+                    else   { if (v > 30189) v = 30189; v = (v * 19077 - 39057361) >> 14; }
+                } else {
+                    if (p) v = (v * 1799 + 4081085) >> 11;
+                    else   v = (v * 14071 + 33561947) >> 14;
+                }
+                v = (v + 64) >> 7;
+                row[x] = (uint8_t)(v < 0 ? 0 : v > 255 ? 255 : v);
+            }
+        }
+    }
+}
+
 int tto_run_chain(const tto_chain *c,
                   const uint8_t *sy, const uint8_t *su, const uint8_t *sv,
                   int sys, int sus, int svs,
@@ -387,27 +414,7 @@ int tto_run_chain(const tto_chain *c,
      * (v = p << 7), lum/chrConvertRange on the 15-bit row (swscale.c lumRangeToJpeg_c,
      * chrRangeToJpeg_c, lumRangeFromJpeg_c, chrRangeFromJpeg_c -- constants of FFmpeg 4.x-6.0,
      * recalled, UNVERIFIED), then yuv2plane1_8_c: (v + 64) >> 7 clipped.  Borders included. */
-    if (c->out_range) {
-        for (int p = 0; p < 3; p++) {
-            const int sub = p ? 1 : 0;
-            const int ow = (c->out_w + sub) >> sub, oh = (c->out_h + sub) >> sub;
-            for (int y = 0; y < oh; y++) {
-                uint8_t *row = dp[p] + (size_t)y * dst_[p];
-                for (int x = 0; x < ow; x++) {
-                    int v = row[x] << 7;
-                    if (c->out_range == 1) {
-                        if (p) { if (v > 30775) v = 30775; v = (v * 4663 - 9289992) >> 12; }
-                        else   { if (v > 30189) v = 30189; v = (v * 19077 - 39057361) >> 14; }
-                    } else {
-                        if (p) v = (v * 1799 + 4081085) >> 11;
-                        else   v = (v * 14071 + 33561947) >> 14;
-                    }
-                    v = (v + 64) >> 7;
-                    row[x] = (uint8_t)(v < 0 ? 0 : v > 255 ? 255 : v);
-                }
-            }
-        }
-    }
+    tto_range_pass(c->out_range, c->out_w, c->out_h, dp[0], dp[1], dp[2], dst_[0], dst_[1], dst_[2]);
     return 0;
 }
 
@@ -855,6 +862,7 @@ int tto_run_chain_rgbin(const tto_chain *c, const uint8_t *src, int sstride,
             memcpy(canvas + ((size_t)(c->pad_y + y) * W + c->pad_x) * pb, src + (size_t)(c->pre_y + y) * sstride + (size_t)c->pre_x * pb, (size_t)c->pre_w * pb);
         rcc = tto_sws_packed_to_yuv420_range(c->in_fmt, canvas, W * pb, W, H, dy, du, dv, dys, dus, dvs, W, H, c->alg, c->sc_range == 1);
         (void)cw2;
+        if (!rcc) tto_range_pass(c->out_range, W, H, dy, du, dv, dys, dus, dvs);   /* (`...,format=yuv420p,format=yuvj420p`: the encoder's pass) */
         free(canvas);
         free(buf);
         return rcc;

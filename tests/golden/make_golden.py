@@ -68,6 +68,7 @@ RGBIN_CASES = {
     "rgbin_shrink_96x170_to_54x96": dict(geom(96, 170, 54, 96), in_fmt=1),                          # shrunk: chroma read from pixel pairs
     "rgbin_pad_on_rgb_64x36_in_80x61": dict(geom(64, 36, 64, 36, pad=(7, 5, 80, 61)), in_fmt=1, rgb_stage=2, fill_rgb=0x336699, out_fmt=0),   # no scale: the pad on RGB pixels, then the conversion of the canvas
     "rgbin_to_yuvj_96x170_to_54x96": dict(geom(96, 170, 54, 96), in_fmt=1, sc_range=1),            # the converting context writes full range (range step on its 15-bit rows)
+    "rgbin_thumb_pad_then_range_pass_72x128": dict(geom(72, 128, 101, 180, pad=(108, 0, 320, 180), out_range=1), in_fmt=1),   # the reference's thumbnail chain + its encoder's range pass, fed with rgb24
     "bgr24_same_size_66x37": dict(geom(66, 37, 66, 37), in_fmt=2),                                 # swscale's bgr24toYV12 converter (ff_rgb24toyv12_c), odd height
 }
 PATTERNS = ("random", "impulse", "zone")

@@ -210,6 +210,8 @@ def test_random_enlargements_packed_rgb_in(tts, oracle, seed):
             cw = max(8, int(rng.integers(8, ow + 1)) // 8 * 8)
             chh = int(rng.integers(8, oh + 1))
             parts.append("crop=%d:%d:%d:%d" % (cw, chh, int(rng.integers(0, ow - cw + 1)), int(rng.integers(0, oh - chh + 1))))
+        if rng.random() < 0.25:                                # what the frames leave as: full range out of the converting context, a pass of its own, or both
+            parts.append(str(rng.choice(["format=yuvj420p", "format=yuv420p,format=yuvj420p", "format=yuvj420p,format=yuv420p"])))
         vf, n = ",".join(parts), int(rng.choice([1, 2, 5, 21]))
         try:
             plan = tts.Plan.from_vf(vf, iw, ih, in_fmt="rgb24")
@@ -262,6 +264,8 @@ def test_random_shrinks_packed_rgb_in(tts, oracle, seed):
             cw, chh = 2 * int(rng.integers(8, ow // 2 + 1)), int(rng.integers(8, oh + 1))
             parts.append("crop=%d:%d:%d:%d" % (cw, chh, 2 * int(rng.integers(0, (ow - cw) // 2 + 1)), int(rng.integers(0, oh - chh + 1))))
         fmt = str(rng.choice(["rgb24", "rgb24", "bgr24", "rgba", "bgra"]))
+        if rng.random() < 0.25:
+            parts.append(str(rng.choice(["format=yuvj420p", "format=yuv420p,format=yuvj420p", "format=yuvj420p,format=yuv420p"])))
         vf, n = ",".join(parts), int(rng.choice([1, 2, 5, 19]))
         try:
             plan = tts.Plan.from_vf(vf, iw, ih, in_fmt=fmt)

@@ -699,7 +699,7 @@ def test_rgb24_input_host_path_and_rejections(tts, oracle):
     plan = tts.Plan.from_vf("scale=96:54", 64, 36, in_fmt="rgb24")
     src = rgb_frames("zone", 64, 36, 5)
     assert np.array_equal(plan.run_host(src), oracle.run_chain(plan.geom, src))
-    for vf, iw in (("scale=96:54,format=rgb24", 64), ("scale=48:27", 63), ("format=yuv420p", 63), ("pad=81:60", 64), ("scale=96:54,format=yuv420p,format=yuvj420p", 64)):
+    for vf, iw in (("scale=96:54,format=rgb24", 64), ("scale=48:27", 63), ("format=yuv420p", 63), ("pad=81:60", 64), ("scale=96:54,format=yuv420p,format=yuvj420p,format=yuv420p", 64)):
         with pytest.raises(tts.TtsError, match="UNSUPPORTED"):
             tts.Plan.from_vf(vf, iw, 36, in_fmt="rgb24")
 
@@ -759,3 +759,67 @@ def test_packed_rgb_input_into_yuvj420p(tts, oracle, vf, iw, ih, fmt):
         bad = np.flatnonzero(got != want)
         assert bad.size == 0, "%s %s %dx%d %s [%s]: %d bytes differ, first at %d" % (fmt, vf, iw, ih, pat, plan.kernel_name(0), bad.size, bad[0])
         assert not np.array_equal(got, limited.run_batch(d).cpu().numpy())
+
+
+THUMB_PINNED_RGBIN = "scale=320x180:force_original_aspect_ratio=decrease,pad=320x180:-1:-1:color=black,format=yuv420p,format=yuvj420p"
+RGBIN_RANGE_PASS_CASES = [
+    (THUMB_PINNED_RGBIN, 720, 1280, (0, 1)),                              # the reference's thumbnail chain + its mjpeg encoder, fed with RGB frames
+    (THUMB_PINNED_RGBIN, 1280, 720, (0, 1)),
+    ("format=yuv420p,format=yuvj420p", 64, 36, (0, 1)),                    # no scale: the conversion pass, then the range pass
+    ("scale=96:54,format=yuv420p,format=yuvj420p", 64, 36, (0, 1)),        # an enlargement (the strip walk)
+    ("scale=96:54,format=yuvj420p,format=yuv420p", 64, 36, (1, 2)),        # full range out of the converting context, back to limited at the end
+    ("pad=80:60:7:5:color=red,format=yuv420p,format=yuvj420p", 64, 36, (0, 1)),   # the pad on RGB pixels, conversion, range pass
+    ("format=yuv420p,pad=80:60:6:4:color=red,format=yuvj420p", 64, 36, (0, 1)),   # the pad behind the conversion, on yuv420p (limited-range red), range pass
+]
+
+
+@pytest.mark.parametrize("fmt", ["rgb24", "bgr24", "rgba"])
+@pytest.mark.parametrize("vf,iw,ih,steps", RGBIN_RANGE_PASS_CASES)
+def test_packed_rgb_input_then_a_range_pass(tts, oracle, vf, iw, ih, steps, fmt):
+    """Fed with packed RGB, a yuv format of the OTHER range behind the one the converting context wrote: a range pass of its own
+    over the finished frame (tts_geom.out_range), border included -- a launch of range_kernel behind the RGB-input kernels."""
+    import torch
+    plan = tts.Plan.from_vf(vf, iw, ih, in_fmt=fmt)
+    assert (plan.geom.sc_range, plan.geom.out_range) == steps and plan.kernel_name(0).endswith("+range_pass"), plan.kernel_name(0)
+    for pat in ("random", "impulse"):
+        src = repack(rgb_frames(pat, iw, ih, 3), iw, ih, fmt)
+        want = oracle.run_chain(plan.geom, src)
+        got = plan.run_batch(torch.from_numpy(src).cuda()).cpu().numpy()
+        bad = np.flatnonzero(got != want)
+        assert bad.size == 0, "%s %s %dx%d %s [%s]: %d bytes differ, first at %d" % (fmt, vf, iw, ih, pat, plan.kernel_name(0), bad.size, bad[0])
+    # the unpinned form of the same chain converts inside the context: other bytes
+    if steps == (0, 1) and "scale" in vf:
+        inside = tts.Plan.from_vf(vf.replace(",format=yuv420p,format=yuvj420p", ",format=yuvj420p"), iw, ih, in_fmt=fmt)
+        assert (inside.geom.sc_range, inside.geom.out_range) == (1, 0)
+        assert not np.array_equal(got, inside.run_batch(torch.from_numpy(src).cuda()).cpu().numpy())
+
+
+@pytest.mark.parametrize("planewise", [False, True])
+def test_packed_rgb_input_range_pass_through_frame_pointers(tts, oracle, monkeypatch, planewise):
+    """The same through tts_run: every plane its own allocation, padded rows (the range pass must stay off the padding)."""
+    import torch
+    if planewise:
+        monkeypatch.setenv("TTS_PLANEWISE", "1")
+    iw, ih, n = 72, 128, 5
+    plan = tts.Plan.from_vf(THUMB_PINNED_RGBIN, iw, ih, in_fmt="rgb24")
+    ow, oh = plan.out_size
+    src = rgb_frames("random", iw, ih, n)
+    want = oracle.run_chain(plan.geom, src)
+    sp, dp, ss, ds, keep = [], [], [], [], []
+    for i in range(n):
+        t = torch.zeros((ih, iw * 3 + 12), dtype=torch.uint8, device="cuda")
+        t[:, : iw * 3] = torch.from_numpy(src[i].reshape(ih, iw * 3)).cuda()
+        keep.append(t); sp.append([t.data_ptr(), 0, 0]); ss.append([iw * 3 + 12, 0, 0])
+        outs, ostr = [], []
+        for k in range(3):
+            w_, h_ = (ow, oh) if k == 0 else ((ow + 1) // 2, (oh + 1) // 2)
+            o = torch.full((h_, w_ + 16), 16, dtype=torch.uint8, device="cuda")   # (16: a value the range pass would change)
+            outs.append(o); ostr.append(w_ + 16)
+        dp.append(outs); ds.append(ostr)
+    plan.run_frames(sp, [[t.data_ptr() for t in o] for o in dp], ss, ds)
+    torch.cuda.synchronize()
+    for i in range(n):
+        for k, w in enumerate(synth.split(want[i], ow, oh)):
+            g = dp[i][k].cpu().numpy()
+            assert np.array_equal(g[:, : w.shape[1]], w), (i, k)
+            assert (g[:, w.shape[1]:] == 16).all(), "the range pass ran over the stride padding"

@@ -205,3 +205,22 @@ def test_parse_vf_full_range_source(tts):
             tts.parse_vf(vf, 640, 360, in_fmt="yuvj420p")
     with pytest.raises(tts.TtsError, match="two range passes"):
         tts.parse_vf("format=yuvj420p,format=yuv420p", 640, 360)
+
+
+def test_parse_vf_packed_rgb_source_range_steps(tts):
+    """Fed with packed RGB: the first yuv format is what the converting context writes (sc_range 1 for yuvj420p), one of the other
+    range behind it is a pass of its own at the end (out_range) -- the reference's thumbnail chain + its mjpeg encoder."""
+    T = "scale=320x180:force_original_aspect_ratio=decrease,pad=320x180:-1:-1:color=red"
+    for vf, want in ((T + ",format=yuv420p,format=yuvj420p", dict(sc_range=0, out_range=1, rgb_stage=0, fill_y=81, fill_u=90, fill_v=240)),
+                     (T + ",format=yuvj420p", dict(sc_range=1, out_range=0, fill_y=76, fill_u=85, fill_v=255)),
+                     (T + ",format=yuvj420p,format=yuv420p", dict(sc_range=1, out_range=2, fill_y=76)),
+                     ("format=yuv420p,format=yuvj420p", dict(sc_range=0, out_range=1, do_scale=0)),
+                     ("pad=700:400:-1:-1:color=red,format=yuv420p,format=yuvj420p", dict(sc_range=0, out_range=1, rgb_stage=2)),
+                     ("format=yuv420p,pad=700:400:-1:-1:color=red,format=yuvj420p", dict(sc_range=0, out_range=1, rgb_stage=0, fill_y=81)),
+                     ("format=yuvj420p,pad=700:400:-1:-1:color=red", dict(sc_range=1, out_range=0, rgb_stage=0, fill_y=76)),
+                     ("scale=320:180", dict(sc_range=0, out_range=0))):
+        g = tts.parse_vf(vf, 640, 360, in_fmt="rgb24").as_dict()
+        for k, v in want.items():
+            assert g[k] == v, (vf, k, g[k], v)
+    with pytest.raises(tts.TtsError, match="two range passes"):
+        tts.parse_vf("scale=320:180,format=yuv420p,format=yuvj420p,format=yuv420p", 640, 360, in_fmt="rgb24")

@@ -81,6 +81,8 @@ CHAINS = [
     ("scale=w=720:h=1280", 480, 854, "yuvj420p", "yuvj420p"),
     (THUMB_REF, 720, 1280, "yuv420p", "yuvj420p"),
     (THUMB_REF + ",format=yuvj420p", 720, 1280, "yuvj420p", "yuvj420p"),
+    # the reference's thumbnail chain + its encoder's range pass, fed with RGB frames
+    (THUMB_REF + ",format=yuvj420p", 720, 1280, "yuvj420p", "rgb24"),
     # packed RGB in, yuvj420p out: the converting context writes full range itself (limited-range table + lum/chrRangeToJpeg_c on its 15-bit rows)
     ("scale=640:360,format=yuvj420p", 1280, 720, "yuvj420p", "rgb24"),
     ("format=yuvj420p", 64, 48, "yuvj420p", "bgr24"),

@@ -228,8 +228,8 @@ int check_geom(const tts_geom &g)
         // a crop in front of the conversion works on RGB pixels (any offset); rgb24ToUV_half_c reads pixel pairs
         const bool canvas = g.rgb_stage == TTS_RGB_AT_END;      // (the conversion reads a padded RGB canvas: its width is checked below)
         // (sc_range TO_FULL on a chain fed with RGB: the converting context itself writes yuvj420p -- the range step on its 15-bit rows;
-        // a range pass of its own behind such a chain is not built)
-        if (g.out_fmt != TTS_FMT_YUV420P || g.out_range != TTS_RANGE_KEEP || g.sc_range == TTS_RANGE_TO_LIMITED || (!canvas && (g.pre_w & 1) && rgb_in_half_chroma(g.pre_w, g.sc_w))) return TTS_ERR_UNSUPPORTED;
+        // out_range: a range pass of its own over the finished frame, as behind any other chain)
+        if (g.out_fmt != TTS_FMT_YUV420P || g.sc_range == TTS_RANGE_TO_LIMITED || (!canvas && (g.pre_w & 1) && rgb_in_half_chroma(g.pre_w, g.sc_w))) return TTS_ERR_UNSUPPORTED;
         if (!canvas && bgr24_special_converter(g) && (g.pre_w & 1)) return TTS_ERR_UNSUPPORTED;   // (already covered: the same size is never an enlargement)
     } else if (has_pre && !(even(g.pre_x) && even(g.pre_y) && even(g.pre_w) && even(g.pre_h))) return TTS_ERR_INVALID_INPUT;
     if (g.sc_w < 1 || g.sc_h < 1 || g.sc_w > 16384 || g.sc_h > 16384) return TTS_ERR_INVALID_INPUT;

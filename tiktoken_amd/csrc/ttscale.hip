@@ -242,7 +242,12 @@ const char *tts_plan_kernel_name(const tts_plan *p, int plane_class)
         return sbuf;
     }
     if (p->rgb) return tts::rgb_plan_kernel_name(p->rgb);
-    if (p->rgbin) return tts::rgbin_plan_kernel_name(p->rgbin);
+    if (p->rgbin) {
+        if (p->g.out_range == TTS_RANGE_KEEP) return tts::rgbin_plan_kernel_name(p->rgbin);
+        static thread_local char rbuf[128];                 // (the range pass at the end: a launch of its own behind these kernels)
+        std::snprintf(rbuf, sizeof rbuf, "%s+range_pass", tts::rgbin_plan_kernel_name(p->rgbin));
+        return rbuf;
+    }
     const ClassPlan &c = p->cls[plane_class];
     if (c.kind == 0) std::snprintf(buf, sizeof buf, "generic");
     else if (c.kind == 2) {
@@ -284,6 +289,31 @@ int check_device(const tts_plan *p)
     return TTS_OK;
 }
 
+// Packed RGB in, tts_geom.out_range set (`...,format=yuv420p,format=yuvj420p`: the reference's thumbnail chain and its mjpeg
+// encoder, fed with RGB frames): the range pass over the finished canvas, in place, behind the kernels of ttscale_rgb.hip.
+// `addr` holds the canvas origins of the destination planes; `only` as in rgbin_launch.
+int rgbin_range_pass(const tts_plan *p, uint8_t *dst, int n, const int dstride[2], const FrameAddr &addr, hipStream_t st, int only = -1)
+{
+    const tts_geom &g = p->g;
+    if (g.out_range == TTS_RANGE_KEEP) return TTS_OK;
+    for (int ci = 0; ci < 2; ++ci) {
+        if (only >= 0 && ci != (only ? 1 : 0)) continue;
+        RangeArgs r{};
+        r.dst = dst; r.w = ceil_shift(g.out_w, ci); r.h = ceil_shift(g.out_h, ci); r.stride = dstride[ci];
+        r.planes = only >= 0 ? 1 : ci ? 2 : 1; r.plane0 = only >= 0 ? only : ci;
+        r.origin = 0;
+        r.addr = addr;
+        tts::build_range_lut(g.out_range, ci != 0, r.lut);
+        const int per = 65535 / r.planes;
+        for (int f0 = 0; f0 < n; f0 += per) {
+            r.frame0 = f0;
+            dim3 grid((r.w + 255) / 256, (r.h + 3) / 4, std::min(per, n - f0) * r.planes);
+            if (const int rc = launch_checked("range_kernel", range_kernel, grid, dim3(kBlock), 0, st, r)) return rc;
+        }
+    }
+    return TTS_OK;
+}
+
 // Frames at a fixed pitch, Y / U / V back to back inside a frame, rows `sstride[class]` / `dstride[class]`
 // bytes apart (class 0 = luma, 1 = both chroma planes).
 int run_batch_impl(const tts_plan *p, const void *src, size_t src_pitch, const int sstride[2], void *dst, size_t dst_pitch,
@@ -307,8 +337,9 @@ int run_batch_impl(const tts_plan *p, const void *src, size_t src_pitch, const i
         addr.dst_plane[0] = 0;
         addr.dst_plane[1] = uint32_t(dstride[0]) * uint32_t(g.out_h);
         addr.dst_plane[2] = addr.dst_plane[1] + uint32_t(dstride[1]) * uint32_t(ceil_shift(g.out_h, 1));
-        return tts::rgbin_launch(p->rgbin, static_cast<const uint8_t *>(src), static_cast<uint8_t *>(dst), n_frames, sstride[0], dstride,
-                                 addr, static_cast<hipStream_t>(hip_stream));
+        if (const int rc = tts::rgbin_launch(p->rgbin, static_cast<const uint8_t *>(src), static_cast<uint8_t *>(dst), n_frames, sstride[0], dstride,
+                                             addr, static_cast<hipStream_t>(hip_stream))) return rc;
+        return rgbin_range_pass(p, static_cast<uint8_t *>(dst), n_frames, dstride, addr, static_cast<hipStream_t>(hip_stream));
     }
     const int bpp = g.out_fmt == TTS_FMT_YUV420P ? 0 : g.out_fmt >= TTS_FMT_RGBA ? 4 : 3;   // packed RGB out: one plane
     for (int ci = 0; ci < 2; ++ci)
@@ -436,6 +467,7 @@ int run_rgbin_frames(const tts_plan *p, const tts_frame *src, const tts_frame *d
             const int rc = tts::rgbin_launch(p->rgbin, reinterpret_cast<const uint8_t *>(smin), reinterpret_cast<uint8_t *>(dmin), n,
                                              src[f0].stride[0], dstride, addr, static_cast<hipStream_t>(hip_stream), only);
             if (rc) return rc;
+            if (const int rrc = rgbin_range_pass(p, reinterpret_cast<uint8_t *>(dmin), n, dstride, addr, static_cast<hipStream_t>(hip_stream), only)) return rrc;
             f0 += n;
         }
         return TTS_OK;

@@ -2162,7 +2162,7 @@ int rgbin_plan_create(const tts_geom &g, RgbInPlan **out)
     const bool canvas = g.rgb_stage == TTS_RGB_AT_END;
     const int src_w = canvas ? g.out_w : g.pre_w, src_h = canvas ? g.out_h : g.pre_h, dst_w = canvas ? g.out_w : g.sc_w, dst_h = canvas ? g.out_h : g.sc_h;
     const bool half = rgb_in_half_chroma(src_w, dst_w);              // sws_init_context()'s chrSrcHSubSample for this context
-    if (g.in_fmt == TTS_FMT_YUV420P || g.out_fmt != TTS_FMT_YUV420P || g.out_range != TTS_RANGE_KEEP || g.sc_range == TTS_RANGE_TO_LIMITED || (half && (src_w & 1))) {
+    if (g.in_fmt == TTS_FMT_YUV420P || g.out_fmt != TTS_FMT_YUV420P || g.sc_range == TTS_RANGE_TO_LIMITED || (half && (src_w & 1))) {
         set_last_error("packed RGB in: the chain must hand out yuv420p or yuvj420p and, unless it widens the picture, read an even width");
         return TTS_ERR_UNSUPPORTED;
     }

@@ -300,8 +300,9 @@ int parse_vf(const char *vf, int iw, int ih, tts_geom &g, std::string &err, int 
     int sc_step = TTS_RANGE_KEEP, end_step = TTS_RANGE_KEEP;
     bool pad_full = src_full;
     try {
-        bool seen_scale = false, yuv_pinned = false, link_full = false;   // (the packed-RGB bookkeeping, as before)
+        bool seen_scale = false, yuv_pinned = false;                      // (the packed-RGB-out bookkeeping)
         bool cur_full = src_full, range_pass_seen = false;
+        bool rgb_converted = false;                                       // packed RGB in: the converting context has been passed
         const std::vector<std::string> filters = split(vf, ',');
         auto yuv_format_of = [&](const std::string &raw, bool &is_format, bool &full) {   // true: a yuv format filter
             const std::string f = trim(raw);
@@ -329,6 +330,17 @@ int parse_vf(const char *vf, int iw, int ih, tts_geom &g, std::string &err, int 
                     }
                     if (mid != cur_full) sc_step = mid ? TTS_RANGE_TO_FULL : TTS_RANGE_TO_LIMITED;
                     cur_full = mid;
+                } else if (!rgb_converted) {
+                    // packed RGB in: the scale is the converter; it writes the range of the first yuv format behind it (yuv420p
+                    // where nothing says), through the limited-range table + lum/chrRangeToJpeg_c for yuvj420p (sc_range)
+                    bool mid = false;
+                    for (size_t fj = fi + 1; fj < filters.size(); ++fj) {
+                        bool is_format, full;
+                        if (yuv_format_of(filters[fj], is_format, full)) { mid = full; break; }
+                        if (is_format) break;
+                    }
+                    if (mid) sc_step = TTS_RANGE_TO_FULL;
+                    cur_full = mid; rgb_converted = true;
                 }
                 seen_scale = true; yuv_pinned = false;
             }
@@ -343,12 +355,18 @@ int parse_vf(const char *vf, int iw, int ih, tts_geom &g, std::string &err, int 
                 cur_full = pf == "yuvj420p";
                 range_pass_seen = true;
             }
-            if (pf == "yuvj420p") {
-                // fed with packed RGB: the context that converts (the scale, or the pass inserted here) writes yuvj420p itself unless
-                // a format=yuv420p came first -- then this would be a range pass of its own behind it
-                if (g.in_fmt != TTS_FMT_YUV420P && (yuv_pinned || link_full)) { err = "packed RGB in: format=yuvj420p behind a format=yuv420p (a range pass of its own): not supported"; return TTS_ERR_UNSUPPORTED; }
-                link_full = true;
-            } else if (pf == "yuv420p") link_full = false;
+            if (g.in_fmt != TTS_FMT_YUV420P && fmt == TTS_FMT_YUV420P) {
+                // fed with packed RGB: the first yuv format is written by the context that converts (the scale in front of it, or
+                // the pass inserted here); one of the other range behind it is a range pass of its own (the reference's thumbnail
+                // chain pins yuv420p and its mjpeg encoder asks for yuvj420p: `...,format=yuv420p,format=yuvj420p`)
+                const bool full = pf == "yuvj420p";
+                if (!rgb_converted) { if (full) sc_step = TTS_RANGE_TO_FULL; cur_full = full; rgb_converted = true; }
+                else if (full != cur_full) {
+                    if (end_step != TTS_RANGE_KEEP) { err = "two range passes in one chain: not supported"; return TTS_ERR_UNSUPPORTED; }
+                    end_step = full ? TTS_RANGE_TO_FULL : TTS_RANGE_TO_LIMITED;
+                    cur_full = full;
+                }
+            }
             if (fmt == TTS_FMT_YUV420P) { yuv_pinned = true; continue; }
             if (sc_step != TTS_RANGE_KEEP) { err = "packed RGB behind a scale that changes the range: pin the scale's output first (format=yuv420p,format=yuvj420p: a range pass of its own)"; return TTS_ERR_UNSUPPORTED; }
             if (g.in_fmt == TTS_FMT_YUV420P && cur_full && end_step != TTS_RANGE_TO_FULL) { err = "packed RGB out of a full-range source: not supported"; return TTS_ERR_UNSUPPORTED; }
@@ -389,9 +407,7 @@ int parse_vf(const char *vf, int iw, int ih, tts_geom &g, std::string &err, int 
                         stage = kAfterScale;
                         converted_by_format = true;
                     }
-                    // yuvj420p = the same planes in full range: the range step of a second, unscaled swscale pass
-                    if (pf == "yuvj420p") g.out_range = TTS_RANGE_TO_FULL;
-                    else if (pf == "yuv420p") g.out_range = TTS_RANGE_KEEP;
+                    // (which range steps the yuv formats stand for: the first pass above has decided, see below)
                 }
                 continue;
             }
@@ -525,9 +541,9 @@ int parse_vf(const char *vf, int iw, int ih, tts_geom &g, std::string &err, int 
     }
     // fed with packed RGB into yuvj420p: a pad behind the converting context sits on a yuvj420p link (a pad on the RGB pixels in
     // front of it keeps its RGB colour)
-    if (g.in_fmt != TTS_FMT_YUV420P && g.out_range == TTS_RANGE_TO_FULL) {
-        if (g.do_pad && g.rgb_stage != TTS_RGB_AT_END) rgb_to_yuv_full((g.fill_rgb >> 16) & 255, (g.fill_rgb >> 8) & 255, g.fill_rgb & 255, g);
-        g.sc_range = TTS_RANGE_TO_FULL; g.out_range = TTS_RANGE_KEEP;     // (the converting context's own step, not a pass at the end)
+    if (g.in_fmt != TTS_FMT_YUV420P) {
+        g.sc_range = sc_step; g.out_range = end_step;                     // (the converting context's own step; a pass at the end)
+        if (g.do_pad && g.rgb_stage != TTS_RGB_AT_END && pad_full) rgb_to_yuv_full((g.fill_rgb >> 16) & 255, (g.fill_rgb >> 8) & 255, g.fill_rgb & 255, g);
     }
     if (g.in_fmt == TTS_FMT_YUV420P) {
         g.out_range = end_step;
