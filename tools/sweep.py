@@ -47,6 +47,9 @@ CASES = {
     "half_rgbin": ("scale=960:540", 1920, 1080, 6220800 + 777600),                       # 2x shrink from RGB: 8 taps across, 16 down the chroma planes
     "web_rgbin": ("scale=720:1280", 1080, 1920, 6220800 + 1382400),                     # the web box from RGB: 1.5x
     "thumb_rgbin": ("scale=320:568:flags=area", 1080, 1920, 6220800 + 272640),          # BASELINE's thumbnails from RGB
+    "thumbref_rgbin": ("scale=320x180:force_original_aspect_ratio=decrease,pad=320x180:-1:-1:color=black,format=yuv420p", 1920, 1080, 6220800 + 86400),   # the reference's thumbnail chain fed with rgb24 frames
+    "thumbref_rgbin_yuvj": ("scale=320x180:force_original_aspect_ratio=decrease,pad=320x180:-1:-1:color=black,format=yuv420p,format=yuvj420p", 1920, 1080, 6220800 + 86400),   # ... + the mjpeg encoder's range pass
+    "portrait_rgbin_yuvj": ("scale=1080:1920:force_original_aspect_ratio=increase,crop=1080:1920,format=yuv420p,format=yuvj420p", 1920, 1080, 608 * 1080 * 3 + 3110400),
     "cvt_yuvj": ("format=yuvj420p", 1920, 1080, 3110400 * 2),                               # range step alone
     "thumbref_yuvj": ("scale=320x180:force_original_aspect_ratio=decrease,pad=320x180:-1:-1:color=black,format=yuv420p,format=yuvj420p", 1920, 1080, 3110400 + 86400),   # the reference's chain + the mjpeg encoder's range pass (fused into the store)
     "thumbref_yuvj_inscale": ("scale=320x180:force_original_aspect_ratio=decrease,pad=320x180:-1:-1:color=black,format=yuvj420p", 1920, 1080, 3110400 + 86400),   # nothing pins yuv420p: the scale's own context converts the range (column walk, RNG)
@@ -67,7 +70,7 @@ CASES = {
 }
 
 
-IN_FMT = {"portrait_rgbin": "rgb24", "stretch_rgbin": "rgb24", "cvt_rgbin": "rgb24", "half_rgbin": "rgb24", "web_rgbin": "rgb24", "thumb_rgbin": "rgb24", "cvt_bgrin": "bgr24"}
+IN_FMT = {"thumbref_rgbin": "rgb24", "thumbref_rgbin_yuvj": "rgb24", "portrait_rgbin_yuvj": "rgb24", "portrait_rgbin": "rgb24", "stretch_rgbin": "rgb24", "cvt_rgbin": "rgb24", "half_rgbin": "rgb24", "web_rgbin": "rgb24", "thumb_rgbin": "rgb24", "cvt_bgrin": "bgr24"}
 
 
 def plan_for(case):
