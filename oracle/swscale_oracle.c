@@ -403,6 +403,8 @@ int tto_run_chain(const tto_chain *c,
             const int ow = (c->out_w + sub) >> sub, oh = (c->out_h + sub) >> sub;
             const int px = c->pad_x >> sub, py = c->pad_y >> sub;
             const int in_w_r = (c->crop_w & ~1) >> sub;
+            /* vf_pad.c config_input(): "Input area not within the padded area" is an error there */
+            if (c->pad_x < 0 || c->pad_y < 0 || c->pad_x + c->crop_w > c->out_w || c->pad_y + c->crop_h > c->out_h) { free(scaled); return -1; }
             for (int y = 0; y < oh; y++) memset(dp[p] + (size_t)y * dst_[p], fill[p], (size_t)ow);
             tto_copy_rect(q, qs, dp[p] + (size_t)py * dst_[p] + px, dst_[p], in_w_r < cw ? in_w_r : cw, ch);
         }

@@ -255,7 +255,7 @@ def test_random_shrinks_packed_rgb_in(tts, oracle, seed):
     for _ in range(6):
         iw = int(rng.choice([4, 4, 2])) * int(rng.integers(8, 360))
         ih = int(rng.integers(12, 420))
-        ow = max(8, int(iw / rng.uniform(1.0, 2.3)))
+        ow = max(8, int(iw / (rng.uniform(1.0, 2.3) if rng.random() < 0.6 else rng.uniform(2.3, 12.5))))   # (beyond 8 taps across: two columns a lane)
         if rng.random() < 0.85:
             ow &= ~1
         oh = max(4, int(ih / rng.uniform(1.0, 6.0)))
@@ -263,6 +263,10 @@ def test_random_shrinks_packed_rgb_in(tts, oracle, seed):
         if rng.random() < 0.3 and ow > 40 and oh > 16:
             cw, chh = 2 * int(rng.integers(8, ow // 2 + 1)), int(rng.integers(8, oh + 1))
             parts.append("crop=%d:%d:%d:%d" % (cw, chh, 2 * int(rng.integers(0, (ow - cw) // 2 + 1)), int(rng.integers(0, oh - chh + 1))))
+        if rng.random() < 0.2:                                 # a pad behind the scale: the border-fill launch in front of the walk
+            cw_, ch_ = (int(parts[-1].split("=")[1].split(":")[0]), int(parts[-1].split("=")[1].split(":")[1])) if len(parts) > 1 else (ow, oh)
+            pw, ph = cw_ + 2 * int(rng.integers(0, 20)), ch_ + 2 * int(rng.integers(0, 12))
+            parts.append("pad=%d:%d:%s:color=%s" % (pw, ph, rng.choice(["-1:-1", "%d:%d" % (int(rng.integers(0, pw - cw_ + 1)), int(rng.integers(0, ph - ch_ + 1)))]), rng.choice(["black", "red", "0x336699"])))
         fmt = str(rng.choice(["rgb24", "rgb24", "bgr24", "rgba", "bgra"]))
         if rng.random() < 0.25:
             parts.append(str(rng.choice(["format=yuvj420p", "format=yuv420p,format=yuvj420p", "format=yuvj420p,format=yuv420p"])))

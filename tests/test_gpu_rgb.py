@@ -823,3 +823,67 @@ def test_packed_rgb_input_range_pass_through_frame_pointers(tts, oracle, monkeyp
             g = dp[i][k].cpu().numpy()
             assert np.array_equal(g[:, : w.shape[1]], w), (i, k)
             assert (g[:, w.shape[1]:] == 16).all(), "the range pass ran over the stride padding"
+
+
+THUMB_R2 = "scale=320x180:force_original_aspect_ratio=decrease,pad=320x180:-1:-1:color=black,format=yuv420p"
+RGBIN_MANY_TAP_CASES = [
+    (THUMB_R2, 1920, 1080, "rgb24", 2),                                    # the reference's thumbnail chain fed with RGB frames: 6x, 25 taps across; the pad is the whole canvas
+    (THUMB_R2, 720, 1280, "rgb24", 3),                                     # a portrait source: 7.1x, the 100-column picture letterboxed at 108
+    (THUMB_R2 + ",format=yuvj420p", 1280, 720, "bgr24", 3),                # 4x + the mjpeg encoder's range pass
+    (THUMB_R2, 3840, 2160, "rgb24", 1),                                    # 4K: 12x, 49 taps across
+    ("scale=640:360", 1920, 1080, "rgb24", 3),                             # 3x: 13 taps
+    ("scale=322:182", 1284, 724, "bgr24", 3),                              # 4x off the grids: an output width of 4 k + 2
+    ("scale=480:270,crop=400:201:40:33", 1920, 1080, "rgb24", 2),          # 4x and a crop at odd rows behind it
+    ("crop=1000:700:100:53,scale=200:140:flags=bilinear,pad=256:144:28:2:color=red", 1284, 800, "rgb24", 3),   # a crop on RGB pixels in front (the row ends on the walk's grid of 4 pixels), bilinear, a pad at its own offset
+    ("scale=160:90:flags=area", 1920, 1080, "rgb24", 2),                   # area at 12x
+]
+
+
+@pytest.mark.parametrize("vf,iw,ih,fmt,n", RGBIN_MANY_TAP_CASES)
+def test_packed_rgb_input_many_tap_shrinks(tts, oracle, vf, iw, ih, fmt, n):
+    """Shrinks of more than 8 taps across from 3-byte RGB: the source-row walk with two luma columns a lane
+    (rgbin_shrink_kernel<16, TPH, KP, 2>), a pad behind the scale as a border fill in front of it."""
+    import torch
+    plan = tts.Plan.from_vf(vf, iw, ih, in_fmt=fmt)
+    name = plan.kernel_name(0)
+    assert name.startswith("rgbin_shrink<") and "16px" in name and ("+pad" in name) == ("pad" in vf), name
+    for pat in ("random", "impulse"):
+        src = repack(rgb_frames(pat, iw, ih, n), iw, ih, fmt)
+        want = oracle.run_chain(plan.geom, src)
+        got = plan.run_batch(torch.from_numpy(src).cuda()).cpu().numpy()
+        bad = np.flatnonzero(got != want)
+        assert bad.size == 0, "%s %s %dx%d %s [%s]: %d bytes differ, first at %d" % (fmt, vf, iw, ih, pat, name, bad.size, bad[0])
+
+
+def test_packed_rgb_input_many_tap_shrink_batches_and_pointers(tts, oracle):
+    """A batch whose waves straddle frames (40 frames of a 7x portrait thumbnail: 50 strips a frame), against the oracle on a
+    few frames and frame against frame on the rest; then the same through per-frame pointers with padded rows."""
+    import torch
+    iw, ih, n = 360, 640, 40
+    plan = tts.Plan.from_vf(THUMB_R2, iw, ih, in_fmt="rgb24")
+    assert plan.kernel_name(0).startswith("rgbin_shrink<") and plan.kernel_name(0).endswith("+pad"), plan.kernel_name(0)
+    src = rgb_frames("random", iw, ih, n)
+    got = plan.run_batch(torch.from_numpy(src).cuda()).cpu().numpy()
+    want = oracle.run_chain(plan.geom, src[:3])
+    assert np.array_equal(got[:3], want)
+    for k in (3, 17, 39):
+        assert np.array_equal(got[k], plan.run_batch(torch.from_numpy(src[k: k + 1]).cuda()).cpu().numpy()[0]), k
+    ow, oh = plan.out_size
+    sp, dp, ss, ds, keep = [], [], [], [], []
+    for i in range(5):
+        t = torch.zeros((ih, iw * 3 + 12), dtype=torch.uint8, device="cuda")
+        t[:, : iw * 3] = torch.from_numpy(src[i].reshape(ih, iw * 3)).cuda()
+        keep.append(t); sp.append([t.data_ptr(), 0, 0]); ss.append([iw * 3 + 12, 0, 0])
+        outs, ostr = [], []
+        for k in range(3):
+            w_, h_ = (ow, oh) if k == 0 else ((ow + 1) // 2, (oh + 1) // 2)
+            o = torch.full((h_, w_ + 16), 9, dtype=torch.uint8, device="cuda")
+            outs.append(o); ostr.append(w_ + 16)
+        dp.append(outs); ds.append(ostr)
+    plan.run_frames(sp, [[t.data_ptr() for t in o] for o in dp], ss, ds)
+    torch.cuda.synchronize()
+    for i in range(5):
+        for k, w in enumerate(synth.split(got[i], ow, oh)):
+            g = dp[i][k].cpu().numpy()
+            assert np.array_equal(g[:, : w.shape[1]], w), (i, k)
+            assert (g[:, w.shape[1]:] == 9).all(), "wrote into the stride padding"

@@ -224,3 +224,16 @@ def test_parse_vf_packed_rgb_source_range_steps(tts):
             assert g[k] == v, (vf, k, g[k], v)
     with pytest.raises(tts.TtsError, match="two range passes"):
         tts.parse_vf("scale=320:180,format=yuv420p,format=yuvj420p,format=yuv420p", 640, 360, in_fmt="rgb24")
+
+
+def test_pad_must_contain_the_picture_after_rounding(tts):
+    """vf_pad rounds its canvas DOWN to the chroma grid and then insists that the input area lies within it: an odd picture
+    height that only fitted the unrounded canvas is an error in ffmpeg, and here (it used to be let through with a row to spare)."""
+    with pytest.raises(tts.TtsError, match="INVALID"):
+        tts.parse_vf("scale=24:43,pad=42:55:0:12:color=black", 242, 137)
+    with pytest.raises(tts.TtsError, match="INVALID"):
+        tts.parse_vf("scale=24:43,pad=42:55:0:12:color=black", 242, 137, in_fmt="bgr24")
+    g = tts.parse_vf("scale=24:43,pad=42:56:0:12:color=black", 242, 137).as_dict()      # fits: all 43 rows are kept
+    assert (g["pad_y"], g["crop_h"], g["out_h"]) == (12, 43, 56)
+    g = tts.parse_vf("scale=101:180,pad=320x180:-1:-1", 1080, 1920).as_dict()            # an odd width that fits: kept in the geometry (its last column goes to the fill)
+    assert (g["pad_x"], g["crop_w"], g["out_w"]) == (108, 101, 320)

@@ -257,9 +257,9 @@ int check_geom(const tts_geom &g)
     if (g.out_w > 16384 || g.out_h > 16384) return TTS_ERR_INVALID_INPUT;     // (a pad canvas: the same limit as every other size here)
     if (g.do_pad) {
         if (!(even(g.pad_x) && even(g.pad_y) && even(g.out_w) && even(g.out_h))) return TTS_ERR_INVALID_INPUT;
-        if (g.pad_x < 0 || g.pad_y < 0 || g.pad_x + g.crop_w > g.out_w + 1 || g.pad_y + g.crop_h > g.out_h + 1 ||
-            g.out_w < g.crop_w || g.out_h < g.crop_h) return TTS_ERR_INVALID_INPUT;
-        if (rgb_pad && (g.pad_x + g.crop_w > g.out_w || g.pad_y + g.crop_h > g.out_h)) return TTS_ERR_INVALID_INPUT;   // (RGB pixels: no chroma grid, no slack)
+        // vf_pad.c config_input(): "Input area ... not within the padded area" once the canvas has been rounded down to the chroma
+        // grid (an odd picture that fits keeps all its rows; its last COLUMN goes to the fill when the right border is drawn)
+        if (g.pad_x < 0 || g.pad_y < 0 || g.pad_x + g.crop_w > g.out_w || g.pad_y + g.crop_h > g.out_h) return TTS_ERR_INVALID_INPUT;
         if ((g.fill_y | g.fill_u | g.fill_v) & ~255) return TTS_ERR_INVALID_INPUT;
     } else if (g.out_w != g.crop_w || g.out_h != g.crop_h) {
         return TTS_ERR_INVALID_INPUT;

@@ -304,10 +304,12 @@ int rgbin_range_pass(const tts_plan *p, uint8_t *dst, int n, const int dstride[2
         r.origin = 0;
         r.addr = addr;
         tts::build_range_lut(g.out_range, ci != 0, r.lut);
+        r.affine = tts::range_affine(g.out_range, ci != 0, r.mul, r.add, r.shift) ? 1 : 0;
+        if (r.stride == r.w && r.h > 1) { r.w *= r.h; r.h = 1; }       // rows back to back: the plane as one row
         const int per = 65535 / r.planes;
         for (int f0 = 0; f0 < n; f0 += per) {
             r.frame0 = f0;
-            dim3 grid((r.w + 255) / 256, (r.h + 3) / 4, std::min(per, n - f0) * r.planes);
+            dim3 grid(r.h == 1 ? (r.w + 16 * kBlock - 1) / (16 * kBlock) : (r.w + 1023) / 1024, (r.h + 3) / 4, std::min(per, n - f0) * r.planes);
             if (const int rc = launch_checked("range_kernel", range_kernel, grid, dim3(kBlock), 0, st, r)) return rc;
         }
     }

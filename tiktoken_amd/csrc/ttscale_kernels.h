@@ -1132,29 +1132,43 @@ __global__ __launch_bounds__(kBlock) void fill_kernel(const FillArgs a)
         if (!(in_rows && i >= a.px && i < a.px + a.pw)) row[i] = f;
 }
 
-// Range step (tts_geom.out_range): every byte of the finished canvas through a 256-entry table,
-// in place.  Thumbnail-sized work; four bytes per lane.
+// Range step (tts_geom.out_range) as a pass of its own over the finished canvas, in place: behind the general kernel and
+// behind the kernels fed with packed RGB (the walks of this file carry the step in their store epilogue instead).  Sixteen
+// bytes a lane through the closed form of filter.cpp range_affine() where the row allows dword access, byte by byte at
+// ragged ends and on rows off the dword grid; the 256-entry table only if the step has no closed form (it always has).
 struct RangeArgs {
     uint8_t *dst;
     int32_t w, h, stride;              // canvas of this plane class
     int32_t planes, plane0;
     int32_t frame0;
     uint32_t origin;                   // bytes from the canvas origin to the picture origin
+    int32_t affine, mul, add, shift;   // affine: (p * mul + add) >> shift, clipped, equals the table
     FrameAddr addr;
     uint8_t lut[256];
 };
 
 __global__ __launch_bounds__(kBlock) void range_kernel(const RangeArgs a)
 {
-    const int x  = (int(blockIdx.x) * 64 + int(threadIdx.x & 63)) * 4;
-    const int y  = int(blockIdx.y) * 4 + int(threadIdx.x >> 6);
+    // (h == 1: a plane whose rows lie back to back, taken as one row by the host -- all four waves of a workgroup side by side)
+    const int x  = a.h == 1 ? (int(blockIdx.x) * kBlock + int(threadIdx.x)) * 16 : (int(blockIdx.x) * 64 + int(threadIdx.x & 63)) * 16;
+    const int y  = a.h == 1 ? 0 : int(blockIdx.y) * 4 + int(threadIdx.x >> 6);
     const int fp = int(blockIdx.z);
     if (x >= a.w || y >= a.h) return;
     const int plane = a.plane0 + fp % a.planes, frame = a.frame0 + fp / a.planes;
     const size_t doff = (a.addr.use_table ? size_t(a.addr.dst_tab[plane][frame])
                                           : size_t(frame) * a.addr.dst_pitch + a.addr.dst_plane[plane]) - a.origin;
     uint8_t *row = a.dst + doff + size_t(y) * size_t(a.stride);
-    for (int i = x; i < min(x + 4, a.w); ++i) row[i] = a.lut[row[i]];
+    if (a.affine && x + 16 <= a.w && (reinterpret_cast<uintptr_t>(row) & 3u) == 0) {
+        u32x4_t v = *reinterpret_cast<const u32x4_t *>(row + x);
+        v.x = range_bytes4(v.x, a.mul, a.add, a.shift); v.y = range_bytes4(v.y, a.mul, a.add, a.shift);
+        v.z = range_bytes4(v.z, a.mul, a.add, a.shift); v.w = range_bytes4(v.w, a.mul, a.add, a.shift);
+        *reinterpret_cast<u32x4_t *>(row + x) = v;
+        return;
+    }
+    for (int i = x; i < min(x + 16, a.w); ++i) {
+        if (a.affine) { const int v = (int(row[i]) * a.mul + a.add) >> a.shift; row[i] = uint8_t(v < 0 ? 0 : v > 255 ? 255 : v); }
+        else row[i] = a.lut[row[i]];
+    }
 }
 
 }  // namespace

@@ -1107,9 +1107,10 @@ int launch_all(const tts_plan *p, const uint8_t *src, uint8_t *dst, int n, const
             r.origin = uint32_t(c.pad_y) * uint32_t(dst_stride[ci]) + uint32_t(c.pad_x);
             r.addr = addr;
             tts::build_range_lut(p->g.out_range, ci != 0, r.lut);
+            r.affine = tts::range_affine(p->g.out_range, ci != 0, r.mul, r.add, r.shift) ? 1 : 0;
             z_launches(r.planes, [&](int f0, int nf) {
                 r.frame0 = f0;
-                dim3 grid((c.canvas_w + 255) / 256, (c.canvas_h + 3) / 4, nf * r.planes);
+                dim3 grid((c.canvas_w + 1023) / 1024, (c.canvas_h + 3) / 4, nf * r.planes);
                 return launch_checked("range_kernel", range_kernel, grid, dim3(kBlock), 0, st, r);
             });
             if (lrc) return lrc;

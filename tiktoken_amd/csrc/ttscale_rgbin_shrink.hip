@@ -1,5 +1,5 @@
-// ttscale_rgbin_shrink.hip -- packed rgb24 in, yuv420p out, the picture SHRUNK (at most 8 taps across: ratios up to
-// about 2x; any ratio down the picture): one walk over the source rows.
+// ttscale_rgbin_shrink.hip -- packed rgb24 in, yuv420p out, the picture SHRUNK (any ratio down the picture; up to 50 taps
+// across: bicubic down to a twelfth, the reference's thumbnail chain on a 4K source): one walk over the source rows.
 //
 // swscale reads chroma at half width here (filter.h rgb_in_half_chroma(): rgb24ToUV_half_c on pixel pairs), at every
 // source row: the chroma planes shrink by the picture's ratio across and by TWICE that down the picture (16 and more
@@ -12,6 +12,9 @@
 // wave-uniform taps from a host table per source row, v_mad_i32_i24 -- and an output row leaves, (sum + 64 << 12) >> 19
 // clipped, when its last source row has gone in; the sums then move up one place.  No ring, so no limit on the number
 // of vertical taps and no unrolling by a ring's depth.  No barrier: a wave's LDS rows are its own.
+// More than 8 taps across (NL = 2): a lane owns 2 luma columns and the U and the V column under them, converts 16 pixels a
+// row, and keeps 3 TPH tap pairs in registers; a pad behind the scale (src/services/video.js:331) is a border-fill launch of
+// its own in front (rgbin_pad_fill_kernel) and an offset on the picture's rows.
 #include "ttscale_rgb.h"
 
 #include <algorithm>
@@ -36,6 +39,7 @@ struct RgbInShrinkArgs {
     int32_t seg_rows, nseg;
     int32_t src_stride, dst_stride[2];
     uint32_t src_origin;
+    uint32_t dst_origin[2];            // the picture's origin inside the canvas (a pad), luma / chroma planes, in bytes
     float cy[4];                       // rgb24ToY_c: coefficients of R, G, B x 2^-9 and (2 bias + 1) / 1024
     float cu[4], cv[4];                // rgb24ToUV_half_c: coefficients x 2^-10 and 2^-11 (see the kernel)
     FrameAddr addr;
@@ -47,14 +51,16 @@ typedef const __attribute__((address_space(4))) int32_t *ctab_t;   // wave-unifo
 // PXL: pixels of the wave's runs a lane converts per row (4 or 8); TPH: tap pairs of a horizontal window (taps <= 6, 8);
 // KP: sums kept per column = the most output rows any source row of this geometry contributes to (6: 16 registers fewer
 // than 8, which is the fourth wave a SIMD)
-template <int PXL, int TPH, int KP>
-__global__ __launch_bounds__(kBlock, KP == 6 ? 4 : 3) void rgbin_shrink_kernel(const uint8_t *__restrict__ src, uint8_t *__restrict__ dst,
+// NL: luma columns a lane owns (4; 2 for the many-tap windows), NL / 2 columns of each chroma plane under them
+template <int PXL, int TPH, int KP, int NL = 4>
+__global__ __launch_bounds__(kBlock, NL == 2 ? 2 : KP == 6 ? 4 : 3) void rgbin_shrink_kernel(const uint8_t *__restrict__ src, uint8_t *__restrict__ dst,
                                                                  const int32_t *__restrict__ tab, const RgbInShrinkArgs a)
 {
-    static_assert((PXL == 4 || PXL == 8) && (TPH == 3 || TPH == 4), "pixels a lane converts; tap pairs a window");
+    static_assert((PXL == 4 || PXL == 8 || PXL == 16) && TPH >= 3 && TPH <= 25 && (NL == 4 || NL == 2), "pixels a lane converts; tap pairs a window; luma columns a lane");
+    constexpr int NC = NL / 2;                                       // chroma columns a lane (of each plane)
     constexpr int NP = PXL / 2, NPC = PXL / 4, NDW = (3 * PXL + 6) / 4;   // pixel pairs = luma dwords; chroma dwords; aligned dwords that hold a lane's 3 PXL bytes at any phase
     constexpr int CBL = 32 * PXL + 8, CBC = 16 * PXL + 8;            // dwords of one copy of a luma / chroma row (+ slack: windows read whole tap pairs; the odd copy starts one dword in)
-    constexpr int ST = 7 + 6 * TPH;                                  // words of a strip's table entry
+    constexpr int ST = NL + NC + (NL + NC) * TPH + 1;                // words of a strip's table entry
     // every row twice: as pairs (s0 s1)(s2 s3).. and, one halfword on, as (s1 s2)(s3 s4)..: a window that starts on an
     // odd sample reads the second copy, so that every tap pair of every window is ONE aligned dword (no v_perm)
     __shared__ uint32_t ldsy[kBlock / 64][2 * CBL];
@@ -90,27 +96,27 @@ __global__ __launch_bounds__(kBlock, KP == 6 ? 4 : 3) void rgbin_shrink_kernel(c
     const uint8_t *sbase4 = sbase - mis;
     const uint32_t off0 = mis + loff + a.src_origin + 3u * uint32_t(conv ? cpx : 0);
     // this lane's windows and taps
-    int li[4], ci[2];                                                // first dword of each window, in the copy its parity picks
-    uint32_t lt[4][TPH], ct[2][TPH];
+    int li[NL], ci[NC];                                              // first dword of each window, in the copy its parity picks
+    uint32_t lt[NL][TPH], ct[NC][TPH];
     {
         const int32_t *T = tab + a.o_strip + size_t(ST) * strip;
 #pragma unroll
-        for (int c = 0; c < 4; ++c) {
+        for (int c = 0; c < NL; ++c) {
             const int h = T[c] + adj;
             li[c] = (h & 1) ? CBL + 1 + (h >> 1) : (h >> 1);
 #pragma unroll
-            for (int k = 0; k < TPH; ++k) lt[c][k] = uint32_t(T[4 + TPH * c + k]);
+            for (int k = 0; k < TPH; ++k) lt[c][k] = uint32_t(T[NL + TPH * c + k]);
         }
 #pragma unroll
-        for (int j = 0; j < 2; ++j) {
-            const int h = T[4 + 4 * TPH + j] + (adj >> 1);
+        for (int j = 0; j < NC; ++j) {
+            const int h = T[NL + NL * TPH + j] + (adj >> 1);
             ci[j] = (h & 1) ? CBC + 1 + (h >> 1) : (h >> 1);
 #pragma unroll
-            for (int k = 0; k < TPH; ++k) ct[j][k] = uint32_t(T[6 + 4 * TPH + TPH * j + k]);
+            for (int k = 0; k < TPH; ++k) ct[j][k] = uint32_t(T[NL + NC + NL * TPH + TPH * j + k]);
         }
         // first output column of the strip: the last strip of a row is slid left, not cut short (the host tabulates it)
         const int col = T[ST - 1];
-        dy += col; du += col >> 1; dv += col >> 1;
+        dy += a.dst_origin[0] + uint32_t(col); du += a.dst_origin[1] + uint32_t(col >> 1); dv += a.dst_origin[1] + uint32_t(col >> 1);
     }
     const int ra = a.h0 + seg * a.seg_rows, rb = min(ra + a.seg_rows, a.h1);
     ctab_t rows = (ctab_t)(tab + a.o_rows);
@@ -118,13 +124,13 @@ __global__ __launch_bounds__(kBlock, KP == 6 ? 4 : 3) void rgbin_shrink_kernel(c
     const f32x2_t yR = a.cy[0], yG = a.cy[1], yB = a.cy[2], y0 = a.cy[3];
     const f32x2_t cR = {a.cu[0], a.cv[0]}, cG = {a.cu[1], a.cv[1]}, cB = {a.cu[2], a.cv[2]}, c0 = {a.cu[3], a.cv[3]};
     constexpr int kBias = 64 << 12;
-    int accl[4][KP], accu[2][KP], accv[2][KP];
+    int accl[NL][KP], accu[NC][KP], accv[NC][KP];
 #pragma unroll
     for (int k = 0; k < KP; ++k) {
 #pragma unroll
-        for (int c = 0; c < 4; ++c) accl[c][k] = kBias;
+        for (int c = 0; c < NL; ++c) accl[c][k] = kBias;
 #pragma unroll
-        for (int j = 0; j < 2; ++j) accu[j][k] = accv[j][k] = kBias;
+        for (int j = 0; j < NC; ++j) accu[j][k] = accv[j][k] = kBias;
     }
     // A lane's 3 PXL bytes of a source row as the aligned dwords that hold them.  Every dword read holds at least one byte
     // of the lane's pixels (the host keeps those inside the frame), so it lies in a mapped page: the last of the NDW is
@@ -218,16 +224,16 @@ __global__ __launch_bounds__(kBlock, KP == 6 ? 4 : 3) void rgbin_shrink_kernel(c
         __builtin_amdgcn_wave_barrier();
         __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
         // ---- hScale16To15_c from the wave's rows
-        int hl[4], hu[2], hv[2];
+        int hl[NL], hu[NC], hv[NC];
 #pragma unroll
-        for (int c = 0; c < 4; ++c) {
+        for (int c = 0; c < NL; ++c) {
             int acc = 0;
 #pragma unroll
             for (int k = 0; k < TPH; ++k) acc = dot2(Y[li[c] + k], lt[c][k], acc);
             hl[c] = min(acc >> 13, 32767);
         }
 #pragma unroll
-        for (int j = 0; j < 2; ++j) {
+        for (int j = 0; j < NC; ++j) {
             int au = 0, av = 0;
 #pragma unroll
             for (int k = 0; k < TPH; ++k) { au = dot2(U[ci[j] + k], ct[j][k], au); av = dot2(V[ci[j] + k], ct[j][k], av); }
@@ -239,45 +245,71 @@ __global__ __launch_bounds__(kBlock, KP == 6 ? 4 : 3) void rgbin_shrink_kernel(c
         for (int k = 0; k < KP; ++k) {
             if (k < 4 || k < npl) {                                  // wave-uniform (the first four always: zero taps where nothing is pending)
 #pragma unroll
-                for (int c = 0; c < 4; ++c) accl[c][k] = __mul24(hl[c], e[4 + k]) + accl[c][k];
+                for (int c = 0; c < NL; ++c) accl[c][k] = __mul24(hl[c], e[4 + k]) + accl[c][k];
             }
             if (k < 4 || k < npc) {
 #pragma unroll
-                for (int j = 0; j < 2; ++j) { accu[j][k] = __mul24(hu[j], e[4 + kPend + k]) + accu[j][k]; accv[j][k] = __mul24(hv[j], e[4 + kPend + k]) + accv[j][k]; }
+                for (int j = 0; j < NC; ++j) { accu[j][k] = __mul24(hu[j], e[4 + kPend + k]) + accu[j][k]; accv[j][k] = __mul24(hv[j], e[4 + kPend + k]) + accv[j][k]; }
             }
         }
         // ---- output rows this source row completes (stored by the segment that owns the row)
         const int ncl = e[2] & 255, ncc = (e[2] >> 8) & 255;
         for (int i = 0; i < ncl; ++i) {                              // wave-uniform
-            const uint32_t o = pack4<19>(accl[0][0], accl[1][0], accl[2][0], accl[3][0]);
+            uint32_t o;
+            if constexpr (NL == 4) o = pack4<19>(accl[0][0], accl[1][0], accl[2][0], accl[3][0]);
+            else o = pack2(accl[0][0], accl[1][0]);
             if (live && r >= ra) {
                 uint8_t *q = dy + size_t(e[0] + i) * a.dst_stride[0];
                 typedef uint32_t u32_b __attribute__((aligned(2)));   // (an output width of 4 k + 2: the slid last strip starts on a halfword)
-                *reinterpret_cast<u32_b *>(q) = o;
+                if constexpr (NL == 4) *reinterpret_cast<u32_b *>(q) = o;
+                else *reinterpret_cast<uint16_t *>(q) = uint16_t(o);
             }
 #pragma unroll
-            for (int c = 0; c < 4; ++c) {
+            for (int c = 0; c < NL; ++c) {
 #pragma unroll
                 for (int k = 0; k < KP - 1; ++k) accl[c][k] = accl[c][k + 1];
                 accl[c][KP - 1] = kBias;
             }
         }
         for (int i = 0; i < ncc; ++i) {
-            const uint32_t ou = pack2(accu[0][0], accu[1][0]), ov = pack2(accv[0][0], accv[1][0]);
+            const uint32_t ou = pack2(accu[0][0], accu[NC - 1][0]), ov = pack2(accv[0][0], accv[NC - 1][0]);
             if (live && r >= ra) {
                 const size_t ro = size_t(e[1] + i) * a.dst_stride[1];
                 typedef uint16_t u16_b __attribute__((aligned(1)));   // (chroma columns: any byte)
-                *reinterpret_cast<u16_b *>(du + ro) = uint16_t(ou);
-                *reinterpret_cast<u16_b *>(dv + ro) = uint16_t(ov);
+                if constexpr (NC == 2) { *reinterpret_cast<u16_b *>(du + ro) = uint16_t(ou); *reinterpret_cast<u16_b *>(dv + ro) = uint16_t(ov); }
+                else { du[ro] = uint8_t(ou); dv[ro] = uint8_t(ov); }
             }
 #pragma unroll
-            for (int j = 0; j < 2; ++j) {
+            for (int j = 0; j < NC; ++j) {
 #pragma unroll
                 for (int k = 0; k < KP - 1; ++k) { accu[j][k] = accu[j][k + 1]; accv[j][k] = accv[j][k + 1]; }
                 accu[j][KP - 1] = accv[j][KP - 1] = kBias;
             }
         }
     }
+}
+
+// The border of a padded canvas (a pad behind the scale), every plane of every frame: four bytes a lane, the picture's
+// rectangle left alone.
+struct RgbInPadFillArgs {
+    uint8_t *dst;
+    int32_t w[2], h[2], stride[2];     // canvas of a luma / chroma plane
+    int32_t px[2], py[2], pw[2], ph[2];   // the picture's rectangle in it
+    int32_t fill[3];
+    int32_t frame0;
+    FrameAddr addr;
+};
+
+__global__ __launch_bounds__(kBlock) void rgbin_pad_fill_kernel(const RgbInPadFillArgs a)
+{
+    const int plane = int(blockIdx.z) % 3, frame = a.frame0 + int(blockIdx.z) / 3, k = plane ? 1 : 0;
+    const int x = (int(blockIdx.x) * 64 + int(threadIdx.x & 63)) * 4, y = int(blockIdx.y) * 4 + int(threadIdx.x >> 6);
+    if (x >= a.w[k] || y >= a.h[k]) return;
+    uint8_t *row = a.dst + (a.addr.use_table ? size_t(a.addr.dst_tab[plane][frame]) : size_t(frame) * a.addr.dst_pitch + a.addr.dst_plane[plane]) + size_t(y) * size_t(a.stride[k]);
+    const bool in_rows = y >= a.py[k] && y < a.py[k] + a.ph[k];
+    const uint8_t f = uint8_t(a.fill[plane]);
+    for (int i = x; i < min(x + 4, a.w[k]); ++i)
+        if (!(in_rows && i >= a.px[k] && i < a.px[k] + a.pw[k])) row[i] = f;
 }
 
 template <class... P, class... A>
@@ -301,7 +333,9 @@ struct RgbInShrinkPlan {
     tts_geom g{};
     int32_t *d_tab = nullptr;
     RgbInShrinkArgs args{};            // table offsets and constants; per-launch fields are filled in by rgbin_shrink_launch
-    int pxl = 8, tph = 4, kp = 8;
+    int pxl = 8, tph = 4, kp = 8, nl = 4;
+    bool pad = false;                  // a pad behind the scale: rgbin_pad_fill_kernel in front, the picture at its offset
+    int vt_max = 0;                    // the taller of the two vertical filters
     int seg_knob = 0;                  // TTS_RGBIN_SEG at plan creation: row segments a launch (0: the launch decides)
     char name[96] = "";
 };
@@ -310,20 +344,26 @@ RgbInShrinkPlan *rgbin_shrink_create(const tts_geom &g, const AxisFilter &lh, co
 {
     auto env = [](const char *k) { const char *v = std::getenv(k); return v ? std::atoi(v) : 0; };
     if (env("TTS_FORCE_GENERIC") || env("TTS_NO_RGBIN_SHRINK")) return nullptr;
-    if (!rgb_in_half_chroma(g.pre_w, g.sc_w) || (g.pre_w & 1) || g.do_pad || g.out_w != g.crop_w || g.out_h != g.crop_h) return nullptr;
-    if ((g.out_w & 1) || g.out_w < 16 || (g.crop_x & 1) || g.pre_h < 8 || ((g.in_w - g.pre_x) & 3)) return nullptr;   // (lanes convert on a grid of 4 pixels that must end with the row)
-    if (lh.size > 8 || ch.size > 8) return nullptr;
+    if (!rgb_in_half_chroma(g.pre_w, g.sc_w) || (g.pre_w & 1)) return nullptr;
+    if (!g.do_pad && (g.out_w != g.crop_w || g.out_h != g.crop_h)) return nullptr;
+    // the picture inside its canvas (vf_pad: an odd picture loses its last column to the fill; offsets are even)
+    const int ow = g.do_pad ? (g.crop_w & ~1) : g.out_w, oh = g.do_pad ? g.crop_h : g.out_h, och = (oh + 1) >> 1;
+    if (g.do_pad && ((g.pad_x | g.pad_y) & 1)) return nullptr;
+    if ((ow & 1) || ow < 16 || (g.crop_x & 1) || g.pre_h < 8 || ((g.in_w - g.pre_x) & 3)) return nullptr;   // (lanes convert on a grid of 4 pixels that must end with the row)
+    if (lh.size > 50 || ch.size > 50) return nullptr;
     if (lh.size == 1 && lv.size == 1 && ch.size == 1) return nullptr;                   // (the conversion alone: rgbin_walk_kernel)
     auto monotone = [](const std::vector<int32_t> &v) { for (size_t i = 1; i < v.size(); ++i) if (v[i] < v[i - 1]) return false; return true; };
     if (!monotone(lh.pos) || !monotone(ch.pos) || !monotone(lv.pos) || !monotone(cv.pos)) return nullptr;
     const int ox = g.crop_x, oy = g.crop_y, oxc = g.crop_x >> 1, oyc = g.crop_y >> 1;
-    const int ow = g.out_w, oh = g.out_h, och = (g.out_h + 1) >> 1;
     if (ox + ow > int(lh.pos.size()) || oxc + ow / 2 > int(ch.pos.size()) || oy + oh > int(lv.pos.size()) || oyc + och > int(cv.pos.size())) return nullptr;
-    const int strips = (ow + 3) / 4, lht = lh.size, cht = ch.size, lvt = lv.size, cvt = cv.size;
-    const int tph = std::max(lht, cht) <= 6 ? 3 : 4, st = 7 + 6 * tph;
+    const int lht = lh.size, cht = ch.size, lvt = lv.size, cvt = cv.size, mt = std::max(lht, cht);
+    // <= 8 taps across: 4 luma columns a lane, windows of 3 or 4 tap pairs; more: 2 columns a lane, 7 .. 25 tap pairs
+    const int nl = mt <= 8 ? 4 : 2, nc = nl / 2;
+    const int tph = mt <= 6 ? 3 : mt <= 8 ? 4 : mt <= 14 ? 7 : mt <= 20 ? 10 : mt <= 26 ? 13 : mt <= 38 ? 19 : 25;
+    const int strips = (ow + nl - 1) / nl, st = nl + nc + (nl + nc) * tph + 1;
     RgbInShrinkPlan *p = new (std::nothrow) RgbInShrinkPlan();
     if (!p) return nullptr;
-    p->g = g; p->tph = tph;
+    p->g = g; p->tph = tph; p->nl = nl; p->pad = g.do_pad != 0;
     RgbInShrinkArgs &a = p->args;
     std::vector<int32_t> t;
     auto pk = [](int a0, int a1) { return int32_t(uint32_t(uint16_t(int16_t(a0))) | uint32_t(uint16_t(int16_t(a1))) << 16); };
@@ -334,22 +374,22 @@ RgbInShrinkPlan *rgbin_shrink_create(const tts_geom &g, const AxisFilter &lh, co
     t.resize(size_t(st) * strips, 0);
     for (int s = 0; s < strips; ++s) {
         int32_t *T = t.data() + size_t(st) * s;
-        const int c0 = std::min(4 * s, ow - 4);                                  // (even: ow is)
+        const int c0 = std::min(nl * s, ow - nl);                                // (even: ow is)
         int lo = INT_MAX, hi = 0;
-        for (int c = 0; c < 4; ++c) {
+        for (int c = 0; c < nl; ++c) {
             const int vx = ox + c0 + c;
-            int tp[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+            int tp[52] = {0};
             for (int k = 0; k < lht; ++k) tp[k] = lh.taps[size_t(vx) * lht + k];
             T[c] = lh.pos[vx];
-            for (int k = 0; k < tph; ++k) T[4 + tph * c + k] = pk(tp[2 * k], tp[2 * k + 1]);
+            for (int k = 0; k < tph; ++k) T[nl + tph * c + k] = pk(tp[2 * k], tp[2 * k + 1]);
             lo = std::min(lo, lh.pos[vx]); hi = std::max(hi, lh.pos[vx] + lht);   // (a window reads whole tap pairs: past its taps, whatever the LDS row holds meets zero taps)
         }
-        for (int j = 0; j < 2; ++j) {
+        for (int j = 0; j < nc; ++j) {
             const int vx = oxc + c0 / 2 + j;
-            int tp[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+            int tp[52] = {0};
             for (int k = 0; k < cht; ++k) tp[k] = ch.taps[size_t(vx) * cht + k];
-            T[4 + 4 * tph + j] = ch.pos[vx];
-            for (int k = 0; k < tph; ++k) T[6 + 4 * tph + tph * j + k] = pk(tp[2 * k], tp[2 * k + 1]);
+            T[nl + nl * tph + j] = ch.pos[vx];
+            for (int k = 0; k < tph; ++k) T[nl + nc + nl * tph + tph * j + k] = pk(tp[2 * k], tp[2 * k + 1]);
             lo = std::min(lo, 2 * ch.pos[vx]); hi = std::max(hi, 2 * (ch.pos[vx] + cht));
         }
         T[st - 1] = c0;
@@ -393,14 +433,15 @@ RgbInShrinkPlan *rgbin_shrink_create(const tts_geom &g, const AxisFilter &lh, co
     };
     int best_pxl = 0, best_spw = 0;
     double best_cost = 1e30;
-    for (int pxl : {4, 8}) {
+    for (int pxl : {4, 8, 16}) {
+        if ((nl == 4) == (pxl == 16)) continue;                                  // (the instantiations on offer: 4 or 8 pixels a lane with 4 columns, 16 with 2)
         int spw = 0;
-        for (int cand = 64; cand >= 16 && !spw; --cand) if (deal(pxl, cand, false)) spw = cand;
+        for (int cand = 64; cand >= (nl == 4 ? 16 : 4) && !spw; --cand) if (deal(pxl, cand, false)) spw = cand;
         if (!spw) continue;
         const double cost = (11.0 * pxl + 50.0 + 24.0 * tph) / spw;              // instructions a source row: conversion + the rest, per strip
         if (cost < best_cost) { best_cost = cost; best_pxl = pxl; best_spw = spw; }
     }
-    if (env("TTS_RGBIN_SHRINK_PXL") == 4 || env("TTS_RGBIN_SHRINK_PXL") == 8) {
+    if (nl == 4 && (env("TTS_RGBIN_SHRINK_PXL") == 4 || env("TTS_RGBIN_SHRINK_PXL") == 8)) {
         best_pxl = env("TTS_RGBIN_SHRINK_PXL"); best_spw = 0;
         for (int cand = 64; cand >= 16 && !best_spw; --cand) if (deal(best_pxl, cand, false)) best_spw = cand;
     }
@@ -451,7 +492,8 @@ RgbInShrinkPlan *rgbin_shrink_create(const tts_geom &g, const AxisFilter &lh, co
     a.cy[3] = float(2 * ((32 << 14) + (1 << 8)) + 1) / 1024.0f;
     a.cu[3] = a.cv[3] = 1.0f / 2048.0f;
     p->seg_knob = env("TTS_RGBIN_SEG");
-    std::snprintf(p->name, sizeof p->name, "rgbin_shrink<%d,%d,%d,%d,%dpx,%d strips a wave,%d sums>", lht, lvt, cht, cvt, best_pxl, best_spw, p->kp);
+    p->vt_max = std::max(lvt, cvt);
+    std::snprintf(p->name, sizeof p->name, "rgbin_shrink<%d,%d,%d,%d,%dpx,%d strips a wave,%d sums>%s", lht, lvt, cht, cvt, best_pxl, best_spw, p->kp, p->pad ? "+pad" : "");
     return p;
 }
 
@@ -473,14 +515,41 @@ int rgbin_shrink_launch(const RgbInShrinkPlan *p, const uint8_t *src, uint8_t *d
     w.src_stride = src_stride; w.dst_stride[0] = dst_stride[0]; w.dst_stride[1] = dst_stride[1];
     w.src_origin = uint32_t(g.pre_y) * uint32_t(src_stride) + uint32_t(g.pre_x) * 3u;
     w.addr = addr;
+    if (p->pad) {
+        // the border first (the picture's rectangle is left alone: the walk below writes all of it), then the picture at its offset
+        RgbInPadFillArgs f{};
+        f.dst = dst; f.addr = addr;
+        const int cw = g.crop_w & ~1;
+        for (int k = 0; k < 2; ++k) {
+            f.w[k] = (g.out_w + k) >> k; f.h[k] = (g.out_h + k) >> k; f.stride[k] = dst_stride[k];
+            f.px[k] = g.pad_x >> k; f.py[k] = g.pad_y >> k; f.pw[k] = (cw + k) >> k; f.ph[k] = (g.crop_h + k) >> k;
+        }
+        f.fill[0] = g.fill_y; f.fill[1] = g.fill_u; f.fill[2] = g.fill_v;
+        for (int f0 = 0; f0 < n; f0 += 21845) {
+            f.frame0 = f0;
+            if (const int rc = launch_shrink("rgbin_pad_fill_kernel", rgbin_pad_fill_kernel, dim3(unsigned((g.out_w + 255) / 256), unsigned((g.out_h + 3) / 4), unsigned(std::min(21845, n - f0) * 3)),
+                                             dim3(kBlock), st, f)) return rc;
+        }
+        w.dst_origin[0] = uint32_t(g.pad_y) * uint32_t(dst_stride[0]) + uint32_t(g.pad_x);
+        w.dst_origin[1] = uint32_t(g.pad_y >> 1) * uint32_t(dst_stride[1]) + uint32_t(g.pad_x >> 1);
+    }
     // row segments: enough waves for about four rounds of the chip's resident waves (3 a SIMD), none shorter than 48 source
     // rows (each starts as many rows early as the chroma filter is tall)
     const int64_t waves = (int64_t(w.total) + w.spw - 1) / w.spw;
     const int rows = w.h1 - w.h0;
-    int nseg = int(std::max<int64_t>(1, std::min<int64_t>((int64_t(4) * 3072 + waves - 1) / waves, std::max(1, rows / 48))));
+    // (... nor than four times the tallest vertical filter: a segment starts that many rows early)
+    const int min_rows = std::max(48, 4 * p->vt_max);
+    int nseg = int(std::max<int64_t>(1, std::min<int64_t>((int64_t(4) * 3072 + waves - 1) / waves, std::max(1, rows / min_rows))));
     if (p->seg_knob > 0) nseg = std::max(1, std::min(p->seg_knob, rows / 8));
     w.seg_rows = (rows + nseg - 1) / nseg;
     w.nseg = (rows + w.seg_rows - 1) / w.seg_rows;
+    if (p->nl == 2) {
+#define TTS_SHRINK2(TPH_) (p->kp == 6 ? rgbin_shrink_kernel<16, TPH_, 6, 2> : rgbin_shrink_kernel<16, TPH_, 8, 2>)
+        auto fn2 = p->tph == 7 ? TTS_SHRINK2(7) : p->tph == 10 ? TTS_SHRINK2(10) : p->tph == 13 ? TTS_SHRINK2(13) : p->tph == 19 ? TTS_SHRINK2(19) : TTS_SHRINK2(25);
+#undef TTS_SHRINK2
+        return launch_shrink("rgbin_shrink_kernel", fn2, dim3(unsigned((waves + kBlock / 64 - 1) / (kBlock / 64)), unsigned(w.nseg), 1), dim3(kBlock), st,
+                             src, dst, static_cast<const int32_t *>(p->d_tab), w);
+    }
     auto fn = p->kp == 6 ? (p->pxl == 4 ? (p->tph == 3 ? rgbin_shrink_kernel<4, 3, 6> : rgbin_shrink_kernel<4, 4, 6>) : (p->tph == 3 ? rgbin_shrink_kernel<8, 3, 6> : rgbin_shrink_kernel<8, 4, 6>))
                          : (p->pxl == 4 ? (p->tph == 3 ? rgbin_shrink_kernel<4, 3, 8> : rgbin_shrink_kernel<4, 4, 8>) : (p->tph == 3 ? rgbin_shrink_kernel<8, 3, 8> : rgbin_shrink_kernel<8, 4, 8>));
     return launch_shrink("rgbin_shrink_kernel", fn, dim3(unsigned((waves + kBlock / 64 - 1) / (kBlock / 64)), unsigned(w.nseg), 1), dim3(kBlock), st,
