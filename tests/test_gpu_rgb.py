@@ -836,6 +836,9 @@ RGBIN_MANY_TAP_CASES = [
     ("scale=480:270,crop=400:201:40:33", 1920, 1080, "rgb24", 2),          # 4x and a crop at odd rows behind it
     ("crop=1000:700:100:53,scale=200:140:flags=bilinear,pad=256:144:28:2:color=red", 1284, 800, "rgb24", 3),   # a crop on RGB pixels in front (the row ends on the walk's grid of 4 pixels), bilinear, a pad at its own offset
     ("scale=160:90:flags=area", 1920, 1080, "rgb24", 2),                   # area at 12x
+    (THUMB_R2, 1920, 1080, "rgba", 2),                                     # four-byte pixels: the same walk, the fourth byte skipped
+    (THUMB_R2, 720, 1280, "bgra", 3),
+    ("scale=640:360", 1920, 1080, "bgra", 2),
 ]
 
 

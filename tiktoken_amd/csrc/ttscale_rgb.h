@@ -74,7 +74,7 @@ int rgbin_launch(const RgbInPlan *p, const uint8_t *src, uint8_t *dst, int n, in
 // ---- packed rgb24 in, shrunk (at most 8 taps across): one walk over the source rows (ttscale_rgbin_shrink.hip) ----
 struct RgbInShrinkPlan;
 // nullptr: the geometry does not fit (an enlargement across, more than 8 taps across, a pad, odd widths, ...)
-RgbInShrinkPlan *rgbin_shrink_create(const tts_geom &g, const AxisFilter &lh, const AxisFilter &lv, const AxisFilter &ch, const AxisFilter &cv, const int coef[9]);
+RgbInShrinkPlan *rgbin_shrink_create(const tts_geom &g, const AxisFilter &lh, const AxisFilter &lv, const AxisFilter &ch, const AxisFilter &cv, const int coef[9], int pb = 3);
 void rgbin_shrink_destroy(RgbInShrinkPlan *p);
 const char *rgbin_shrink_name(const RgbInShrinkPlan *p);
 int rgbin_shrink_launch(const RgbInShrinkPlan *p, const uint8_t *src, uint8_t *dst, int n, int src_stride, const int dst_stride[2],

@@ -2326,10 +2326,10 @@ int rgbin_plan_create(const tts_geom &g, RgbInPlan **out)
             }
         }
     }
-    if (!rc && three && !p->walk && !p->strip) {
+    if (!rc && !p->walk && !p->strip && (three || (p->pb == 4 && !p->yv12 && !canvas && !p->range15))) {   // (rgba / bgra too: the walk skips the fourth byte)
         int coef[9];
         rgbin_coefficients(coef, p->blue_first);
-        p->shrink = rgbin_shrink_create(g, p->lh, p->lv, p->ch, p->cv, coef);
+        p->shrink = rgbin_shrink_create(g, p->lh, p->lv, p->ch, p->cv, coef, p->pb);
     }
     p->yv12_rows = p->yv12 && !g.do_pad && g.crop_x == 0 && g.crop_y == 0 && g.crop_w == g.sc_w && g.crop_h == g.sc_h && g.out_w == g.sc_w && g.out_h == g.sc_h &&
                    g.pre_w >= 8 && !std::getenv("TTS_FORCE_GENERIC");

@@ -52,13 +52,15 @@ typedef const __attribute__((address_space(4))) int32_t *ctab_t;   // wave-unifo
 // KP: sums kept per column = the most output rows any source row of this geometry contributes to (6: 16 registers fewer
 // than 8, which is the fourth wave a SIMD)
 // NL: luma columns a lane owns (4; 2 for the many-tap windows), NL / 2 columns of each chroma plane under them
-template <int PXL, int TPH, int KP, int NL = 4>
+// PB: bytes a source pixel (3; 4 for rgba / bgra: the fourth byte is not read)
+template <int PXL, int TPH, int KP, int NL = 4, int PB = 3>
 __global__ __launch_bounds__(kBlock, NL == 2 ? 2 : KP == 6 ? 4 : 3) void rgbin_shrink_kernel(const uint8_t *__restrict__ src, uint8_t *__restrict__ dst,
                                                                  const int32_t *__restrict__ tab, const RgbInShrinkArgs a)
 {
     static_assert((PXL == 4 || PXL == 8 || PXL == 16) && TPH >= 3 && TPH <= 25 && (NL == 4 || NL == 2), "pixels a lane converts; tap pairs a window; luma columns a lane");
     constexpr int NC = NL / 2;                                       // chroma columns a lane (of each plane)
-    constexpr int NP = PXL / 2, NPC = PXL / 4, NDW = (3 * PXL + 6) / 4;   // pixel pairs = luma dwords; chroma dwords; aligned dwords that hold a lane's 3 PXL bytes at any phase
+    static_assert(PB == 3 || PB == 4, "packed pixels of 3 or 4 bytes");
+    constexpr int NP = PXL / 2, NPC = PXL / 4, NDW = (PB * PXL + 6) / 4;   // pixel pairs = luma dwords; chroma dwords; aligned dwords that hold a lane's PB PXL bytes at any phase
     constexpr int CBL = 32 * PXL + 8, CBC = 16 * PXL + 8;            // dwords of one copy of a luma / chroma row (+ slack: windows read whole tap pairs; the odd copy starts one dword in)
     constexpr int ST = NL + NC + (NL + NC) * TPH + 1;                // words of a strip's table entry
     // every row twice: as pairs (s0 s1)(s2 s3).. and, one halfword on, as (s1 s2)(s3 s4)..: a window that starts on an
@@ -94,7 +96,7 @@ __global__ __launch_bounds__(kBlock, NL == 2 ? 2 : KP == 6 ? 4 : 3) void rgbin_s
     }
     const uint32_t mis = uint32_t(reinterpret_cast<uintptr_t>(sbase) & 3u);
     const uint8_t *sbase4 = sbase - mis;
-    const uint32_t off0 = mis + loff + a.src_origin + 3u * uint32_t(conv ? cpx : 0);
+    const uint32_t off0 = mis + loff + a.src_origin + uint32_t(PB) * uint32_t(conv ? cpx : 0);
     // this lane's windows and taps
     int li[NL], ci[NC];                                              // first dword of each window, in the copy its parity picks
     uint32_t lt[NL][TPH], ct[NC][TPH];
@@ -140,7 +142,7 @@ __global__ __launch_bounds__(kBlock, NL == 2 ? 2 : KP == 6 ? 4 : 3) void rgbin_s
         const uint32_t *q = reinterpret_cast<const uint32_t *>(sbase4 + oa);
 #pragma unroll
         for (int k = 0; k < NDW - 1; ++k) raw[k] = q[k];
-        const bool need_last = (o & 3u) + 3u * PXL > 4u * (NDW - 1);
+        const bool need_last = (o & 3u) + uint32_t(PB) * PXL > 4u * (NDW - 1);
         raw[NDW - 1] = *reinterpret_cast<const uint32_t *>(sbase4 + (oa + (need_last ? 4u * (NDW - 1) : 4u * (NDW - 2))));
     };
     uint32_t nx[NDW];
@@ -173,7 +175,7 @@ __global__ __launch_bounds__(kBlock, NL == 2 ? 2 : KP == 6 ? 4 : 3) void rgbin_s
             float tu[NP], tv[NP];
 #pragma unroll
             for (int i = 0; i < NP; ++i) {
-                const f32x2_t R = {ub(6 * i), ub(6 * i + 3)}, G = {ub(6 * i + 1), ub(6 * i + 4)}, B = {ub(6 * i + 2), ub(6 * i + 5)};
+                const f32x2_t R = {ub(2 * PB * i), ub(2 * PB * i + PB)}, G = {ub(2 * PB * i + 1), ub(2 * PB * i + PB + 1)}, B = {ub(2 * PB * i + 2), ub(2 * PB * i + PB + 2)};
                 // rgb24ToY_c: (ry r + gy g + by b + (32 << 14) + (1 << 8)) >> 9: 8-bit channels times 15-bit coefficients x 2^-9
                 // are exact in fp32; adding 2^23 - 1/2 to (2 sum + 1) / 1024 leaves floor(sum / 512) in the low mantissa bits
                 f32x2_t t = R * yR + (G * yG + (B * yB + y0));
@@ -333,15 +335,16 @@ struct RgbInShrinkPlan {
     tts_geom g{};
     int32_t *d_tab = nullptr;
     RgbInShrinkArgs args{};            // table offsets and constants; per-launch fields are filled in by rgbin_shrink_launch
-    int pxl = 8, tph = 4, kp = 8, nl = 4;
+    int pxl = 8, tph = 4, kp = 8, nl = 4, pb = 3;
     bool pad = false;                  // a pad behind the scale: rgbin_pad_fill_kernel in front, the picture at its offset
     int vt_max = 0;                    // the taller of the two vertical filters
     int seg_knob = 0;                  // TTS_RGBIN_SEG at plan creation: row segments a launch (0: the launch decides)
     char name[96] = "";
 };
 
-RgbInShrinkPlan *rgbin_shrink_create(const tts_geom &g, const AxisFilter &lh, const AxisFilter &lv, const AxisFilter &ch, const AxisFilter &cv, const int coef[9])
+RgbInShrinkPlan *rgbin_shrink_create(const tts_geom &g, const AxisFilter &lh, const AxisFilter &lv, const AxisFilter &ch, const AxisFilter &cv, const int coef[9], int pb)
 {
+    if (pb != 3 && pb != 4) return nullptr;
     auto env = [](const char *k) { const char *v = std::getenv(k); return v ? std::atoi(v) : 0; };
     if (env("TTS_FORCE_GENERIC") || env("TTS_NO_RGBIN_SHRINK")) return nullptr;
     if (!rgb_in_half_chroma(g.pre_w, g.sc_w) || (g.pre_w & 1)) return nullptr;
@@ -363,7 +366,7 @@ RgbInShrinkPlan *rgbin_shrink_create(const tts_geom &g, const AxisFilter &lh, co
     const int strips = (ow + nl - 1) / nl, st = nl + nc + (nl + nc) * tph + 1;
     RgbInShrinkPlan *p = new (std::nothrow) RgbInShrinkPlan();
     if (!p) return nullptr;
-    p->g = g; p->tph = tph; p->nl = nl; p->pad = g.do_pad != 0;
+    p->g = g; p->tph = tph; p->nl = nl; p->pad = g.do_pad != 0; p->pb = pb;
     RgbInShrinkArgs &a = p->args;
     std::vector<int32_t> t;
     auto pk = [](int a0, int a1) { return int32_t(uint32_t(uint16_t(int16_t(a0))) | uint32_t(uint16_t(int16_t(a1))) << 16); };
@@ -434,14 +437,14 @@ RgbInShrinkPlan *rgbin_shrink_create(const tts_geom &g, const AxisFilter &lh, co
     int best_pxl = 0, best_spw = 0;
     double best_cost = 1e30;
     for (int pxl : {4, 8, 16}) {
-        if ((nl == 4) == (pxl == 16)) continue;                                  // (the instantiations on offer: 4 or 8 pixels a lane with 4 columns, 16 with 2)
+        if ((nl == 4) == (pxl == 16) || (pb == 4 && pxl == 4)) continue;         // (the instantiations on offer: 4 or 8 pixels a lane with 4 columns -- 8 of four bytes --, 16 with 2)
         int spw = 0;
         for (int cand = 64; cand >= (nl == 4 ? 16 : 4) && !spw; --cand) if (deal(pxl, cand, false)) spw = cand;
         if (!spw) continue;
         const double cost = (11.0 * pxl + 50.0 + 24.0 * tph) / spw;              // instructions a source row: conversion + the rest, per strip
         if (cost < best_cost) { best_cost = cost; best_pxl = pxl; best_spw = spw; }
     }
-    if (nl == 4 && (env("TTS_RGBIN_SHRINK_PXL") == 4 || env("TTS_RGBIN_SHRINK_PXL") == 8)) {
+    if (nl == 4 && pb == 3 && (env("TTS_RGBIN_SHRINK_PXL") == 4 || env("TTS_RGBIN_SHRINK_PXL") == 8)) {
         best_pxl = env("TTS_RGBIN_SHRINK_PXL"); best_spw = 0;
         for (int cand = 64; cand >= 16 && !best_spw; --cand) if (deal(best_pxl, cand, false)) best_spw = cand;
     }
@@ -493,7 +496,7 @@ RgbInShrinkPlan *rgbin_shrink_create(const tts_geom &g, const AxisFilter &lh, co
     a.cu[3] = a.cv[3] = 1.0f / 2048.0f;
     p->seg_knob = env("TTS_RGBIN_SEG");
     p->vt_max = std::max(lvt, cvt);
-    std::snprintf(p->name, sizeof p->name, "rgbin_shrink<%d,%d,%d,%d,%dpx,%d strips a wave,%d sums>%s", lht, lvt, cht, cvt, best_pxl, best_spw, p->kp, p->pad ? "+pad" : "");
+    std::snprintf(p->name, sizeof p->name, "rgbin_shrink<%d,%d,%d,%d,%dpx%s,%d strips a wave,%d sums>%s", lht, lvt, cht, cvt, best_pxl, pb == 4 ? " of 4 bytes" : "", best_spw, p->kp, p->pad ? "+pad" : "");
     return p;
 }
 
@@ -513,7 +516,7 @@ int rgbin_shrink_launch(const RgbInShrinkPlan *p, const uint8_t *src, uint8_t *d
     RgbInShrinkArgs w = p->args;
     w.total = n * w.strips; w.nframes = n;
     w.src_stride = src_stride; w.dst_stride[0] = dst_stride[0]; w.dst_stride[1] = dst_stride[1];
-    w.src_origin = uint32_t(g.pre_y) * uint32_t(src_stride) + uint32_t(g.pre_x) * 3u;
+    w.src_origin = uint32_t(g.pre_y) * uint32_t(src_stride) + uint32_t(g.pre_x) * uint32_t(p->pb);
     w.addr = addr;
     if (p->pad) {
         // the border first (the picture's rectangle is left alone: the walk below writes all of it), then the picture at its offset
@@ -544,10 +547,16 @@ int rgbin_shrink_launch(const RgbInShrinkPlan *p, const uint8_t *src, uint8_t *d
     w.seg_rows = (rows + nseg - 1) / nseg;
     w.nseg = (rows + w.seg_rows - 1) / w.seg_rows;
     if (p->nl == 2) {
-#define TTS_SHRINK2(TPH_) (p->kp == 6 ? rgbin_shrink_kernel<16, TPH_, 6, 2> : rgbin_shrink_kernel<16, TPH_, 8, 2>)
+#define TTS_SHRINK2(TPH_) (p->pb == 4 ? (p->kp == 6 ? rgbin_shrink_kernel<16, TPH_, 6, 2, 4> : rgbin_shrink_kernel<16, TPH_, 8, 2, 4>) \
+                                      : (p->kp == 6 ? rgbin_shrink_kernel<16, TPH_, 6, 2> : rgbin_shrink_kernel<16, TPH_, 8, 2>))
         auto fn2 = p->tph == 7 ? TTS_SHRINK2(7) : p->tph == 10 ? TTS_SHRINK2(10) : p->tph == 13 ? TTS_SHRINK2(13) : p->tph == 19 ? TTS_SHRINK2(19) : TTS_SHRINK2(25);
 #undef TTS_SHRINK2
         return launch_shrink("rgbin_shrink_kernel", fn2, dim3(unsigned((waves + kBlock / 64 - 1) / (kBlock / 64)), unsigned(w.nseg), 1), dim3(kBlock), st,
+                             src, dst, static_cast<const int32_t *>(p->d_tab), w);
+    }
+    if (p->pb == 4) {
+        auto fn4 = p->kp == 6 ? (p->tph == 3 ? rgbin_shrink_kernel<8, 3, 6, 4, 4> : rgbin_shrink_kernel<8, 4, 6, 4, 4>) : (p->tph == 3 ? rgbin_shrink_kernel<8, 3, 8, 4, 4> : rgbin_shrink_kernel<8, 4, 8, 4, 4>);
+        return launch_shrink("rgbin_shrink_kernel", fn4, dim3(unsigned((waves + kBlock / 64 - 1) / (kBlock / 64)), unsigned(w.nseg), 1), dim3(kBlock), st,
                              src, dst, static_cast<const int32_t *>(p->d_tab), w);
     }
     auto fn = p->kp == 6 ? (p->pxl == 4 ? (p->tph == 3 ? rgbin_shrink_kernel<4, 3, 6> : rgbin_shrink_kernel<4, 4, 6>) : (p->tph == 3 ? rgbin_shrink_kernel<8, 3, 6> : rgbin_shrink_kernel<8, 4, 6>))
