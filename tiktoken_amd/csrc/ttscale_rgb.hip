@@ -31,6 +31,7 @@
 #include <cstring>
 #include <new>
 #include <tuple>
+#include <type_traits>
 #include <vector>
 
 #include "filter.h"
@@ -1444,6 +1445,7 @@ struct RgbInStripArgs {
     int32_t src_stride, dst_stride[2];
     uint32_t src_origin;
     float cf[3][4];                                                    // per plane: coefficients of R, G, B (x 2^-9) and (2 bias + 1) / 1024
+    int32_t range15;                                                   // the context writes yuvj420p (tts_geom.sc_range): the range step on its 15-bit rows
     FrameAddr addr;
 };
 
@@ -1621,23 +1623,30 @@ __global__ __launch_bounds__(kBlock, 3) void rgbin_strip_kernel(const uint8_t *_
             __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
             __builtin_amdgcn_wave_barrier();
             __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-            // ---- hScale16To15_c from the wave's rows into the rings
+            // ---- hScale16To15_c from the wave's rows into the rings (RNG: the context writes yuvj420p -- swscale.c lumRangeToJpeg_c /
+            // chrRangeToJpeg_c on the 15-bit samples; the loops are spelt twice so that the usual path pays nothing for it)
             const uint32_t *Y = lds[wave][0], *U = lds[wave][1], *V = lds[wave][2];
+            auto hpass = [&](auto RNG) {
 #pragma unroll
-            for (int c = 0; c < 8; ++c) {
-                const int acc = dot2(Y[li[c]], lt[c][0], dot2(Y[li[c] + 1], lt[c][1], 0)) >> 13;
-                const uint32_t t = uint32_t(min(acc, 32767));
-                ringl[c][(s & 3) / 2] = (s & 1) ? __builtin_amdgcn_perm(t, ringl[c][(s & 3) / 2], 0x05040100) : __builtin_amdgcn_perm(ringl[c][(s & 3) / 2], t, 0x07060100);
-            }
+                for (int c = 0; c < 8; ++c) {
+                    int acc = min(dot2(Y[li[c]], lt[c][0], dot2(Y[li[c] + 1], lt[c][1], 0)) >> 13, 32767);
+                    if constexpr (decltype(RNG)::value) acc = (__mul24(min(acc, 30189), 19077) - 39057361) >> 14;
+                    const uint32_t t = uint32_t(acc);
+                    ringl[c][(s & 3) / 2] = (s & 1) ? __builtin_amdgcn_perm(t, ringl[c][(s & 3) / 2], 0x05040100) : __builtin_amdgcn_perm(ringl[c][(s & 3) / 2], t, 0x07060100);
+                }
 #pragma unroll
-            for (int j = 0; j < 4; ++j) {
-                int au = 0, av = 0;
+                for (int j = 0; j < 4; ++j) {
+                    int au = 0, av = 0;
 #pragma unroll
-                for (int k = 0; k < CHD; ++k) { au = dot2(U[ci[j] + k], ct[j][k], au); av = dot2(V[ci[j] + k], ct[j][k], av); }
-                const uint32_t tu = uint32_t(min(au >> 13, 32767)), tv = uint32_t(min(av >> 13, 32767));
-                ringu[j][s / 2] = (s & 1) ? __builtin_amdgcn_perm(tu, ringu[j][s / 2], 0x05040100) : __builtin_amdgcn_perm(ringu[j][s / 2], tu, 0x07060100);
-                ringv[j][s / 2] = (s & 1) ? __builtin_amdgcn_perm(tv, ringv[j][s / 2], 0x05040100) : __builtin_amdgcn_perm(ringv[j][s / 2], tv, 0x07060100);
-            }
+                    for (int k = 0; k < CHD; ++k) { au = dot2(U[ci[j] + k], ct[j][k], au); av = dot2(V[ci[j] + k], ct[j][k], av); }
+                    au = min(au >> 13, 32767); av = min(av >> 13, 32767);
+                    if constexpr (decltype(RNG)::value) { au = (__mul24(min(au, 30775), 4663) - 9289992) >> 12; av = (__mul24(min(av, 30775), 4663) - 9289992) >> 12; }
+                    const uint32_t tu = uint32_t(au), tv = uint32_t(av);
+                    ringu[j][s / 2] = (s & 1) ? __builtin_amdgcn_perm(tu, ringu[j][s / 2], 0x05040100) : __builtin_amdgcn_perm(ringu[j][s / 2], tu, 0x07060100);
+                    ringv[j][s / 2] = (s & 1) ? __builtin_amdgcn_perm(tv, ringv[j][s / 2], 0x05040100) : __builtin_amdgcn_perm(ringv[j][s / 2], tv, 0x07060100);
+                }
+            };
+            if (a.range15) hpass(std::true_type{}); else hpass(std::false_type{});   // wave-uniform
             __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");     // (the next row's conversion overwrites the wave's LDS rows)
             __builtin_amdgcn_wave_barrier();
             // ---- output rows this source row completes
@@ -2173,14 +2182,14 @@ int rgbin_plan_create(const tts_geom &g, RgbInPlan **out)
     p->pb = packed_pixel_bytes(g.in_fmt);
     p->blue_first = packed_blue_first(g.in_fmt);
     p->canvas = canvas;
-    p->range15 = g.sc_range == TTS_RANGE_TO_FULL;            // the converting context writes yuvj420p: the general kernel alone carries its range step
+    p->range15 = g.sc_range == TTS_RANGE_TO_FULL;            // the converting context writes yuvj420p: the source-row walk and the general kernel carry its range step
     p->yv12 = bgr24_special_converter(g);
     if (p->yv12 && (src_w & 1)) {
         set_last_error("swscale's bgr24 -> yuv420p converter for pictures of the same size never writes the last column of an odd width: not supported");
         delete p;
         return TTS_ERR_UNSUPPORTED;
     }
-    const bool three = p->pb == 3 && !p->yv12 && !canvas && !p->range15;   // the walks read 3-byte pixels; 4-byte sources run the tiled / general kernels
+    const bool three = p->pb == 3 && !p->yv12 && !canvas;    // the conversion walk and the strip walk read 3-byte pixels
     int rc = TTS_OK;
     if (!build_axis_filter(src_w, dst_w, 1 << 14, g.alg, p->lh) || !build_axis_filter(src_h, dst_h, 1 << 12, g.alg, p->lv) ||
         !build_axis_filter(half ? src_w / 2 : src_w, (dst_w + 1) >> 1, 1 << 14, g.alg, p->ch) || !build_axis_filter(src_h, (dst_h + 1) >> 1, 1 << 12, g.alg, p->cv)) {
@@ -2204,7 +2213,7 @@ int rgbin_plan_create(const tts_geom &g, RgbInPlan **out)
     }
     // The conversion alone (nothing in the chain resizes, crops or pads): the streaming walk.  Its arithmetic has the
     // one-tap filters folded in, so they are checked to be exactly that: position i, the full weight.
-    if (!rc && three && !std::getenv("TTS_FORCE_GENERIC") && !(std::getenv("TTS_NO_RGBIN_WALK") && std::atoi(std::getenv("TTS_NO_RGBIN_WALK")))) {
+    if (!rc && three && !p->range15 && !std::getenv("TTS_FORCE_GENERIC") && !(std::getenv("TTS_NO_RGBIN_WALK") && std::atoi(std::getenv("TTS_NO_RGBIN_WALK")))) {   // (no range step in its folded arithmetic)
         auto identity = [](const AxisFilter &f, int one) {
             if (f.size != 1) return false;
             for (size_t i = 0; i < f.pos.size(); ++i) if (f.pos[i] != int(i) || f.taps[i] != one) return false;
@@ -2326,7 +2335,7 @@ int rgbin_plan_create(const tts_geom &g, RgbInPlan **out)
             }
         }
     }
-    if (!rc && !p->walk && !p->strip && (three || (p->pb == 4 && !p->yv12 && !canvas && !p->range15))) {   // (rgba / bgra too: the walk skips the fourth byte)
+    if (!rc && !p->walk && !p->strip && !p->yv12 && !canvas) {   // (rgba / bgra too: the walk skips the fourth byte; and it carries the range step of a context that writes yuvj420p)
         int coef[9];
         rgbin_coefficients(coef, p->blue_first);
         p->shrink = rgbin_shrink_create(g, p->lh, p->lv, p->ch, p->cv, coef, p->pb);
@@ -2336,7 +2345,7 @@ int rgbin_plan_create(const tts_geom &g, RgbInPlan **out)
     if (p->yv12) std::snprintf(p->name, sizeof p->name, p->yv12_rows ? "bgr24_yv12_rows" : "bgr24_yv12");
     else if (p->shrink) std::snprintf(p->name, sizeof p->name, "%s", rgbin_shrink_name(p->shrink));
     else if (p->walk) std::snprintf(p->name, sizeof p->name, "rgbin_walk<%d>", p->cv.size);
-    else if (p->strip) std::snprintf(p->name, sizeof p->name, "rgbin_strip<%d,%d,%d,%d,%dpx>", p->lh.size, p->lv.size, p->ch.size, p->cv.size, p->pxl);   // luma taps across / down, chroma taps across / down
+    else if (p->strip) std::snprintf(p->name, sizeof p->name, "rgbin_strip<%d,%d,%d,%d,%dpx>%s", p->lh.size, p->lv.size, p->ch.size, p->cv.size, p->pxl, p->range15 ? "+range15" : "");   // luma taps across / down, chroma taps across / down
     else if (p->tiled) std::snprintf(p->name, sizeof p->name, "rgbin_tile<%d,%d>", p->th[0], p->th[1]);
     else std::snprintf(p->name, sizeof p->name, "rgbin_generic<%d,%d,%d,%d>%s%s", p->lh.size, p->lv.size, p->ch.size, p->cv.size, p->range15 ? "+range15" : "", canvas ? "+rgb_pad" : "");
     if (p->yv12 && canvas) std::snprintf(p->name, sizeof p->name, "bgr24_yv12+rgb_pad");
@@ -2448,6 +2457,7 @@ int rgbin_launch(const RgbInPlan *p, const uint8_t *src, uint8_t *dst, int n, in
         w.oh = g.out_h; w.och = (g.out_h + 1) >> 1; w.lvt = p->lv.size; w.cvt = p->cv.size; w.h = g.pre_h;
         w.src_stride = src_stride; w.dst_stride[0] = dst_stride[0]; w.dst_stride[1] = dst_stride[1];
         w.src_origin = a.src_origin;
+        w.range15 = p->range15 ? 1 : 0;
         // rgb24ToY_c: (ry r + gy g + by b + (32 << 14) + (1 << 8)) >> 9, rgb24ToUV_c: (... + (256 << 14) + (1 << 8)) >> 9, in the
         // kernel's exact float form: coefficients x 2^-9, constant (2 bias + 1) / 1024
         for (int pl = 0; pl < 3; ++pl) {

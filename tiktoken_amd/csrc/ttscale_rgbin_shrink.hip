@@ -40,6 +40,7 @@ struct RgbInShrinkArgs {
     int32_t src_stride, dst_stride[2];
     uint32_t src_origin;
     uint32_t dst_origin[2];            // the picture's origin inside the canvas (a pad), luma / chroma planes, in bytes
+    int32_t range15;                   // the converting context writes yuvj420p (tts_geom.sc_range): lum / chrRangeToJpeg_c on the 15-bit rows
     float cy[4];                       // rgb24ToY_c: coefficients of R, G, B x 2^-9 and (2 bias + 1) / 1024
     float cu[4], cv[4];                // rgb24ToUV_half_c: coefficients x 2^-10 and 2^-11 (see the kernel)
     FrameAddr addr;
@@ -234,12 +235,20 @@ __global__ __launch_bounds__(kBlock, NL == 2 ? 2 : KP == 6 ? 4 : 3) void rgbin_s
             for (int k = 0; k < TPH; ++k) acc = dot2(Y[li[c] + k], lt[c][k], acc);
             hl[c] = min(acc >> 13, 32767);
         }
+        if (a.range15) {                                             // wave-uniform; swscale.c lumRangeToJpeg_c
+#pragma unroll
+            for (int c = 0; c < NL; ++c) hl[c] = (__mul24(min(hl[c], 30189), 19077) - 39057361) >> 14;
+        }
 #pragma unroll
         for (int j = 0; j < NC; ++j) {
             int au = 0, av = 0;
 #pragma unroll
             for (int k = 0; k < TPH; ++k) { au = dot2(U[ci[j] + k], ct[j][k], au); av = dot2(V[ci[j] + k], ct[j][k], av); }
             hu[j] = min(au >> 13, 32767); hv[j] = min(av >> 13, 32767);
+        }
+        if (a.range15) {                                             // chrRangeToJpeg_c
+#pragma unroll
+            for (int j = 0; j < NC; ++j) { hu[j] = (__mul24(min(hu[j], 30775), 4663) - 9289992) >> 12; hv[j] = (__mul24(min(hv[j], 30775), 4663) - 9289992) >> 12; }
         }
         // ---- vertical pass, output-stationary: this row into the sums of the output rows that hold it
         const int npl = (e[2] >> 16) & 255, npc = (e[2] >> 24) & 255;
@@ -494,9 +503,10 @@ RgbInShrinkPlan *rgbin_shrink_create(const tts_geom &g, const AxisFilter &lh, co
     for (int k = 0; k < 3; ++k) { a.cy[k] = float(coef[k]) / 512.0f; a.cu[k] = float(coef[3 + k]) / 1024.0f; a.cv[k] = float(coef[6 + k]) / 1024.0f; }
     a.cy[3] = float(2 * ((32 << 14) + (1 << 8)) + 1) / 1024.0f;
     a.cu[3] = a.cv[3] = 1.0f / 2048.0f;
+    a.range15 = g.sc_range == TTS_RANGE_TO_FULL ? 1 : 0;
     p->seg_knob = env("TTS_RGBIN_SEG");
     p->vt_max = std::max(lvt, cvt);
-    std::snprintf(p->name, sizeof p->name, "rgbin_shrink<%d,%d,%d,%d,%dpx%s,%d strips a wave,%d sums>%s", lht, lvt, cht, cvt, best_pxl, pb == 4 ? " of 4 bytes" : "", best_spw, p->kp, p->pad ? "+pad" : "");
+    std::snprintf(p->name, sizeof p->name, "rgbin_shrink<%d,%d,%d,%d,%dpx%s,%d strips a wave,%d sums>%s%s", lht, lvt, cht, cvt, best_pxl, pb == 4 ? " of 4 bytes" : "", best_spw, p->kp, a.range15 ? "+range15" : "", p->pad ? "+pad" : "");
     return p;
 }
 
