@@ -553,6 +553,18 @@ int rgbin_shrink_launch(const RgbInShrinkPlan *p, const uint8_t *src, uint8_t *d
     // (... nor than four times the tallest vertical filter: a segment starts that many rows early)
     const int min_rows = std::max(48, 4 * p->vt_max);
     int nseg = int(std::max<int64_t>(1, std::min<int64_t>((int64_t(4) * 3072 + waves - 1) / waves, std::max(1, rows / min_rows))));
+    if (p->nl == 2) {
+        // Many taps: a segment starts a whole vertical filter early (49 rows for the reference's thumbnails), so short segments
+        // cost real work, and the launch is a round or two of the chip's resident waves (3 a SIMD; 2 at 25 tap pairs), so a
+        // last round that is mostly empty costs as much as a full one.  Take the count with the least rounds x rows a wave.
+        const int64_t slots = int64_t(p->tph > 19 ? 2 : 3) * 4 * 256;
+        double best = 1e30;
+        for (int cand = 1; cand <= std::max(1, rows / std::max(16, p->vt_max)); ++cand) {
+            const int sr = (rows + cand - 1) / cand;
+            const double cost = double((waves * cand + slots - 1) / slots) * double(sr + p->vt_max);
+            if (cost < best) { best = cost; nseg = cand; }
+        }
+    }
     if (p->seg_knob > 0) nseg = std::max(1, std::min(p->seg_knob, rows / 8));
     w.seg_rows = (rows + nseg - 1) / nseg;
     w.nseg = (rows + w.seg_rows - 1) / w.seg_rows;
