@@ -363,7 +363,7 @@ RgbInShrinkPlan *rgbin_shrink_create(const tts_geom &g, const AxisFilter &lh, co
     if (g.do_pad && ((g.pad_x | g.pad_y) & 1)) return nullptr;
     if ((ow & 1) || ow < 16 || (g.crop_x & 1) || g.pre_h < 8 || ((g.in_w - g.pre_x) & 3)) return nullptr;   // (lanes convert on a grid of 4 pixels that must end with the row)
     if (lh.size > 50 || ch.size > 50) return nullptr;
-    if (lh.size == 1 && lv.size == 1 && ch.size == 1) return nullptr;                   // (the conversion alone: rgbin_walk_kernel)
+    if (lh.size == 1 && lv.size == 1 && ch.size == 1 && pb == 3 && g.sc_range == TTS_RANGE_KEEP) return nullptr;   // (the conversion alone: rgbin_walk_kernel -- which reads 3-byte pixels and has no range step)
     auto monotone = [](const std::vector<int32_t> &v) { for (size_t i = 1; i < v.size(); ++i) if (v[i] < v[i - 1]) return false; return true; };
     if (!monotone(lh.pos) || !monotone(ch.pos) || !monotone(lv.pos) || !monotone(cv.pos)) return nullptr;
     const int ox = g.crop_x, oy = g.crop_y, oxc = g.crop_x >> 1, oyc = g.crop_y >> 1;

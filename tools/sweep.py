@@ -65,6 +65,8 @@ CASES = {
     "cvt_rgb24_portrait": ("format=rgb24", 1080, 1920, 3110400 + 6220800),
     "cvt_rgba": ("format=rgba", 1920, 1080, 3110400 + 8294400),
     "cvt_rgbin": ("format=yuv420p", 1920, 1080, 6220800 + 3110400),                                  # rgb24 -> yuv420p, no scale
+    "cvt_rgbin_yuvj": ("format=yuvj420p", 1920, 1080, 6220800 + 3110400),                             # rgb24 -> yuvj420p, no scale: the converting context writes full range
+    "cvt_rgbain": ("format=yuv420p", 1920, 1080, 8294400 + 3110400),                                 # rgba -> yuv420p, no scale
     "cvt_bgrin": ("format=yuv420p", 1920, 1080, 6220800 + 3110400),                                  # bgr24 -> yuv420p, no scale: swscale's special converter
     "web_rgb24": ("scale=720:1280,format=rgb24", 1080, 1920, 3110400 + 2764800),      # 1.5x shrink written as RGB
     "web_rgba": ("scale=720:1280,format=rgba", 1080, 1920, 3110400 + 3686400),
@@ -74,7 +76,7 @@ CASES = {
 }
 
 
-IN_FMT = {"thumbref_rgbin_inctx": "rgb24", "thumbref_rgbain": "rgba", "thumbref_portrait_rgbin": "rgb24", "portrait_rgbin_inctx": "rgb24", "thumbref_rgbin": "rgb24", "thumbref_rgbin_yuvj": "rgb24", "portrait_rgbin_yuvj": "rgb24", "portrait_rgbin": "rgb24", "stretch_rgbin": "rgb24", "cvt_rgbin": "rgb24", "half_rgbin": "rgb24", "web_rgbin": "rgb24", "thumb_rgbin": "rgb24", "cvt_bgrin": "bgr24"}
+IN_FMT = {"cvt_rgbin_yuvj": "rgb24", "cvt_rgbain": "rgba", "thumbref_rgbin_inctx": "rgb24", "thumbref_rgbain": "rgba", "thumbref_portrait_rgbin": "rgb24", "portrait_rgbin_inctx": "rgb24", "thumbref_rgbin": "rgb24", "thumbref_rgbin_yuvj": "rgb24", "portrait_rgbin_yuvj": "rgb24", "portrait_rgbin": "rgb24", "stretch_rgbin": "rgb24", "cvt_rgbin": "rgb24", "half_rgbin": "rgb24", "web_rgbin": "rgb24", "thumb_rgbin": "rgb24", "cvt_bgrin": "bgr24"}
 
 
 def plan_for(case):
