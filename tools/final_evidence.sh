@@ -17,7 +17,7 @@ timeout -k 10 300 python bench.py --frames 300 > $O/${P}_bench300.json 2> $O/${P
 (cd /tmp && TMPDIR=/tmp timeout -k 10 400 rocprofv3 --kernel-trace --stats --output-format csv -d $O/${P}_benchprof -- python3 $R/bench.py --no-cpu-baseline > $O/${P}_bench_under_rocprof.json 2> $O/${P}_benchprof.err) || { echo "rocprofv3 bench failed"; exit 1; }
 timeout -k 10 200 python -c "import __graft_entry__ as g; g.smoke(); print('smoke ok')" 2>&1 | tail -n 2
 : > $O/${P}_sweep.txt
-for c in portrait 4k 720p web stretch thumb thumbref thumbref_portrait thumbref_4k half third portrait_rgb24 portrait_rgba thumbref_rgb24 web_rgb24 cvt_rgb24 cvt_rgba cvt_rgbin portrait_rgbin stretch_rgbin web_rgba 4k_rgb24 half_rgb24 half_rgbin web_rgbin thumb_rgbin cvt_bgrin thumbref_yuvj thumbref_yuvj_inscale half_yuvj_inscale portrait_yuvj_inscale; do
+for c in portrait 4k 720p web stretch thumb thumbref thumbref_portrait thumbref_4k half third portrait_rgb24 portrait_rgba thumbref_rgb24 web_rgb24 cvt_rgb24 cvt_rgba cvt_rgbin portrait_rgbin stretch_rgbin web_rgba 4k_rgb24 half_rgb24 half_rgbin web_rgbin thumb_rgbin cvt_bgrin thumbref_yuvj thumbref_yuvj_inscale half_yuvj_inscale portrait_yuvj_inscale thumbref_rgbin thumbref_rgbin_yuvj thumbref_rgbin_inctx thumbref_rgbain thumbref_portrait_rgbin portrait_rgbin_inctx portrait_rgbin_yuvj cvt_rgbin_yuvj cvt_rgbain; do
   for fr in 300 1200; do
     timeout -k 10 100 python tools/sweep.py --case $c --frames $fr --segs 0 --ns 8 2>&1 | grep SEG_ROWS | sed "s/^/$c $fr /" >> $O/${P}_sweep.txt || exit 1
   done
