@@ -890,3 +890,13 @@ def test_packed_rgb_input_many_tap_shrink_batches_and_pointers(tts, oracle):
             g = dp[i][k].cpu().numpy()
             assert np.array_equal(g[:, : w.shape[1]], w), (i, k)
             assert (g[:, w.shape[1]:] == 9).all(), "wrote into the stride padding"
+
+
+def test_packed_rgb_input_thumbnail_chain_host_path(tts, oracle):
+    """tts_run_host (pinned staging, chunks): the reference's thumbnail chain + its encoder's range pass fed with host RGB frames --
+    border fill, many-tap walk and range pass, chunk after chunk."""
+    iw, ih, n = 720, 1280, 7
+    plan = tts.Plan.from_vf(THUMB_PINNED_RGBIN, iw, ih, in_fmt="rgb24")
+    assert plan.kernel_name(0).startswith("rgbin_shrink<") and plan.kernel_name(0).endswith("+pad+range_pass"), plan.kernel_name(0)
+    src = rgb_frames("zone", iw, ih, n)
+    assert np.array_equal(plan.run_host(src), oracle.run_chain(plan.geom, src))
