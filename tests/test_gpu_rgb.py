@@ -842,14 +842,18 @@ RGBIN_MANY_TAP_CASES = [
 ]
 
 
+@pytest.mark.parametrize("pxl", [0, 8, 16])
 @pytest.mark.parametrize("vf,iw,ih,fmt,n", RGBIN_MANY_TAP_CASES)
-def test_packed_rgb_input_many_tap_shrinks(tts, oracle, vf, iw, ih, fmt, n):
-    """Shrinks of more than 8 taps across from 3-byte RGB: the source-row walk with two luma columns a lane
-    (rgbin_shrink_kernel<16, TPH, KP, 2>), a pad behind the scale as a border fill in front of it."""
+def test_packed_rgb_input_many_tap_shrinks(tts, oracle, monkeypatch, vf, iw, ih, fmt, n, pxl):
+    """Shrinks of more than 8 taps across from packed RGB: the source-row walk with two luma columns a lane
+    (rgbin_shrink_kernel<PXL, TPH, KP, 2, PB>: 8 or 16 pixels converted a lane, the planner's pick and each one forced), a pad
+    behind the scale as a border fill in front of it."""
     import torch
+    if pxl:
+        monkeypatch.setenv("TTS_RGBIN_SHRINK_PXL", str(pxl))
     plan = tts.Plan.from_vf(vf, iw, ih, in_fmt=fmt)
     name = plan.kernel_name(0)
-    assert name.startswith("rgbin_shrink<") and "16px" in name and ("+pad" in name) == ("pad" in vf), name
+    assert name.startswith("rgbin_shrink<") and ("%dpx" % pxl in name if pxl else "8px" in name or "16px" in name) and ("+pad" in name) == ("pad" in vf), name
     for pat in ("random", "impulse"):
         src = repack(rgb_frames(pat, iw, ih, n), iw, ih, fmt)
         want = oracle.run_chain(plan.geom, src)

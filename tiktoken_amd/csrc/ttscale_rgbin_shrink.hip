@@ -446,16 +446,20 @@ RgbInShrinkPlan *rgbin_shrink_create(const tts_geom &g, const AxisFilter &lh, co
     int best_pxl = 0, best_spw = 0;
     double best_cost = 1e30;
     for (int pxl : {4, 8, 16}) {
-        if ((nl == 4) == (pxl == 16) || (pb == 4 && pxl == 4)) continue;         // (the instantiations on offer: 4 or 8 pixels a lane with 4 columns -- 8 of four bytes --, 16 with 2)
+        if ((nl == 4 && pxl == 16) || (nl == 2 && pxl == 4) || (pb == 4 && pxl == 4)) continue;   // (the instantiations on offer: 4 or 8 pixels a lane with 4 columns -- 8 of four bytes --, 8 or 16 with 2)
         int spw = 0;
         for (int cand = 64; cand >= (nl == 4 ? 16 : 4) && !spw; --cand) if (deal(pxl, cand, false)) spw = cand;
         if (!spw) continue;
-        const double cost = (11.0 * pxl + 50.0 + 24.0 * tph) / spw;              // instructions a source row: conversion + the rest, per strip
+        // instructions a source row: conversion + the rest, per strip.  (Two columns a lane: 16 pixels a lane measured 1.5-1.7x
+        // its instruction count against 8 -- one wave a SIMD fewer, and its LDS rows are written 8 dwords a lane, an 8-way bank
+        // conflict: 67 % of the LDS cycles of the first version, profiles/r03/n_rgbin_shrink_many_tap_pmc_summary.txt)
+        const double cost = (11.0 * pxl + 50.0 + 24.0 * tph) / spw * (nl == 2 && pxl == 16 ? 1.6 : 1.0);
         if (cost < best_cost) { best_cost = cost; best_pxl = pxl; best_spw = spw; }
     }
-    if (nl == 4 && pb == 3 && (env("TTS_RGBIN_SHRINK_PXL") == 4 || env("TTS_RGBIN_SHRINK_PXL") == 8)) {
+    if ((nl == 4 && pb == 3 && (env("TTS_RGBIN_SHRINK_PXL") == 4 || env("TTS_RGBIN_SHRINK_PXL") == 8)) ||
+        (nl == 2 && (env("TTS_RGBIN_SHRINK_PXL") == 8 || env("TTS_RGBIN_SHRINK_PXL") == 16))) {
         best_pxl = env("TTS_RGBIN_SHRINK_PXL"); best_spw = 0;
-        for (int cand = 64; cand >= 16 && !best_spw; --cand) if (deal(best_pxl, cand, false)) best_spw = cand;
+        for (int cand = 64; cand >= (nl == 4 ? 16 : 4) && !best_spw; --cand) if (deal(best_pxl, cand, false)) best_spw = cand;
     }
     bool ok = best_pxl != 0 && best_spw != 0 && deal(best_pxl, best_spw, true);
     // per source row: the output rows whose filters hold it (a run of rows: positions do not decrease), its tap in each,
@@ -555,9 +559,9 @@ int rgbin_shrink_launch(const RgbInShrinkPlan *p, const uint8_t *src, uint8_t *d
     int nseg = int(std::max<int64_t>(1, std::min<int64_t>((int64_t(4) * 3072 + waves - 1) / waves, std::max(1, rows / min_rows))));
     if (p->nl == 2) {
         // Many taps: a segment starts a whole vertical filter early (49 rows for the reference's thumbnails), so short segments
-        // cost real work, and the launch is a round or two of the chip's resident waves (3 a SIMD; 2 at 25 tap pairs), so a
+        // cost real work, and the launch is a round or two of the chip's resident waves (2 to 4 a SIMD), so a
         // last round that is mostly empty costs as much as a full one.  Take the count with the least rounds x rows a wave.
-        const int64_t slots = int64_t(p->tph > 19 ? 2 : 3) * 4 * 256;
+        const int64_t slots = int64_t(p->pxl == 8 ? (p->tph > 13 ? 3 : 4) : (p->tph > 19 ? 2 : 3)) * 4 * 256;   // (by the instantiations' registers)
         double best = 1e30;
         for (int cand = 1; cand <= std::max(1, rows / std::max(16, p->vt_max)); ++cand) {
             const int sr = (rows + cand - 1) / cand;
@@ -569,10 +573,12 @@ int rgbin_shrink_launch(const RgbInShrinkPlan *p, const uint8_t *src, uint8_t *d
     w.seg_rows = (rows + nseg - 1) / nseg;
     w.nseg = (rows + w.seg_rows - 1) / w.seg_rows;
     if (p->nl == 2) {
-#define TTS_SHRINK2(TPH_) (p->pb == 4 ? (p->kp == 6 ? rgbin_shrink_kernel<16, TPH_, 6, 2, 4> : rgbin_shrink_kernel<16, TPH_, 8, 2, 4>) \
-                                      : (p->kp == 6 ? rgbin_shrink_kernel<16, TPH_, 6, 2> : rgbin_shrink_kernel<16, TPH_, 8, 2>))
+#define TTS_SHRINK2P(PXL_, TPH_) (p->pb == 4 ? (p->kp == 6 ? rgbin_shrink_kernel<PXL_, TPH_, 6, 2, 4> : rgbin_shrink_kernel<PXL_, TPH_, 8, 2, 4>) \
+                                             : (p->kp == 6 ? rgbin_shrink_kernel<PXL_, TPH_, 6, 2> : rgbin_shrink_kernel<PXL_, TPH_, 8, 2>))
+#define TTS_SHRINK2(TPH_) (p->pxl == 8 ? TTS_SHRINK2P(8, TPH_) : TTS_SHRINK2P(16, TPH_))
         auto fn2 = p->tph == 7 ? TTS_SHRINK2(7) : p->tph == 10 ? TTS_SHRINK2(10) : p->tph == 13 ? TTS_SHRINK2(13) : p->tph == 19 ? TTS_SHRINK2(19) : TTS_SHRINK2(25);
 #undef TTS_SHRINK2
+#undef TTS_SHRINK2P
         return launch_shrink("rgbin_shrink_kernel", fn2, dim3(unsigned((waves + kBlock / 64 - 1) / (kBlock / 64)), unsigned(w.nseg), 1), dim3(kBlock), st,
                              src, dst, static_cast<const int32_t *>(p->d_tab), w);
     }

@@ -53,6 +53,7 @@ CASES = {
     "thumbref_rgbain": ("scale=320x180:force_original_aspect_ratio=decrease,pad=320x180:-1:-1:color=black,format=yuv420p", 1920, 1080, 8294400 + 86400),   # ... from rgba frames
     "thumbref_portrait_rgbin": ("scale=320x180:force_original_aspect_ratio=decrease,pad=320x180:-1:-1:color=black,format=yuv420p", 1080, 1920, 6220800 + 86400),
     "portrait_rgbin_inctx": ("scale=1080:1920:force_original_aspect_ratio=increase,crop=1080:1920,format=yuvj420p", 1920, 1080, 608 * 1080 * 3 + 3110400),
+    "quarter_rgbin": ("scale=480:270", 1920, 1080, 6220800 + 194400),                   # 4x from RGB: 17 taps
     "portrait_rgbin_yuvj": ("scale=1080:1920:force_original_aspect_ratio=increase,crop=1080:1920,format=yuv420p,format=yuvj420p", 1920, 1080, 608 * 1080 * 3 + 3110400),
     "cvt_yuvj": ("format=yuvj420p", 1920, 1080, 3110400 * 2),                               # range step alone
     "thumbref_yuvj": ("scale=320x180:force_original_aspect_ratio=decrease,pad=320x180:-1:-1:color=black,format=yuv420p,format=yuvj420p", 1920, 1080, 3110400 + 86400),   # the reference's chain + the mjpeg encoder's range pass (fused into the store)
@@ -76,7 +77,7 @@ CASES = {
 }
 
 
-IN_FMT = {"cvt_rgbin_yuvj": "rgb24", "cvt_rgbain": "rgba", "thumbref_rgbin_inctx": "rgb24", "thumbref_rgbain": "rgba", "thumbref_portrait_rgbin": "rgb24", "portrait_rgbin_inctx": "rgb24", "thumbref_rgbin": "rgb24", "thumbref_rgbin_yuvj": "rgb24", "portrait_rgbin_yuvj": "rgb24", "portrait_rgbin": "rgb24", "stretch_rgbin": "rgb24", "cvt_rgbin": "rgb24", "half_rgbin": "rgb24", "web_rgbin": "rgb24", "thumb_rgbin": "rgb24", "cvt_bgrin": "bgr24"}
+IN_FMT = {"quarter_rgbin": "rgb24", "cvt_rgbin_yuvj": "rgb24", "cvt_rgbain": "rgba", "thumbref_rgbin_inctx": "rgb24", "thumbref_rgbain": "rgba", "thumbref_portrait_rgbin": "rgb24", "portrait_rgbin_inctx": "rgb24", "thumbref_rgbin": "rgb24", "thumbref_rgbin_yuvj": "rgb24", "portrait_rgbin_yuvj": "rgb24", "portrait_rgbin": "rgb24", "stretch_rgbin": "rgb24", "cvt_rgbin": "rgb24", "half_rgbin": "rgb24", "web_rgbin": "rgb24", "thumb_rgbin": "rgb24", "cvt_bgrin": "bgr24"}
 
 
 def plan_for(case):
