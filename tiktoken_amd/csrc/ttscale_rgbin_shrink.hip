@@ -40,6 +40,7 @@ struct RgbInShrinkArgs {
     int32_t src_stride, dst_stride[2];
     uint32_t src_origin;
     uint32_t dst_origin[2];            // the picture's origin inside the canvas (a pad), luma / chroma planes, in bytes
+    int32_t w128;                      // every lane's piece of a row starts on a multiple of 8 samples (8 pixels a lane): vector LDS writes
     int32_t range15;                   // the converting context writes yuvj420p (tts_geom.sc_range): lum / chrRangeToJpeg_c on the 15-bit rows
     float cy[4];                       // rgb24ToY_c: coefficients of R, G, B x 2^-9 and (2 bias + 1) / 1024
     float cu[4], cv[4];                // rgb24ToUV_half_c: coefficients x 2^-10 and 2^-11 (see the kernel)
@@ -66,8 +67,9 @@ __global__ __launch_bounds__(kBlock, NL == 2 ? 2 : KP == 6 ? 4 : 3) void rgbin_s
     constexpr int ST = NL + NC + (NL + NC) * TPH + 1;                // words of a strip's table entry
     // every row twice: as pairs (s0 s1)(s2 s3).. and, one halfword on, as (s1 s2)(s3 s4)..: a window that starts on an
     // odd sample reads the second copy, so that every tap pair of every window is ONE aligned dword (no v_perm)
-    __shared__ uint32_t ldsy[kBlock / 64][2 * CBL];
-    __shared__ uint32_t ldsc[kBlock / 64][2][2 * CBC];
+    __shared__ __attribute__((aligned(16))) uint32_t ldsy[kBlock / 64][2 * CBL];
+    __shared__ __attribute__((aligned(16))) uint32_t ldsc[kBlock / 64][2][2 * CBC];
+    static_assert((2 * CBL) % 4 == 0 && CBL % 4 == 0 && (2 * CBC) % 4 == 0 && CBC % 2 == 0, "a lane's 16-byte (luma) and 8-byte (chroma) row pieces stay aligned in both copies");
     const int wave = __builtin_amdgcn_readfirstlane(int(threadIdx.x >> 6)), lane = int(threadIdx.x & 63);
     const int wid = int(blockIdx.x) * (kBlock / 64) + wave;
     const int g0 = wid * a.spw, seg = int(blockIdx.y);
@@ -199,7 +201,31 @@ __global__ __launch_bounds__(kBlock, NL == 2 ? 2 : KP == 6 ? 4 : 3) void rgbin_s
             }
             __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");   // (the previous row's window reads are done)
             __builtin_amdgcn_wave_barrier();
-            if (conv) {
+            if (PXL == 8 && a.w128) {
+                // Every lane's piece of the row starts on a multiple of 8 samples (the host says so: a.w128): one ds_write_b128 a copy
+                // (b64 for the chroma rows) instead of dword writes 4 dwords apart, a 4-way bank conflict each.  The odd copy's
+                // first dword is (s[-1], s[0]): the low half written here is not this lane's -- the neighbour's halfword store,
+                // the NEXT instruction of every lane, puts the right sample there.
+                if (conv) {
+                    if constexpr (PXL == 8) {
+                        *static_cast<u32x4_t *>(__builtin_assume_aligned(Y + (cs >> 1), 16)) = u32x4_t{pky[0], pky[1], pky[2], pky[3]};
+                        uint32_t *ob = Y + CBL + (cs >> 1);
+                        *static_cast<u32x4_t *>(__builtin_assume_aligned(ob, 16)) =
+                            u32x4_t{pky[0] << 16, __builtin_amdgcn_perm(pky[1], pky[0], 0x05040302), __builtin_amdgcn_perm(pky[2], pky[1], 0x05040302), __builtin_amdgcn_perm(pky[3], pky[2], 0x05040302)};
+                        asm volatile("" ::: "memory");               // (the halfword store after the vector store that covers its neighbour's)
+                        reinterpret_cast<uint16_t *>(ob + 4)[0] = uint16_t(pky[3] >> 16);
+#pragma unroll
+                        for (int p = 0; p < 2; ++p) {
+                            const uint32_t (&pk)[NPC] = p ? pkv : pku;
+                            uint32_t *ce = (p ? V : U) + (cs >> 2), *co = (p ? V : U) + CBC + (cs >> 2);
+                            *static_cast<u32x2_t *>(__builtin_assume_aligned(ce, 8)) = u32x2_t{pk[0], pk[1]};
+                            *static_cast<u32x2_t *>(__builtin_assume_aligned(co, 8)) = u32x2_t{pk[0] << 16, __builtin_amdgcn_perm(pk[1], pk[0], 0x05040302)};
+                            asm volatile("" ::: "memory");
+                            reinterpret_cast<uint16_t *>(co + 2)[0] = uint16_t(pk[1] >> 16);
+                        }
+                    }
+                }
+            } else if (conv) {
                 // even copy, then the odd one: dword m = (s[2m + 1], s[2m + 2]); its first and last halfword belong to the neighbours' dwords
                 {
                     uint32_t *ea = Y + (cs >> 1), *ob = Y + CBL + 1 + (cs >> 1);
@@ -414,6 +440,7 @@ RgbInShrinkPlan *rgbin_shrink_create(const tts_geom &g, const AxisFilter &lh, co
     a.o_wave = uint32_t(t.size());
     t.resize(t.size() + size_t(4) * 64 * strips, 0);
     const int avail = g.in_w - g.pre_x;                                          // pixels from the pre-cropped origin to the end of a source row: a lane's PXL pixels stay inside them
+    bool aligned8 = true;
     auto deal = [&](int pxl, int spw, bool write) {
         if (avail < pxl) return false;
         for (int sA = 0; sA < strips; ++sA) {
@@ -424,7 +451,10 @@ RgbInShrinkPlan *rgbin_shrink_create(const tts_geom &g, const AxisFilter &lh, co
                 const int first = fd ? 0 : sA, count = std::min(spw - i, strips - first), lastS = first + count - 1;
                 // (a piece whose run ends near the end of a row starts early enough for its last lane to stay inside the row)
                 const int top = (avail - pxl) & ~3;
-                const int lo = std::min(slo[first], top);
+                int lo = std::min(slo[first], top);
+                // (8 pixels a lane: pieces start so that every lane, the slid last one included, lies a multiple of 8 pixels
+                // from the piece's first -- the kernel then writes its LDS rows as whole vectors)
+                if (pxl == 8 && ((top - lo) & 7)) { if (lo >= 4) lo -= 4; else if (write) aligned8 = false; }
                 int hi = 0;
                 for (int q = first; q <= lastS; ++q) hi = std::max(hi, shi[q]);
                 const int lanes = (hi - lo + pxl - 1) / pxl;
@@ -462,6 +492,7 @@ RgbInShrinkPlan *rgbin_shrink_create(const tts_geom &g, const AxisFilter &lh, co
         for (int cand = 64; cand >= (nl == 4 ? 16 : 4) && !best_spw; --cand) if (deal(best_pxl, cand, false)) best_spw = cand;
     }
     bool ok = best_pxl != 0 && best_spw != 0 && deal(best_pxl, best_spw, true);
+    a.w128 = best_pxl == 8 && aligned8 && !env("TTS_RGBIN_SHRINK_NO_W128") ? 1 : 0;
     // per source row: the output rows whose filters hold it (a run of rows: positions do not decrease), its tap in each,
     // how many of them it completes, and where a segment that starts at this row has to begin
     std::vector<int> pl(static_cast<size_t>(oh), 0), ll(static_cast<size_t>(oh), 0), pc(static_cast<size_t>(och), 0), lcv(static_cast<size_t>(och), 0);
