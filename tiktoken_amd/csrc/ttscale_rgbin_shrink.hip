@@ -201,27 +201,41 @@ __global__ __launch_bounds__(kBlock, NL == 2 ? 2 : KP == 6 ? 4 : 3) void rgbin_s
             }
             __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");   // (the previous row's window reads are done)
             __builtin_amdgcn_wave_barrier();
-            if (PXL == 8 && a.w128) {
-                // Every lane's piece of the row starts on a multiple of 8 samples (the host says so: a.w128): one ds_write_b128 a copy
-                // (b64 for the chroma rows) instead of dword writes 4 dwords apart, a 4-way bank conflict each.  The odd copy's
-                // first dword is (s[-1], s[0]): the low half written here is not this lane's -- the neighbour's halfword store,
-                // the NEXT instruction of every lane, puts the right sample there.
+            if (PXL >= 8 && a.w128) {
+                // Every lane's piece of the row starts on a multiple of 8 samples (the host says so: a.w128): ds_write_b128 for each
+                // four dwords of a copy (b64 for the chroma rows) instead of dword writes 4 or 8 dwords apart, a 4- / 8-way bank
+                // conflict each.  The odd copy's first dword is (s[-1], s[0]): the low half written here is not this lane's --
+                // the neighbour's halfword store, the NEXT instruction of every lane, puts the right sample there.
                 if (conv) {
-                    if constexpr (PXL == 8) {
-                        *static_cast<u32x4_t *>(__builtin_assume_aligned(Y + (cs >> 1), 16)) = u32x4_t{pky[0], pky[1], pky[2], pky[3]};
-                        uint32_t *ob = Y + CBL + (cs >> 1);
-                        *static_cast<u32x4_t *>(__builtin_assume_aligned(ob, 16)) =
-                            u32x4_t{pky[0] << 16, __builtin_amdgcn_perm(pky[1], pky[0], 0x05040302), __builtin_amdgcn_perm(pky[2], pky[1], 0x05040302), __builtin_amdgcn_perm(pky[3], pky[2], 0x05040302)};
+                    if constexpr (PXL >= 8) {
+                        uint32_t *ea = Y + (cs >> 1), *ob = Y + CBL + (cs >> 1);
+#pragma unroll
+                        for (int q = 0; q < NP / 4; ++q)
+                            *static_cast<u32x4_t *>(__builtin_assume_aligned(ea + 4 * q, 16)) = u32x4_t{pky[4 * q], pky[4 * q + 1], pky[4 * q + 2], pky[4 * q + 3]};
+                        uint32_t od[NP];                                 // the odd copy's dwords of this lane: (s[2m - 1], s[2m])
+                        od[0] = pky[0] << 16;
+#pragma unroll
+                        for (int k = 1; k < NP; ++k) od[k] = __builtin_amdgcn_perm(pky[k], pky[k - 1], 0x05040302);
+#pragma unroll
+                        for (int q = 0; q < NP / 4; ++q)
+                            *static_cast<u32x4_t *>(__builtin_assume_aligned(ob + 4 * q, 16)) = u32x4_t{od[4 * q], od[4 * q + 1], od[4 * q + 2], od[4 * q + 3]};
                         asm volatile("" ::: "memory");               // (the halfword store after the vector store that covers its neighbour's)
-                        reinterpret_cast<uint16_t *>(ob + 4)[0] = uint16_t(pky[3] >> 16);
+                        reinterpret_cast<uint16_t *>(ob + NP)[0] = uint16_t(pky[NP - 1] >> 16);
 #pragma unroll
                         for (int p = 0; p < 2; ++p) {
                             const uint32_t (&pk)[NPC] = p ? pkv : pku;
                             uint32_t *ce = (p ? V : U) + (cs >> 2), *co = (p ? V : U) + CBC + (cs >> 2);
-                            *static_cast<u32x2_t *>(__builtin_assume_aligned(ce, 8)) = u32x2_t{pk[0], pk[1]};
-                            *static_cast<u32x2_t *>(__builtin_assume_aligned(co, 8)) = u32x2_t{pk[0] << 16, __builtin_amdgcn_perm(pk[1], pk[0], 0x05040302)};
+                            uint32_t oc[NPC];
+                            oc[0] = pk[0] << 16;
+#pragma unroll
+                            for (int k = 1; k < NPC; ++k) oc[k] = __builtin_amdgcn_perm(pk[k], pk[k - 1], 0x05040302);
+#pragma unroll
+                            for (int q = 0; q < NPC / 2; ++q) {
+                                *static_cast<u32x2_t *>(__builtin_assume_aligned(ce + 2 * q, 8)) = u32x2_t{pk[2 * q], pk[2 * q + 1]};
+                                *static_cast<u32x2_t *>(__builtin_assume_aligned(co + 2 * q, 8)) = u32x2_t{oc[2 * q], oc[2 * q + 1]};
+                            }
                             asm volatile("" ::: "memory");
-                            reinterpret_cast<uint16_t *>(co + 2)[0] = uint16_t(pk[1] >> 16);
+                            reinterpret_cast<uint16_t *>(co + NPC)[0] = uint16_t(pk[NPC - 1] >> 16);
                         }
                     }
                 }
@@ -452,9 +466,9 @@ RgbInShrinkPlan *rgbin_shrink_create(const tts_geom &g, const AxisFilter &lh, co
                 // (a piece whose run ends near the end of a row starts early enough for its last lane to stay inside the row)
                 const int top = (avail - pxl) & ~3;
                 int lo = std::min(slo[first], top);
-                // (8 pixels a lane: pieces start so that every lane, the slid last one included, lies a multiple of 8 pixels
+                // (8 or 16 pixels a lane: pieces start so that every lane, the slid last one included, lies a multiple of 8 pixels
                 // from the piece's first -- the kernel then writes its LDS rows as whole vectors)
-                if (pxl == 8 && ((top - lo) & 7)) { if (lo >= 4) lo -= 4; else if (write) aligned8 = false; }
+                if (pxl >= 8 && ((top - lo) & 7)) { if (lo >= 4) lo -= 4; else if (write) aligned8 = false; }
                 int hi = 0;
                 for (int q = first; q <= lastS; ++q) hi = std::max(hi, shi[q]);
                 const int lanes = (hi - lo + pxl - 1) / pxl;
@@ -480,10 +494,10 @@ RgbInShrinkPlan *rgbin_shrink_create(const tts_geom &g, const AxisFilter &lh, co
         int spw = 0;
         for (int cand = 64; cand >= (nl == 4 ? 16 : 4) && !spw; --cand) if (deal(pxl, cand, false)) spw = cand;
         if (!spw) continue;
-        // instructions a source row: conversion + the rest, per strip.  (Two columns a lane: 16 pixels a lane measured 1.5-1.7x
-        // its instruction count against 8 -- one wave a SIMD fewer, and its LDS rows are written 8 dwords a lane, an 8-way bank
-        // conflict: 67 % of the LDS cycles of the first version, profiles/r03/n_rgbin_shrink_many_tap_pmc_summary.txt)
-        const double cost = (11.0 * pxl + 50.0 + 24.0 * tph) / spw * (nl == 2 && pxl == 16 ? 1.6 : 1.0);
+        // instructions a source row: conversion + the rest, per strip.  (Two columns a lane: 16 pixels a lane measures about
+        // 1.25x its instruction count against 8 -- one wave a SIMD fewer, and b128 LDS writes 32 bytes apart; before those
+        // vector writes it was 1.6x: profiles/r03/q_rgbin_many_tap_8_vs_16_pixels_a_lane.txt, q_rgbin_lds_vector_writes.txt)
+        const double cost = (11.0 * pxl + 50.0 + 24.0 * tph) / spw * (nl == 2 && pxl == 16 ? 1.25 : 1.0);
         if (cost < best_cost) { best_cost = cost; best_pxl = pxl; best_spw = spw; }
     }
     if ((nl == 4 && pb == 3 && (env("TTS_RGBIN_SHRINK_PXL") == 4 || env("TTS_RGBIN_SHRINK_PXL") == 8)) ||
@@ -492,7 +506,7 @@ RgbInShrinkPlan *rgbin_shrink_create(const tts_geom &g, const AxisFilter &lh, co
         for (int cand = 64; cand >= (nl == 4 ? 16 : 4) && !best_spw; --cand) if (deal(best_pxl, cand, false)) best_spw = cand;
     }
     bool ok = best_pxl != 0 && best_spw != 0 && deal(best_pxl, best_spw, true);
-    a.w128 = best_pxl == 8 && aligned8 && !env("TTS_RGBIN_SHRINK_NO_W128") ? 1 : 0;
+    a.w128 = best_pxl >= 8 && aligned8 && !env("TTS_RGBIN_SHRINK_NO_W128") ? 1 : 0;
     // per source row: the output rows whose filters hold it (a run of rows: positions do not decrease), its tap in each,
     // how many of them it completes, and where a segment that starts at this row has to begin
     std::vector<int> pl(static_cast<size_t>(oh), 0), ll(static_cast<size_t>(oh), 0), pc(static_cast<size_t>(och), 0), lcv(static_cast<size_t>(och), 0);
