@@ -788,3 +788,26 @@ def test_full_range_source(tts, oracle, vf, iw, ih, steps):
         assert bad.size == 0, "%s %dx%d %s [%s]: %d bytes differ, first at %d" % (vf, iw, ih, pat, plan.kernel_name(0), bad.size, bad[0])
         same = np.array_equal(got, limited.run_batch(d).cpu().numpy())
         assert same == (steps == (0, 0) and "pad" not in vf), "a limited-range source of the same bytes: %s" % same
+
+
+@pytest.mark.parametrize("no_union", [0, 1])
+@pytest.mark.parametrize("vf,iw,ih,n", [
+    ("scale=640:360", 1280, 720, 3),                      # exact 2x: a lane's four 12-byte windows one dword apart
+    ("scale=1920:1080", 3840, 2160, 2),                   # ... the four-rows-in-flight instantiation
+    ("scale=960:540,crop=900:500:30:20", 1920, 1080, 2),  # a crop behind it: strips that start off the lattice's origin
+    ("scale=642:360", 1280, 720, 2),                      # not quite 2x: the lattice holds for some waves only
+])
+def test_exact_2x_shrink_one_run_window_read(tts, oracle, monkeypatch, vf, iw, ih, n, no_union):
+    """strip_lds_kernel, two columns a 12-byte window: waves whose lanes all have their four windows one dword apart read the
+    run of 8 dwords once (the LDS bank conflicts of the exact 2x shrink); TTS_NO_UNION=1 keeps the window-by-window
+    read.  Both against the oracle."""
+    import torch
+    monkeypatch.setenv("TTS_NO_UNION", str(no_union))
+    plan = tts.Plan.from_vf(vf, iw, ih)
+    assert plan.kernel_name(0).startswith("strip_lds<8,8,grouped2"), plan.kernel_name(0)
+    for pat in ("random", "impulse"):
+        src = synth.frames(pat, iw, ih, n)
+        got = plan.run_batch(torch.from_numpy(src).cuda()).cpu().numpy()
+        want = oracle.run_chain(plan.geom, src)
+        bad = np.flatnonzero(got != want)
+        assert bad.size == 0, "%s %dx%d %s: %d bytes differ, first at %d" % (vf, iw, ih, pat, bad.size, bad[0])

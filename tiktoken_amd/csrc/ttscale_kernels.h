@@ -64,6 +64,7 @@ struct StripArgs {
     uint32_t grid_scaler;
     uint32_t *queue;
     RangeStep15 r15;               // RNG instantiations only (strip_lds_kernel, column_lds_kernel)
+    int32_t  no_union;             // strip_lds_kernel, two columns a 12-byte window: never read a lane's four windows as one run (A/B knob TTS_NO_UNION)
     int32_t  y16;                  // column walk only: class 0 (luma) stores its UNCLIPPED vertical sums as int16 (2 bytes a column): the
                                    // intermediate of the packed-RGB thumbnail path (ttscale_rgb.hip rgb_scratch_convert_kernel)
     uint64_t *dbg;                 // -DTTS_EXPERIMENTS builds: (start, end) clock of every workgroup of strip_lds_kernel; else null, unused
@@ -584,6 +585,19 @@ __global__ __launch_bounds__(kMaxLdsBlock, (GC == 4 && R == 4 && LW == 4) ? 8 : 
         }
     }
 
+    // Exact 2x shrinks (4K -> 1080p): a lane's four 12-byte windows lie ONE dword apart, so its 16 aligned window dwords are 7
+    // distinct ones, and neighbouring lanes read 4 dwords apart -- a 4-way bank conflict on every read, 80 % of the launch on
+    // the LDS pipe (profiles/r03/q_planar_lds_counters.txt).  A wave all of whose lanes have their windows on that lattice
+    // (every wave but those that hold a strip at a row's end) reads the run of 8 dwords once: half the LDS instructions, and
+    // 6 v_alignbyte instead of 12.
+    [[maybe_unused]] bool one_run = false;
+    if constexpr (GC == 2 && LW == 8) {
+        bool mine = true;
+#pragma unroll
+        for (int j = 1; j < NW; ++j) mine &= lpos[j] == lpos[0] + 4u * uint32_t(j) && ((phase[j] ^ phase[0]) & 3u) == 0;
+        one_run = !a.no_union && __builtin_amdgcn_ballot_w64(!mine) == 0;   // wave-uniform
+    }
+
     uint32_t ring[N][R / 2];
 #pragma unroll
     for (int i = 0; i < N; ++i)
@@ -638,15 +652,33 @@ __global__ __launch_bounds__(kMaxLdsBlock, (GC == 4 && R == 4 && LW == 4) ? 8 : 
             wait_vm_plus<(D - 1) * NDMA>(younger);
             constexpr int GD = G4 && LW >= 6 ? 4 : 3;
             uint32_t wk[NW][GD];                                // the aligned dwords holding each window
+            [[maybe_unused]] bool aligned_already = false;
             if constexpr (G4 && LW >= 6) {
-                u32x2_t wv[NW][2];
-                // (ds_read2's 8-bit dword offsets cannot reach the second slot: its addresses are a few VALU adds)
-                uint32_t lp[NW];
+                bool done = false;
+                if constexpr (GC == 2 && LW == 8) {
+                    if (one_run) {                               // wave-uniform: the four windows as one run of 8 dwords
+                        u32x2_t uv[2][2];
+                        uint32_t up[2] = {lpos[0] + uint32_t(s % D) * uint32_t(kSlotBytes), lpos[0] + uint32_t(s % D) * uint32_t(kSlotBytes) + 16u};
+                        TTS_LDS_READ_WIN4_X2(uv, up);
+                        const uint32_t u[8] = {uv[0][0].x, uv[0][0].y, uv[0][1].x, uv[0][1].y, uv[1][0].x, uv[1][0].y, uv[1][1].x, uv[1][1].y};
+                        uint32_t sh[6];
 #pragma unroll
-                for (int j = 0; j < NW; ++j) lp[j] = lpos[j] + uint32_t(s % D) * uint32_t(kSlotBytes);
-                if constexpr (NW == 2) TTS_LDS_READ_WIN4_X2(wv, lp); else TTS_LDS_READ_WIN4_X4(wv, lp);
+                        for (int m = 0; m < 6; ++m) sh[m] = __builtin_amdgcn_alignbyte(u[m + 1], u[m], phase[0]);
 #pragma unroll
-                for (int j = 0; j < NW; ++j) { wk[j][0] = wv[j][0].x; wk[j][1] = wv[j][0].y; wk[j][2] = wv[j][1].x; wk[j][3] = wv[j][1].y; }
+                        for (int j = 0; j < NW; ++j) { wk[j][0] = sh[j]; wk[j][1] = sh[j + 1]; wk[j][2] = sh[j + 2]; wk[j][3] = 0; }
+                        done = true; aligned_already = true;
+                    }
+                }
+                if (!done) {
+                    u32x2_t wv[NW][2];
+                    // (ds_read2's 8-bit dword offsets cannot reach the second slot: its addresses are a few VALU adds)
+                    uint32_t lp[NW];
+#pragma unroll
+                    for (int j = 0; j < NW; ++j) lp[j] = lpos[j] + uint32_t(s % D) * uint32_t(kSlotBytes);
+                    if constexpr (NW == 2) TTS_LDS_READ_WIN4_X2(wv, lp); else TTS_LDS_READ_WIN4_X4(wv, lp);
+#pragma unroll
+                    for (int j = 0; j < NW; ++j) { wk[j][0] = wv[j][0].x; wk[j][1] = wv[j][0].y; wk[j][2] = wv[j][1].x; wk[j][3] = wv[j][1].y; }
+                }
             } else if constexpr (G4) {
                 TTS_LDS_READ_WIN3_X2(wk, lpos, (s % D) * kSlotBytes);
             } else if constexpr (LW > 4) {
@@ -661,7 +693,7 @@ __global__ __launch_bounds__(kMaxLdsBlock, (GC == 4 && R == 4 && LW == 4) ? 8 : 
 #pragma unroll
                 for (int j = 0; j < NW; ++j) { wk[j][0] = wv[j].x; wk[j][1] = wv[j].y; wk[j][2] = 0; }
             }
-            if constexpr (G4) {                                 // rebuild the two 8- / 12-byte windows
+            if (G4 && !aligned_already) {                       // rebuild the two 8- / 12-byte windows
 #pragma unroll
                 for (int j = 0; j < NW; ++j)
 #pragma unroll

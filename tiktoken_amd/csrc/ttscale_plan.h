@@ -106,6 +106,7 @@ struct Knobs {
     int col_d4 = 1;                   // column walk: v_dot4 on packed bytes with two-digit taps instead of v_perm + v_dot2: 0 never, 1 above 8 tap pairs, 2 wherever the tables exist
     int col_model = 1;                // column walk segment length: 0 = fill rule, 1 = busiest-CU model above 8 tap pairs, 2 = everywhere
     int host_chunk_mb = 128;          // tts_run_host: bytes (source + output) of one pipelined chunk
+    int no_union = 0;                 // strip_lds_kernel (two columns a window): never the one-run read of a lane's four windows (A/B)
     int persist = 0;                  // strip_lds_kernel as a work queue of resident workgroups (experiment; tenths of the resident slots to launch, 10 = all)
     void read()
     {
@@ -116,6 +117,7 @@ struct Knobs {
         exp_srcpitch0 = env_int("TTS_EXP_SRCPITCH0", 0); exp_dstpitch0 = env_int("TTS_EXP_DSTPITCH0", 0);
         exp_stride0 = env_int("TTS_EXP_STRIDE0", 0);
 #endif
+        no_union = env_int("TTS_NO_UNION", 0);
         planewise = env_int("TTS_PLANEWISE", 0);
         span_chunks = env_int("TTS_SPAN_CHUNKS", 0);
         wave_base = env_int("TTS_WAVE_BASE", 0);
@@ -956,6 +958,7 @@ int launch_all(const tts_plan *p, const uint8_t *src, uint8_t *dst, int n, const
         strip_fn fn = pick_strip(ch, p->knobs, a.y16 != 0, range_in_scale);
         if (!fn) return TTS_ERR_UNSUPPORTED;
         if (range_in_scale) set_r15(a, merged, ci);
+        a.no_union = p->knobs.no_union;
         size_t si[2];
         int max_items = 0;
         int64_t total_items = 0;
