@@ -735,6 +735,7 @@ def test_packed_rgb_input_pad_without_scale(tts, oracle, vf, iw, ih, fmt):
 
 RGBIN_YUVJ_CASES = [
     ("format=yuvj420p", 64, 36),                                         # the inserted conversion pass writes full range itself
+    ("format=yuvj420p", 1280, 720),                                      # ... at a size whose batches span row segments (rgbin_walk<..>+range15 for 3-byte pixels)
     ("scale=96:54,format=yuvj420p", 64, 36),                             # ... or the scale does (an enlargement: chroma per pixel)
     ("scale=640:360,format=yuvj420p", 1280, 720),                        # a shrink (chroma from pixel pairs)
     ("crop=100:60:7:3,scale=50:30,pad=64:40:-1:-1:color=red,format=yuvj420p", 128, 72),   # the pad behind it on a yuvj420p link

@@ -1300,6 +1300,8 @@ __device__ __forceinline__ int rgbin_lower_bound(const int32_t *last, int n, int
     return lo;
 }
 
+// RNG: the context writes yuvj420p (tts_geom.sc_range): swscale.c lumRangeToJpeg_c / chrRangeToJpeg_c on the 15-bit samples
+template <bool RNG>
 __global__ __launch_bounds__(kBlock) void rgbin_walk_kernel(const uint8_t *__restrict__ src, uint8_t *__restrict__ dst, const int32_t *__restrict__ tab, const RgbInWalkArgs a)
 {
     const int32_t *last = tab;
@@ -1377,7 +1379,9 @@ __global__ __launch_bounds__(kBlock) void rgbin_walk_kernel(const uint8_t *__res
 #pragma unroll
                 for (int i = 0; i < 8; ++i) {
                     const int s14 = (__mul24(ry, R[i]) + __mul24(gy, G[i]) + __mul24(by, B[i]) + (32 << 14) + (1 << 8)) >> 9;
-                    v[i] = min(2 * s14, 32767) + 64;
+                    int t15 = min(2 * s14, 32767);
+                    if constexpr (RNG) t15 = (__mul24(min(t15, 30189), 19077) - 39057361) >> 14;
+                    v[i] = t15 + 64;
                 }
                 const u32x2_t o = {pack4<7>(v[0], v[1], v[2], v[3]), pack4<7>(v[4], v[5], v[6], v[7])};
                 if (live) gstore_b64(dy + size_t(r) * a.dst_stride[0], o);
@@ -1388,7 +1392,9 @@ __global__ __launch_bounds__(kBlock) void rgbin_walk_kernel(const uint8_t *__res
                 const int sr = R[2 * j] + R[2 * j + 1], sg = G[2 * j] + G[2 * j + 1], sb = B[2 * j] + B[2 * j + 1];
                 const int u14 = (__mul24(ru, sr) + __mul24(gu, sg) + __mul24(bu, sb) + (256 << 15) + (1 << 9)) >> 10;
                 const int v14 = (__mul24(rv, sr) + __mul24(gv, sg) + __mul24(bv, sb) + (256 << 15) + (1 << 9)) >> 10;
-                const uint32_t tu = uint32_t(min(2 * u14, 32767)), tv = uint32_t(min(2 * v14, 32767));
+                int cu = min(2 * u14, 32767), cv = min(2 * v14, 32767);
+                if constexpr (RNG) { cu = (__mul24(min(cu, 30775), 4663) - 9289992) >> 12; cv = (__mul24(min(cv, 30775), 4663) - 9289992) >> 12; }
+                const uint32_t tu = uint32_t(cu), tv = uint32_t(cv);
                 ring[0][j][s / 2] = (s & 1) ? __builtin_amdgcn_perm(tu, ring[0][j][s / 2], 0x05040100) : __builtin_amdgcn_perm(ring[0][j][s / 2], tu, 0x07060100);
                 ring[1][j][s / 2] = (s & 1) ? __builtin_amdgcn_perm(tv, ring[1][j][s / 2], 0x05040100) : __builtin_amdgcn_perm(ring[1][j][s / 2], tv, 0x07060100);
             }
@@ -2213,7 +2219,7 @@ int rgbin_plan_create(const tts_geom &g, RgbInPlan **out)
     }
     // The conversion alone (nothing in the chain resizes, crops or pads): the streaming walk.  Its arithmetic has the
     // one-tap filters folded in, so they are checked to be exactly that: position i, the full weight.
-    if (!rc && three && !p->range15 && !std::getenv("TTS_FORCE_GENERIC") && !(std::getenv("TTS_NO_RGBIN_WALK") && std::atoi(std::getenv("TTS_NO_RGBIN_WALK")))) {   // (no range step in its folded arithmetic)
+    if (!rc && three && !std::getenv("TTS_FORCE_GENERIC") && !(std::getenv("TTS_NO_RGBIN_WALK") && std::atoi(std::getenv("TTS_NO_RGBIN_WALK")))) {
         auto identity = [](const AxisFilter &f, int one) {
             if (f.size != 1) return false;
             for (size_t i = 0; i < f.pos.size(); ++i) if (f.pos[i] != int(i) || f.taps[i] != one) return false;
@@ -2344,7 +2350,7 @@ int rgbin_plan_create(const tts_geom &g, RgbInPlan **out)
                    g.pre_w >= 8 && !std::getenv("TTS_FORCE_GENERIC");
     if (p->yv12) std::snprintf(p->name, sizeof p->name, p->yv12_rows ? "bgr24_yv12_rows" : "bgr24_yv12");
     else if (p->shrink) std::snprintf(p->name, sizeof p->name, "%s", rgbin_shrink_name(p->shrink));
-    else if (p->walk) std::snprintf(p->name, sizeof p->name, "rgbin_walk<%d>", p->cv.size);
+    else if (p->walk) std::snprintf(p->name, sizeof p->name, "rgbin_walk<%d>%s", p->cv.size, p->range15 ? "+range15" : "");
     else if (p->strip) std::snprintf(p->name, sizeof p->name, "rgbin_strip<%d,%d,%d,%d,%dpx>%s", p->lh.size, p->lv.size, p->ch.size, p->cv.size, p->pxl, p->range15 ? "+range15" : "");   // luma taps across / down, chroma taps across / down
     else if (p->tiled) std::snprintf(p->name, sizeof p->name, "rgbin_tile<%d,%d>", p->th[0], p->th[1]);
     else std::snprintf(p->name, sizeof p->name, "rgbin_generic<%d,%d,%d,%d>%s%s", p->lh.size, p->lv.size, p->ch.size, p->cv.size, p->range15 ? "+range15" : "", canvas ? "+rgb_pad" : "");
@@ -2439,7 +2445,7 @@ int rgbin_launch(const RgbInPlan *p, const uint8_t *src, uint8_t *dst, int n, in
         w.nseg = (g.pre_h + w.seg_rows - 1) / w.seg_rows;
         for (int f0 = 0; f0 < n && !rc; f0 += 65535) {
             w.frame0 = f0;
-            rc = launch_rgb("rgbin_walk_kernel", rgbin_walk_kernel, dim3(unsigned((wpr * w.nseg + kBlock / 64 - 1) / (kBlock / 64)), 1, unsigned(std::min(65535, n - f0))),
+            rc = launch_rgb("rgbin_walk_kernel", p->range15 ? rgbin_walk_kernel<true> : rgbin_walk_kernel<false>, dim3(unsigned((wpr * w.nseg + kBlock / 64 - 1) / (kBlock / 64)), 1, unsigned(std::min(65535, n - f0))),
                             dim3(kBlock), 0, st, src, dst, static_cast<const int32_t *>(p->d_walk), w);
         }
         return rc;
