@@ -604,14 +604,29 @@ int rgbin_shrink_launch(const RgbInShrinkPlan *p, const uint8_t *src, uint8_t *d
     int nseg = int(std::max<int64_t>(1, std::min<int64_t>((int64_t(4) * 3072 + waves - 1) / waves, std::max(1, rows / min_rows))));
     if (p->nl == 2) {
         // Many taps: a segment starts a whole vertical filter early (49 rows for the reference's thumbnails), so short segments
-        // cost real work, and the launch is a round or two of the chip's resident waves (2 to 4 a SIMD), so a
-        // last round that is mostly empty costs as much as a full one.  Take the count with the least rounds x rows a wave.
-        const int64_t slots = int64_t(p->pxl == 8 ? (p->tph > 13 ? 3 : 4) : (p->tph > 19 ? 2 : 3)) * 4 * 256;   // (by the instantiations' registers)
+        // cost real work, and the launch is a round or two of the chip's resident waves (2 to 4 a SIMD by the instantiation's
+        // registers), so a last round that is mostly empty costs as much as a full one.  Take the count with the least
+        // rounds x rows a wave (segments no shorter than the tallest filter).
+        const double wps = double(p->pxl <= 8 ? (p->tph > 13 ? 3 : 4) : (p->tph > 19 ? 2 : 3));
+        const int64_t slots = int64_t(wps) * 4 * 256;
         double best = 1e30;
         for (int cand = 1; cand <= std::max(1, rows / std::max(16, p->vt_max)); ++cand) {
             const int sr = (rows + cand - 1) / cand;
             const double cost = double((waves * cand + slots - 1) / slots) * double(sr + p->vt_max);
             if (cost < best) { best = cost; nseg = cand; }
+        }
+        // A launch that leaves most SIMDs with no wave at all -- one thumbnail a call, the reference's use: what counts is how
+        // few rows a wave walks, and a wave alone on its SIMD walks a row in half the time one of three does (measured on R2
+        // from 1080p RGB frames: 1.3 us a row at 0.4 waves a SIMD, 1.6 at 1.2, 1.9 at 1.5, 2.5 at 2.9: about 1.1 + 0.5 k).
+        // Segments down to 8 rows: 122 -> 72 us a call.
+        if (waves * nseg < 4 * 256) {
+            best = 1e30;
+            for (int cand = 1; cand <= std::max(1, rows / 8); ++cand) {
+                const int sr = (rows + cand - 1) / cand;
+                const double k = double(waves) * cand / (4.0 * 256.0);
+                const double cost = double(sr + p->vt_max) * (1.1 + 0.5 * std::min(k, wps)) * std::max(1.0, k / wps);
+                if (cost < best) { best = cost; nseg = cand; }
+            }
         }
     }
     if (p->seg_knob > 0) nseg = std::max(1, std::min(p->seg_knob, rows / 8));
